@@ -1,0 +1,302 @@
+"""ctypes binding of libautomerge_hip.so (include/automerge_hip.h) and a host-side mirror of the
+reference's `Automerge` bulk API (rust/automerge/src/automerge.rs: load :552, get_heads :1300,
+get_changes :1306, hydrate :1415) over batches of documents.
+
+There is no CPU fallback: if the HIP library is missing, importing the engine raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libautomerge_hip.so")
+
+_u8p = C.POINTER(C.c_uint8)
+
+
+class BytesOut(C.Structure):
+    _fields_ = [("data", _u8p), ("len", C.c_size_t)]
+
+
+class ChangeView(C.Structure):
+    _fields_ = [("hash", _u8p), ("raw_bytes", _u8p), ("raw_len", C.c_size_t), ("actor", _u8p), ("actor_len", C.c_size_t),
+                ("seq", C.c_uint64), ("start_op", C.c_uint64), ("num_ops", C.c_uint64), ("timestamp", C.c_int64),
+                ("num_deps", C.c_uint32)]
+
+
+class LoadOpts(C.Structure):
+    _fields_ = [("verify_heads", C.c_int), ("on_partial_load", C.c_int)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_docs", "n_ok", "ops_loaded", "op_rows", "succ_entries", "changes",
+                                          "delete_ops", "encoded_bytes", "change_bytes")]
+
+
+EXPORTS = [
+    "amh_ctx_create", "amh_ctx_destroy", "amh_last_error", "amh_stage_batch", "amh_staged_free", "amh_load_staged",
+    "amh_load_batch", "amh_batch_free", "amh_bytes_free", "amh_doc_status", "amh_batch_get_stats", "amh_heads",
+    "amh_changes", "amh_hydrate_json", "amh_doc_max_op", "amh_merge_batch", "amh_apply_changes", "amh_save_batch",
+    "amh_sync_summaries", "amh_ctx_set_profiling", "amh_ctx_num_kernels", "amh_ctx_kernel_name", "amh_ctx_kernel_time",
+    "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_u64_free",
+]
+
+DOC_ERRORS = {
+    0: "Ok", 1: "Parse", 2: "BadChecksum", 3: "InvalidChangeColumns", 5: "MissingDeps", 6: "DuplicateSeqNumber",
+    20: "InflateDocument(ReadOp)", 21: "InflateDocument(OpsOutOfOrder)", 22: "InflateDocument(MissingActor)",
+    23: "InflateDocument(MismatchingHeads)", 24: "InflateDocument(MissingOps)", 25: "InflateDocument(SuccOutOfOrder)",
+    26: "InflateDocument(InvalidOp)", 30: "InvalidChanges(ChangesOutOfOrder)", 31: "InvalidChanges(MissingChange)",
+    32: "InvalidChanges(ReadChange)", 33: "InvalidChanges(IncorrectMaxOp)", 34: "InvalidChanges(MissingActor)",
+    35: "InvalidChanges(MissingOps)", 90: "TooLarge", 91: "Unsupported",
+}
+
+
+def bind(lib):
+    """Attach argtypes/restypes to a loaded library handle."""
+    vp = C.c_void_p
+    lib.amh_ctx_create.restype = vp
+    lib.amh_ctx_create.argtypes = [C.POINTER(C.c_int), C.c_int]
+    lib.amh_ctx_destroy.argtypes = [vp]
+    lib.amh_last_error.restype = C.c_char_p
+    lib.amh_last_error.argtypes = [vp]
+    lib.amh_stage_batch.restype = vp
+    lib.amh_stage_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t]
+    lib.amh_staged_free.argtypes = [vp]
+    lib.amh_load_staged.restype = vp
+    lib.amh_load_staged.argtypes = [vp, vp, C.POINTER(LoadOpts)]
+    lib.amh_load_batch.restype = vp
+    lib.amh_load_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(LoadOpts)]
+    lib.amh_batch_free.argtypes = [vp]
+    lib.amh_bytes_free.argtypes = [C.POINTER(BytesOut)]
+    lib.amh_doc_status.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
+    lib.amh_batch_get_stats.argtypes = [vp, C.POINTER(BatchStats)]
+    lib.amh_heads.argtypes = [vp, C.c_uint32, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    lib.amh_changes.argtypes = [vp, C.c_uint32, C.POINTER(ChangeView), C.POINTER(C.c_size_t)]
+    lib.amh_hydrate_json.argtypes = [vp, C.c_uint32, C.POINTER(BytesOut)]
+    lib.amh_doc_max_op.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
+    lib.amh_ctx_set_profiling.argtypes = [vp, C.c_int]
+    lib.amh_ctx_kernel_name.restype = C.c_char_p
+    lib.amh_ctx_kernel_name.argtypes = [C.c_int]
+    lib.amh_ctx_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    lib.amh_ctx_reset_profile.argtypes = [vp]
+    lib.amh_gen_map_docs.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                     C.POINTER(BytesOut), C.POINTER(C.POINTER(C.c_uint64))]
+    lib.amh_u64_free.argtypes = [C.POINTER(C.c_uint64)]
+    lib.amh_sync_summaries.argtypes = [vp, vp, C.POINTER(BytesOut)]
+    return lib
+
+
+def load_library(path=None):
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback for the engine.")
+    return bind(C.CDLL(path))
+
+
+class AutomergeError(Exception):
+    """Per-document failure, carrying the reference's error kind (automerge/src/error.rs:7-62)."""
+
+    def __init__(self, kind, msg):
+        self.kind = kind
+        self.kind_name = DOC_ERRORS.get(kind, str(kind))
+        super().__init__(f"{self.kind_name}: {msg}")
+
+
+class EngineError(Exception):
+    pass
+
+
+class Batch:
+    """N loaded documents (amh_batch)."""
+
+    def __init__(self, engine, handle, n):
+        self.engine = engine
+        self.h = handle
+        self.n = n
+
+    def close(self):
+        if self.h:
+            self.engine.lib.amh_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.n
+
+    def status(self, i):
+        kind = C.c_int()
+        msg = C.c_char_p()
+        rc = self.engine.lib.amh_doc_status(self.h, i, C.byref(kind), C.byref(msg))
+        if rc != 0:
+            raise EngineError(f"amh_doc_status failed: {rc}")
+        return kind.value, (msg.value or b"").decode()
+
+    def check(self, i):
+        kind, msg = self.status(i)
+        if kind != 0:
+            raise AutomergeError(kind, msg)
+
+    def get_heads(self, i):
+        self.check(i)
+        p = _u8p()
+        n = C.c_size_t()
+        rc = self.engine.lib.amh_heads(self.h, i, C.byref(p), C.byref(n))
+        if rc != 0:
+            raise EngineError(f"amh_heads failed: {rc}")
+        raw = C.string_at(p, 32 * n.value)
+        return [raw[k:k + 32] for k in range(0, len(raw), 32)]
+
+    def get_changes(self, i):
+        self.check(i)
+        n = C.c_size_t(0)
+        rc = self.engine.lib.amh_changes(self.h, i, None, C.byref(n))
+        if rc != 0:
+            raise EngineError(f"amh_changes failed: {rc}")
+        arr = (ChangeView * max(1, n.value))()
+        cap = C.c_size_t(n.value)
+        rc = self.engine.lib.amh_changes(self.h, i, arr, C.byref(cap))
+        if rc != 0:
+            raise EngineError(f"amh_changes failed: {rc}")
+        out = []
+        for k in range(cap.value):
+            v = arr[k]
+            out.append(dict(hash=C.string_at(v.hash, 32), raw=C.string_at(v.raw_bytes, v.raw_len),
+                            actor=C.string_at(v.actor, v.actor_len), seq=v.seq, start_op=v.start_op, len=v.num_ops,
+                            timestamp=v.timestamp, num_deps=v.num_deps))
+        return out
+
+    def hydrate_json(self, i):
+        self.check(i)
+        o = BytesOut()
+        rc = self.engine.lib.amh_hydrate_json(self.h, i, C.byref(o))
+        if rc != 0:
+            raise EngineError(f"amh_hydrate_json failed: {rc}")
+        s = C.string_at(o.data, o.len).decode("utf-8")
+        self.engine.lib.amh_bytes_free(C.byref(o))
+        return s
+
+    def max_op(self, i):
+        self.check(i)
+        v = C.c_uint64()
+        rc = self.engine.lib.amh_doc_max_op(self.h, i, C.byref(v))
+        if rc != 0:
+            raise EngineError(f"amh_doc_max_op failed: {rc}")
+        return v.value
+
+    def stats(self):
+        s = BatchStats()
+        rc = self.engine.lib.amh_batch_get_stats(self.h, C.byref(s))
+        if rc != 0:
+            raise EngineError(f"amh_batch_get_stats failed: {rc}")
+        return {name: getattr(s, name) for name, _ in BatchStats._fields_}
+
+
+class Staged:
+    def __init__(self, engine, handle, n):
+        self.engine, self.h, self.n = engine, handle, n
+
+    def close(self):
+        if self.h:
+            self.engine.lib.amh_staged_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One context = one GPU (amh_ctx)."""
+
+    def __init__(self, gpu=0, lib=None):
+        self.lib = lib if lib is not None else load_library()
+        ids = (C.c_int * 1)(gpu)
+        self.ctx = self.lib.amh_ctx_create(ids, 1)
+        if not self.ctx:
+            raise EngineError("amh_ctx_create failed: " + (self.lib.amh_last_error(None) or b"").decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.amh_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self):
+        return (self.lib.amh_last_error(self.ctx) or b"").decode()
+
+    @staticmethod
+    def _pack(docs):
+        n = len(docs)
+        ptrs = (C.c_char_p * max(1, n))(*docs) if n else (C.c_char_p * 1)()
+        lens = (C.c_size_t * max(1, n))(*[len(d) for d in docs]) if n else (C.c_size_t * 1)()
+        return ptrs, lens, n
+
+    def stage(self, docs):
+        ptrs, lens, n = self._pack(docs)
+        h = self.lib.amh_stage_batch(self.ctx, ptrs, lens, n)
+        if not h:
+            raise EngineError("amh_stage_batch failed: " + self._err())
+        return Staged(self, h, n)
+
+    def load_staged(self, staged, verify_heads=True):
+        opts = LoadOpts(1 if verify_heads else 0, 0)
+        h = self.lib.amh_load_staged(self.ctx, staged.h, C.byref(opts))
+        if not h:
+            raise EngineError("amh_load_staged failed: " + self._err())
+        return Batch(self, h, staged.n)
+
+    def load_batch(self, docs, verify_heads=True):
+        """== Automerge::load_with_options per document (automerge.rs:601)."""
+        ptrs, lens, n = self._pack(docs)
+        opts = LoadOpts(1 if verify_heads else 0, 0)
+        h = self.lib.amh_load_batch(self.ctx, ptrs, lens, n, C.byref(opts))
+        if not h:
+            raise EngineError("amh_load_batch failed: " + self._err())
+        return Batch(self, h, n)
+
+    def load(self, data, verify_heads=True):
+        """Single document: the n = 1 case; raises AutomergeError like Automerge::load."""
+        b = self.load_batch([data], verify_heads)
+        b.check(0)
+        return b
+
+    # --- measurement -------------------------------------------------------------------------
+    def set_profiling(self, on):
+        self.lib.amh_ctx_set_profiling(self.ctx, 1 if on else 0)
+
+    def reset_profile(self):
+        self.lib.amh_ctx_reset_profile(self.ctx)
+
+    def kernel_times(self):
+        out = {}
+        for k in range(self.lib.amh_ctx_num_kernels()):
+            ms = C.c_double()
+            n = C.c_uint64()
+            self.lib.amh_ctx_kernel_time(self.ctx, k, C.byref(ms), C.byref(n))
+            out[self.lib.amh_ctx_kernel_name(k).decode()] = (ms.value, n.value)
+        return out
+
+    # --- synthetic workloads -----------------------------------------------------------------
+    def gen_map_docs(self, seed, n_docs, n_actors=4, changes_per_actor=5, ops_per_change=50, n_keys=128, threads=8):
+        o = BytesOut()
+        offs = C.POINTER(C.c_uint64)()
+        rc = self.lib.amh_gen_map_docs(seed, n_docs, n_actors, changes_per_actor, ops_per_change, n_keys, threads,
+                                       C.byref(o), C.byref(offs))
+        if rc != 0:
+            raise EngineError(f"amh_gen_map_docs failed: {rc}")
+        blob = C.string_at(o.data, o.len)
+        offsets = [offs[i] for i in range(n_docs + 1)]
+        self.lib.amh_bytes_free(C.byref(o))
+        self.lib.amh_u64_free(offs)
+        return blob, offsets

@@ -1,0 +1,790 @@
+// Host orchestration of the batched load path and the C ABI of libautomerge_hip.so
+// (include/automerge_hip.h).  The host stages bytes, sizes buffers and launches kernels; every
+// per-op / per-change computation happens in the kernels of amh_kernels.inl.
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <array>
+#include <map>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/automerge_hip.h"
+#include "amh_ingest.h"
+#include "amh_launch.h"
+#include "amh_rt.h"
+#include "amh_types.h"
+
+#define AMH_EMPTY32 0xFFFFFFFFu
+#define AMH_NCOLS 14
+
+static thread_local std::string g_last_error;
+
+// ---------------------------------------------------------------------------------------------
+// caching device allocator: steady-state batches allocate nothing
+// ---------------------------------------------------------------------------------------------
+struct DevPool {
+  std::multimap<size_t, void*> free_blocks;
+  size_t live_bytes = 0, pooled_bytes = 0;
+  void* alloc(size_t n, size_t* got) {
+    n = (n + 255) & ~(size_t)255;
+    if (n == 0) n = 256;
+    auto it = free_blocks.lower_bound(n);
+    if (it != free_blocks.end() && it->first <= n + n / 4 + 4096) {
+      void* p = it->second;
+      *got = it->first;
+      pooled_bytes -= it->first;
+      free_blocks.erase(it);
+      live_bytes += *got;
+      return p;
+    }
+    void* p = rt_malloc(n);
+    if (!p) {  // release the pool and retry once
+      trim();
+      p = rt_malloc(n);
+    }
+    if (p) { *got = n; live_bytes += n; }
+    return p;
+  }
+  void release(void* p, size_t n) {
+    if (!p) return;
+    free_blocks.insert({n, p});
+    live_bytes -= n;
+    pooled_bytes += n;
+  }
+  void trim() {
+    for (auto& kv : free_blocks) rt_free(kv.second);
+    free_blocks.clear();
+    pooled_bytes = 0;
+  }
+};
+
+struct amh_ctx {
+  int device = 0;
+  rt_stream stream{};
+  DevPool pool;
+  bool profiling = false;
+  double kernel_ms[AK_NUM] = {0};
+  uint64_t kernel_calls[AK_NUM] = {0};
+  struct Pending { int k; rt_event a, b; };
+  std::vector<Pending> pending;
+  std::string last_error;
+};
+
+static void set_error(amh_ctx* ctx, const std::string& m) {
+  g_last_error = m;
+  if (ctx) ctx->last_error = m;
+}
+
+struct DevAlloc {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct amh_staged {
+  amh_ctx* ctx = nullptr;
+  uint32_t n_docs = 0;
+  std::vector<uint8_t> h_arena;   // normalised input bytes (kept for string / actor access on the host)
+  std::vector<u64> h_doc_off;
+  DevAlloc d_arena, d_doc_off;
+  int refs = 1;
+};
+static void staged_unref(amh_staged* s) {
+  if (!s) return;
+  if (--s->refs > 0) return;
+  s->ctx->pool.release(s->d_arena.p, s->d_arena.cap);
+  s->ctx->pool.release(s->d_doc_off.p, s->d_doc_off.cap);
+  delete s;
+}
+
+struct HostView {  // lazily fetched mirrors for the accessors
+  bool base_ok = false, chg_ok = false, out_ok = false;
+  std::vector<DocCounts> cnt;
+  std::vector<DocDesc> desc;
+  std::vector<u32> row_base, succ_base, chg_base, dep_base, actor_base, doc_max_op;
+  std::vector<u32> c_actor, c_nops, c_ndeps, c_dep_base, c_out_off, c_out_len, dep_idx, actor_off, actor_len, c_doc;
+  std::vector<u64> c_seq, c_start_op;
+  std::vector<i64> c_time;
+  std::vector<u8> c_hash, out_arena;
+  std::map<u32, std::vector<u8>> heads_cache;
+};
+
+struct amh_batch {
+  amh_ctx* ctx = nullptr;
+  amh_staged* staged = nullptr;
+  BatchDev B{};
+  std::vector<DevAlloc> allocs;
+  std::vector<i32> status;
+  u32 tot_ht = 0, tot_map = 0, tot_out = 0;
+  mutable HostView hv;
+};
+
+// ---------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------
+static void launch(amh_ctx* ctx, int k, const BatchDev& B, u32 n) {
+  if (n == 0) return;
+  if (ctx->profiling) {
+    amh_ctx::Pending p;
+    p.k = k;
+    rt_event_create(&p.a);
+    rt_event_create(&p.b);
+    rt_event_record(&p.a, ctx->stream);
+    amh_launch(k, B, n, (void*)ctx->stream);
+    rt_event_record(&p.b, ctx->stream);
+    ctx->pending.push_back(p);
+  } else {
+    amh_launch(k, B, n, (void*)ctx->stream);
+  }
+}
+static void collect_profile(amh_ctx* ctx) {
+  for (auto& p : ctx->pending) {
+    ctx->kernel_ms[p.k] += rt_event_ms(&p.a, &p.b);
+    ctx->kernel_calls[p.k]++;
+    rt_event_destroy(&p.a);
+    rt_event_destroy(&p.b);
+  }
+  ctx->pending.clear();
+}
+
+template <class T>
+static T* balloc(amh_batch* b, size_t count, bool* ok) {
+  DevAlloc a;
+  a.p = b->ctx->pool.alloc(count * sizeof(T), &a.cap);
+  if (!a.p) { *ok = false; return nullptr; }
+  b->allocs.push_back(a);
+  return (T*)a.p;
+}
+
+static bool scan_inplace(amh_batch* b, u32* data, u32 n, u32* total) {
+  amh_ctx* ctx = b->ctx;
+  bool ok = true;
+  u32* tmp = balloc<u32>(b, amh_scan_tmp_words(n), &ok);
+  if (!ok) return false;
+  if (ctx->profiling) {
+    amh_ctx::Pending p;
+    p.k = AK_SCAN;
+    rt_event_create(&p.a);
+    rt_event_create(&p.b);
+    rt_event_record(&p.a, ctx->stream);
+    amh_scan_inplace(data, n, tmp, (void*)ctx->stream);
+    rt_event_record(&p.b, ctx->stream);
+    ctx->pending.push_back(p);
+  } else {
+    amh_scan_inplace(data, n, tmp, (void*)ctx->stream);
+  }
+  if (total) return rt_d2h(total, data + n, sizeof(u32), ctx->stream);
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage: host ingest + one H2D copy
+// ---------------------------------------------------------------------------------------------
+extern "C" amh_staged* amh_stage_batch(amh_ctx* ctx, const uint8_t* const* docs, const size_t* lens, size_t n) {
+  if (!ctx || (n && (!docs || !lens)) || n >= 0x7FFFFFFFull) { set_error(ctx, "invalid argument"); return nullptr; }
+  auto* st = new amh_staged();
+  st->ctx = ctx;
+  st->n_docs = (uint32_t)n;
+  // pass 1: normalise deflated documents (rare), in parallel
+  std::vector<std::vector<uint8_t>> rewritten(n);
+  std::vector<uint8_t> changed(n, 0);
+  unsigned nthreads = std::min<size_t>(std::max<size_t>(1, std::thread::hardware_concurrency()), 16);
+  if (n < 64) nthreads = 1;
+  {
+    std::vector<std::thread> ts;
+    for (unsigned t = 0; t < nthreads; t++)
+      ts.emplace_back([&, t]() {
+        for (size_t i = t; i < n; i += nthreads)
+          if (lens[i] && amh_ingest_normalise(docs[i], lens[i], rewritten[i])) changed[i] = 1;
+      });
+    for (auto& th : ts) th.join();
+  }
+  st->h_doc_off.resize(n + 1);
+  u64 off = 0;
+  for (size_t i = 0; i < n; i++) {
+    st->h_doc_off[i] = off;
+    off += changed[i] ? rewritten[i].size() : lens[i];
+    off = (off + 15) & ~(u64)15;  // 16-byte aligned chunk starts: wide loads in the streaming kernels
+  }
+  st->h_doc_off[n] = off;
+  st->h_arena.assign(off + 64, 0);
+  {
+    std::vector<std::thread> ts;
+    for (unsigned t = 0; t < nthreads; t++)
+      ts.emplace_back([&, t]() {
+        for (size_t i = t; i < n; i += nthreads) {
+          const uint8_t* src = changed[i] ? rewritten[i].data() : docs[i];
+          size_t l = changed[i] ? rewritten[i].size() : lens[i];
+          if (l) memcpy(st->h_arena.data() + st->h_doc_off[i], src, l);
+        }
+      });
+    for (auto& th : ts) th.join();
+  }
+  // document i occupies [doc_off[i], doc_off[i] + len_i); the kernels need the exact length, so the
+  // offsets table carries 2 entries per document: start and end
+  std::vector<u64> se(2 * n + 2);
+  for (size_t i = 0; i < n; i++) {
+    se[2 * i] = st->h_doc_off[i];
+    se[2 * i + 1] = st->h_doc_off[i] + (changed[i] ? rewritten[i].size() : lens[i]);
+  }
+  st->d_arena.p = ctx->pool.alloc(st->h_arena.size(), &st->d_arena.cap);
+  st->d_doc_off.p = ctx->pool.alloc(se.size() * sizeof(u64), &st->d_doc_off.cap);
+  if (!st->d_arena.p || !st->d_doc_off.p) { set_error(ctx, "device out of memory while staging"); staged_unref(st); return nullptr; }
+  bool ok = rt_h2d(st->d_arena.p, st->h_arena.data(), st->h_arena.size(), ctx->stream) &&
+            rt_h2d(st->d_doc_off.p, se.data(), se.size() * sizeof(u64), ctx->stream) && rt_sync(ctx->stream);
+  if (!ok) { set_error(ctx, std::string("H2D copy failed: ") + rt_last_error()); staged_unref(st); return nullptr; }
+  // keep exact ends on the host too
+  st->h_doc_off.resize(2 * n + 2);
+  for (size_t i = 0; i < 2 * n + 2; i++) st->h_doc_off[i] = se[i];
+  return st;
+}
+extern "C" void amh_staged_free(amh_staged* s) { staged_unref(s); }
+
+// ---------------------------------------------------------------------------------------------
+// the device pipeline
+// ---------------------------------------------------------------------------------------------
+extern "C" void amh_batch_free(amh_batch* b) {
+  if (!b) return;
+  for (auto& a : b->allocs) b->ctx->pool.release(a.p, a.cap);
+  staged_unref(b->staged);
+  delete b;
+}
+
+extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts) {
+  if (!ctx || !st_c) { set_error(ctx, "invalid argument"); return nullptr; }
+  amh_staged* st = const_cast<amh_staged*>(st_c);
+  auto* b = new amh_batch();
+  b->ctx = ctx;
+  b->staged = st;
+  st->refs++;
+  BatchDev& B = b->B;
+  u32 n = st->n_docs;
+  B.n_docs = n;
+  B.check_heads = opts ? (opts->verify_heads != 0) : 1;
+  B.arena = (const u8*)st->d_arena.p;
+  B.doc_off = (const u64*)st->d_doc_off.p;
+  bool ok = true;
+  auto fail = [&](const std::string& m) -> amh_batch* {
+    set_error(ctx, m);
+    collect_profile(ctx);
+    amh_batch_free(b);
+    return nullptr;
+  };
+  B.status = balloc<i32>(b, n + 1, &ok);
+  B.desc = balloc<DocDesc>(b, n + 1, &ok);
+  B.cnt = balloc<DocCounts>(b, n + 1, &ok);
+  u32** bases[8] = {&B.row_base, &B.succ_base, &B.chg_base, &B.dep_base, &B.actor_base, &B.ht_base, &B.dt_base, &B.map_base};
+  for (auto pb : bases) *pb = balloc<u32>(b, n + 2, &ok);
+  B.doc_hash = balloc<u8>(b, (size_t)n * 32 + 32, &ok);
+  B.doc_max_op = balloc<u32>(b, n + 1, &ok);
+  B.heads_ok = balloc<u32>(b, n + 1, &ok);
+  if (!ok) return fail("device out of memory");
+  rt_memset(B.status, 0, (n + 1) * sizeof(i32), ctx->stream);
+  launch(ctx, AK_PARSE, B, n);
+  launch(ctx, AK_SHA_DOC, B, n);
+  launch(ctx, AK_COUNT, B, n);
+  launch(ctx, AK_EXTRACT, B, n);
+  u32 totals[8] = {0};
+  for (int i = 0; i < 8; i++)
+    if (!scan_inplace(b, *bases[i], n, &totals[i])) return fail(std::string("scan failed: ") + rt_last_error());
+  for (int i = 0; i < 8; i++)
+    if (totals[i] == 0xFFFFFFFFu) return fail("batch too large: a derived count exceeds 2^32-1");
+  B.tot_rows = totals[0]; B.tot_succ = totals[1]; B.tot_chg = totals[2]; B.tot_deps = totals[3];
+  B.tot_actors = totals[4]; b->tot_ht = totals[5]; B.tot_dt = totals[6]; b->tot_map = totals[7];
+  if ((u64)B.tot_rows + B.tot_dt >= 0x7FFFFFFFull) return fail("batch too large: more than 2^31 ops");
+  u32 T = B.tot_rows + B.tot_dt;
+  size_t NA = B.tot_actors + 1, NC = B.tot_chg + 2, NR = B.tot_rows + 1, NS = B.tot_succ + 1;
+  B.actor_off = balloc<u32>(b, NA, &ok); B.actor_len = balloc<u32>(b, NA, &ok);
+  B.actor_rank = balloc<u32>(b, NA, &ok); B.actor_by_rank = balloc<u32>(b, NA, &ok);
+  B.a_first_chg = balloc<u32>(b, NA, &ok); B.a_last_chg = balloc<u32>(b, NA, &ok);
+  B.c_actor = balloc<u32>(b, NC, &ok); B.c_seq = balloc<u64>(b, NC, &ok); B.c_max_op = balloc<u64>(b, NC, &ok);
+  B.c_time = balloc<i64>(b, NC, &ok); B.c_msg_off = balloc<u32>(b, NC, &ok); B.c_msg_len = balloc<u32>(b, NC, &ok);
+  B.c_ndeps = balloc<u32>(b, NC, &ok); B.c_dep_base = balloc<u32>(b, NC, &ok);
+  B.c_extra_off = balloc<u32>(b, NC, &ok); B.c_extra_len = balloc<u32>(b, NC, &ok); B.c_doc = balloc<u32>(b, NC, &ok);
+  B.dep_idx = balloc<u32>(b, B.tot_deps + 1, &ok);
+  B.c_nops = balloc<u32>(b, NC, &ok); B.c_start_op = balloc<u64>(b, NC, &ok); B.c_op_base = balloc<u32>(b, NC, &ok);
+  B.c_next_same_actor = balloc<u32>(b, NC, &ok); B.c_hash = balloc<u8>(b, NC * 32, &ok);
+  B.c_out_off = balloc<u32>(b, NC, &ok); B.c_out_len = balloc<u32>(b, NC, &ok); B.c_body_len = balloc<u32>(b, NC, &ok);
+  B.c_cols_off = balloc<u32>(b, NC, &ok); B.c_col_len = balloc<u32>(b, NC * AMH_NCOLS, &ok);
+  B.c_map_base = balloc<u32>(b, NC, &ok); B.c_n_other = balloc<u32>(b, NC, &ok);
+  B.chg_actor_map = balloc<u32>(b, (size_t)b->tot_map + 1, &ok);
+  u32** rcols[] = {&B.r_id_actor, &B.r_id_ctr, &B.r_obj_actor, &B.r_obj_ctr, &B.r_key_actor, &B.r_key_ctr, &B.r_key_off,
+                   &B.r_key_len, &B.r_vraw_off, &B.r_mark_off, &B.r_mark_len, &B.r_succ_cnt, &B.r_succ_base, &B.r_doc, &B.r_inc_cnt};
+  for (auto pc : rcols) *pc = balloc<u32>(b, NR, &ok);
+  B.r_insert = balloc<u8>(b, NR, &ok); B.r_action = balloc<u8>(b, NR, &ok); B.r_expand = balloc<u8>(b, NR, &ok);
+  B.r_visible = balloc<u8>(b, NR, &ok); B.r_winner = balloc<u8>(b, NR, &ok);
+  B.r_vmeta = balloc<u64>(b, NR, &ok); B.r_inc_sum = balloc<i64>(b, NR, &ok);
+  B.s_actor = balloc<u32>(b, NS, &ok); B.s_ctr = balloc<u32>(b, NS, &ok); B.s_row = balloc<u32>(b, NS, &ok);
+  B.s_target = balloc<u32>(b, NS, &ok); B.pred_ids = balloc<u64>(b, NS, &ok);
+  B.ht_key = balloc<u64>(b, (size_t)b->tot_ht + 1, &ok); B.ht_val = balloc<u32>(b, (size_t)b->tot_ht + 1, &ok);
+  B.dt_key = balloc<u64>(b, (size_t)B.tot_dt + 1, &ok); B.d_doc = balloc<u32>(b, (size_t)B.tot_dt + 1, &ok);
+  B.d_first_pred_row = balloc<u32>(b, (size_t)B.tot_dt + 1, &ok);
+  B.t_pred_cnt = balloc<u32>(b, (size_t)T + 2, &ok); B.t_pred_base = balloc<u32>(b, (size_t)T + 2, &ok);
+  B.t_pred_fill = balloc<u32>(b, (size_t)T + 2, &ok); B.t_chg = balloc<u32>(b, (size_t)T + 2, &ok);
+  if (!ok) return fail("device out of memory");
+  rt_memset(B.ht_key, 0, ((size_t)b->tot_ht + 1) * 8, ctx->stream);
+  rt_memset(B.dt_key, 0, ((size_t)B.tot_dt + 1) * 8, ctx->stream);
+  rt_memset(B.d_first_pred_row, 0xFF, ((size_t)B.tot_dt + 1) * 4, ctx->stream);
+  rt_memset(B.s_row, 0xFF, NS * 4, ctx->stream);
+  rt_memset(B.t_pred_cnt, 0, ((size_t)T + 2) * 4, ctx->stream);
+  rt_memset(B.t_pred_fill, 0, ((size_t)T + 2) * 4, ctx->stream);
+  rt_memset(B.chg_actor_map, 0, ((size_t)b->tot_map + 1) * 4, ctx->stream);
+  launch(ctx, AK_ACTORS, B, n);
+  launch(ctx, AK_CHG_INIT, B, B.tot_chg);
+  launch(ctx, AK_DECODE_CHG, B, n);
+  launch(ctx, AK_DECODE_OPS, B, n * OC_COUNT);
+  launch(ctx, AK_ROWS, B, B.tot_rows);
+  launch(ctx, AK_OBJ_ORDER, B, B.tot_rows);
+  launch(ctx, AK_SUCC, B, B.tot_succ);
+  launch(ctx, AK_BUCKET, B, T);
+  launch(ctx, AK_CHG_FINISH, B, B.tot_chg);
+  // ops grouped by change
+#ifdef AMH_EMU
+  memcpy(B.c_op_base, B.c_nops, (size_t)B.tot_chg * 4);
+#else
+  (void)hipMemcpyAsync(B.c_op_base, B.c_nops, (size_t)B.tot_chg * 4, hipMemcpyDeviceToDevice, ctx->stream);
+#endif
+  u32 tot_ops = 0;
+  if (!scan_inplace(b, B.c_op_base, B.tot_chg, &tot_ops)) return fail("scan failed");
+  if (tot_ops == 0xFFFFFFFFu) return fail("batch too large");
+  B.tot_ops = tot_ops;
+  B.ops_sorted = balloc<u32>(b, (size_t)tot_ops + 1, &ok);
+  if (!ok) return fail("device out of memory");
+  rt_memset(B.ops_sorted, 0xFF, ((size_t)tot_ops + 1) * 4, ctx->stream);
+  launch(ctx, AK_PLACE, B, T);
+#ifdef AMH_EMU
+  memcpy(B.t_pred_base, B.t_pred_cnt, (size_t)T * 4);
+#else
+  (void)hipMemcpyAsync(B.t_pred_base, B.t_pred_cnt, (size_t)T * 4, hipMemcpyDeviceToDevice, ctx->stream);
+#endif
+  if (!scan_inplace(b, B.t_pred_base, T, nullptr)) return fail("scan failed");
+  launch(ctx, AK_PRED_FILL, B, B.tot_succ);
+  launch(ctx, AK_PRED_SORT, B, T);
+  launch(ctx, AK_ACTOR_MARK, B, T);
+  launch(ctx, AK_ACTOR_RANK, B, B.tot_chg);
+  launch(ctx, AK_ENCODE_SIZE, B, B.tot_chg * AMH_NCOLS);
+  launch(ctx, AK_CHG_LAYOUT, B, B.tot_chg);
+#ifdef AMH_EMU
+  memcpy(B.c_out_off, B.c_out_len, (size_t)B.tot_chg * 4);
+#else
+  (void)hipMemcpyAsync(B.c_out_off, B.c_out_len, (size_t)B.tot_chg * 4, hipMemcpyDeviceToDevice, ctx->stream);
+#endif
+  u32 tot_out = 0;
+  if (!scan_inplace(b, B.c_out_off, B.tot_chg, &tot_out)) return fail("scan failed");
+  if (tot_out == 0xFFFFFFFFu) return fail("batch too large: re-derived changes exceed 4 GiB");
+  b->tot_out = tot_out;
+  B.out_arena = balloc<u8>(b, (size_t)tot_out + 64, &ok);
+  if (!ok) return fail("device out of memory");
+  launch(ctx, AK_ENCODE_STORE, B, B.tot_chg * AMH_NCOLS);
+  launch(ctx, AK_ASSEMBLE_HASH, B, n);
+  launch(ctx, AK_VISIBLE, B, B.tot_rows);
+  b->status.resize(n);
+  if (!rt_d2h(b->status.data(), B.status, n * sizeof(i32), ctx->stream) || !rt_sync(ctx->stream))
+    return fail(std::string("device pipeline failed: ") + rt_last_error());
+  collect_profile(ctx);
+  return b;
+}
+
+extern "C" amh_batch* amh_load_batch(amh_ctx* ctx, const uint8_t* const* docs, const size_t* lens, size_t n, const amh_load_opts* opts) {
+  amh_staged* st = amh_stage_batch(ctx, docs, lens, n);
+  if (!st) return nullptr;
+  amh_batch* b = amh_load_staged(ctx, st, opts);
+  staged_unref(st);
+  return b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host views for the accessors
+// ---------------------------------------------------------------------------------------------
+template <class T>
+static bool fetch(const amh_batch* b, std::vector<T>& v, const T* dev, size_t n) {
+  v.resize(n);
+  return rt_d2h(v.data(), dev, n * sizeof(T), b->ctx->stream);
+}
+static bool ensure_base(const amh_batch* b) {
+  HostView& hv = b->hv;
+  if (hv.base_ok) return true;
+  const BatchDev& B = b->B;
+  u32 n = B.n_docs;
+  bool ok = fetch(b, hv.cnt, B.cnt, n) && fetch(b, hv.desc, B.desc, n) && fetch(b, hv.row_base, B.row_base, n + 1) &&
+            fetch(b, hv.succ_base, B.succ_base, n + 1) && fetch(b, hv.chg_base, B.chg_base, n + 1) &&
+            fetch(b, hv.dep_base, B.dep_base, n + 1) && fetch(b, hv.actor_base, B.actor_base, n + 1) &&
+            fetch(b, hv.doc_max_op, B.doc_max_op, n);
+  hv.base_ok = ok;
+  return ok;
+}
+static bool ensure_chg(const amh_batch* b) {
+  if (!ensure_base(b)) return false;
+  HostView& hv = b->hv;
+  if (hv.chg_ok) return true;
+  const BatchDev& B = b->B;
+  size_t nc = B.tot_chg;
+  bool ok = fetch(b, hv.c_actor, B.c_actor, nc) && fetch(b, hv.c_nops, B.c_nops, nc) && fetch(b, hv.c_ndeps, B.c_ndeps, nc) &&
+            fetch(b, hv.c_dep_base, B.c_dep_base, nc) && fetch(b, hv.c_out_off, B.c_out_off, nc + 1) &&
+            fetch(b, hv.c_out_len, B.c_out_len, nc) && fetch(b, hv.dep_idx, B.dep_idx, (size_t)B.tot_deps) &&
+            fetch(b, hv.c_seq, B.c_seq, nc) && fetch(b, hv.c_start_op, B.c_start_op, nc) && fetch(b, hv.c_time, B.c_time, nc) &&
+            fetch(b, hv.c_hash, B.c_hash, nc * 32) && fetch(b, hv.actor_off, B.actor_off, (size_t)B.tot_actors) &&
+            fetch(b, hv.actor_len, B.actor_len, (size_t)B.tot_actors) && fetch(b, hv.c_doc, B.c_doc, nc);
+  hv.chg_ok = ok;
+  return ok;
+}
+
+static const char* status_msg(int s) {
+  switch (s) {
+    case AMH_OK: return "ok";
+    case AMH_E_PARSE: return "unable to parse chunk";
+    case AMH_E_BAD_CHECKSUM: return "bad checksum";
+    case AMH_E_INVALID_CHANGE_COLUMNS: return "invalid change columns";
+    case AMH_E_READ_OP: return "error inflating document chunk ops: error reading operation";
+    case AMH_E_OPS_OUT_OF_ORDER: return "error inflating document chunk ops: the document contained ops which were out of order";
+    case AMH_E_MISSING_ACTOR: return "error inflating document chunk ops: an operation referenced a missing actor id";
+    case AMH_E_MISMATCHING_HEADS: return "error inflating document chunk ops: mismatching heads";
+    case AMH_E_MISSING_OPS: return "error inflating document chunk ops: missing operations";
+    case AMH_E_SUCC_OUT_OF_ORDER: return "error inflating document chunk ops: succ out of order";
+    case AMH_E_INVALID_OP: return "error inflating document chunk ops: invalid op type";
+    case AMH_E_CHANGES_OUT_OF_ORDER: return "error inflating document chunk ops: invalid changes: changes out of order";
+    case AMH_E_MISSING_CHANGE: return "error inflating document chunk ops: invalid changes: missing change";
+    case AMH_E_READ_CHANGE: return "error inflating document chunk ops: invalid changes: unable to read change metadata";
+    case AMH_E_INCORRECT_MAX_OP: return "error inflating document chunk ops: invalid changes: incorrect max op";
+    case AMH_E_COLLECT_MISSING_ACTOR: return "error inflating document chunk ops: invalid changes: a change referenced an actor index we couldn't find";
+    case AMH_E_COLLECT_MISSING_OPS: return "error inflating document chunk ops: invalid changes: missing ops";
+    case AMH_E_MISSING_DEPS: return "missing dependencies";
+    case AMH_E_DUPLICATE_SEQ: return "duplicate seq number";
+    case AMH_E_TOO_LARGE: return "document exceeds the engine's size limits";
+    case AMH_E_UNSUPPORTED: return "document shape not handled by this round's device path (change chunks / apply_changes)";
+    default: return "unknown";
+  }
+}
+
+extern "C" int amh_doc_status(const amh_batch* b, uint32_t doc, int* err_kind, const char** msg) {
+  if (!b || doc >= b->B.n_docs) return AMH_ERR_INVALID_ARG;
+  if (err_kind) *err_kind = b->status[doc];
+  if (msg) *msg = status_msg(b->status[doc]);
+  return AMH_SUCCESS;
+}
+
+extern "C" int amh_batch_get_stats(const amh_batch* b, amh_batch_stats* out) {
+  if (!b || !out) return AMH_ERR_INVALID_ARG;
+  if (!ensure_chg(b)) return AMH_ERR_DEVICE;
+  memset(out, 0, sizeof(*out));
+  const HostView& hv = b->hv;
+  out->n_docs = b->B.n_docs;
+  for (u32 d = 0; d < b->B.n_docs; d++) {
+    if (b->status[d]) continue;
+    out->n_ok++;
+    out->op_rows += hv.cnt[d].n_rows;
+    out->succ_entries += hv.cnt[d].n_succ;
+    out->changes += hv.cnt[d].n_chg;
+    for (u32 c = hv.chg_base[d]; c < hv.chg_base[d] + hv.cnt[d].n_chg; c++) {
+      out->ops_loaded += hv.c_nops[c];
+      out->change_bytes += hv.c_out_len[c];
+    }
+  }
+  out->delete_ops = out->ops_loaded - out->op_rows;
+  for (u32 d = 0; d < b->B.n_docs; d++) out->encoded_bytes += b->staged->h_doc_off[2 * (size_t)d + 1] - b->staged->h_doc_off[2 * (size_t)d];
+  return AMH_SUCCESS;
+}
+
+extern "C" int amh_doc_max_op(const amh_batch* b, uint32_t doc, uint64_t* max_op) {
+  if (!b || doc >= b->B.n_docs || !max_op) return AMH_ERR_INVALID_ARG;
+  if (b->status[doc]) return AMH_ERR_DOC_FAILED;
+  if (!ensure_base(b)) return AMH_ERR_DEVICE;
+  *max_op = b->hv.doc_max_op[doc];
+  return AMH_SUCCESS;
+}
+
+extern "C" int amh_heads(const amh_batch* b, uint32_t doc, const uint8_t** hashes32, size_t* n) {
+  if (!b || doc >= b->B.n_docs || !hashes32 || !n) return AMH_ERR_INVALID_ARG;
+  if (b->status[doc]) return AMH_ERR_DOC_FAILED;
+  if (!ensure_chg(b)) return AMH_ERR_DEVICE;
+  HostView& hv = b->hv;
+  auto it = hv.heads_cache.find(doc);
+  if (it == hv.heads_cache.end()) {
+    u32 cb = hv.chg_base[doc], nc = hv.cnt[doc].n_chg;
+    std::vector<uint8_t> is_dep(nc, 0);
+    for (u32 i = 0; i < nc; i++)
+      for (u32 k = 0; k < hv.c_ndeps[cb + i]; k++) is_dep[hv.dep_idx[hv.c_dep_base[cb + i] + k]] = 1;
+    std::vector<std::array<uint8_t, 32>> hs;
+    for (u32 i = 0; i < nc; i++)
+      if (!is_dep[i]) {
+        std::array<uint8_t, 32> h;
+        memcpy(h.data(), hv.c_hash.data() + (size_t)(cb + i) * 32, 32);
+        hs.push_back(h);
+      }
+    std::sort(hs.begin(), hs.end());
+    hs.erase(std::unique(hs.begin(), hs.end()), hs.end());
+    std::vector<u8> flat;
+    for (auto& h : hs) flat.insert(flat.end(), h.begin(), h.end());
+    it = hv.heads_cache.emplace(doc, std::move(flat)).first;
+  }
+  *hashes32 = it->second.data();
+  *n = it->second.size() / 32;
+  return AMH_SUCCESS;
+}
+
+extern "C" int amh_changes(const amh_batch* b, uint32_t doc, amh_change_view* out, size_t* n) {
+  if (!b || doc >= b->B.n_docs || !n) return AMH_ERR_INVALID_ARG;
+  if (b->status[doc]) return AMH_ERR_DOC_FAILED;
+  if (!ensure_chg(b)) return AMH_ERR_DEVICE;
+  HostView& hv = b->hv;
+  if (!hv.out_ok) {
+    if (!fetch(b, hv.out_arena, b->B.out_arena, (size_t)b->tot_out)) return AMH_ERR_DEVICE;
+    hv.out_ok = true;
+  }
+  u32 cb = hv.chg_base[doc], nc = hv.cnt[doc].n_chg;
+  size_t cap = *n;
+  *n = nc;
+  if (!out || cap < nc) return cap == 0 ? AMH_SUCCESS : AMH_ERR_INVALID_ARG;
+  const uint8_t* chunk = b->staged->h_arena.data() + b->staged->h_doc_off[2 * (size_t)doc];
+  u32 ab = hv.actor_base[doc];
+  for (u32 i = 0; i < nc; i++) {
+    u32 c = cb + i;
+    out[i].hash = hv.c_hash.data() + (size_t)c * 32;
+    out[i].raw_bytes = hv.out_arena.data() + hv.c_out_off[c];
+    out[i].raw_len = hv.c_out_len[c];
+    out[i].actor = chunk + hv.actor_off[ab + hv.c_actor[c]];
+    out[i].actor_len = hv.actor_len[ab + hv.c_actor[c]];
+    out[i].seq = hv.c_seq[c];
+    out[i].start_op = hv.c_start_op[c];
+    out[i].num_ops = hv.c_nops[c];
+    out[i].timestamp = hv.c_time[c];
+    out[i].num_deps = hv.c_ndeps[c];
+  }
+  return AMH_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------
+// canonical materialization: formatting only — order, visibility and counter values come from the
+// device arrays (r_visible, r_inc_sum, document order)
+// ---------------------------------------------------------------------------------------------
+static std::string hexs(const uint8_t* p, size_t n) {
+  static const char* d = "0123456789abcdef";
+  std::string s;
+  for (size_t i = 0; i < n; i++) { s.push_back(d[p[i] >> 4]); s.push_back(d[p[i] & 15]); }
+  return s;
+}
+static void json_str(std::string& out, const uint8_t* p, size_t n) {
+  out.push_back('"');
+  for (size_t i = 0; i < n; i++) {
+    uint8_t c = p[i];
+    if (c == '"') out += "\\\"";
+    else if (c == '\\') out += "\\\\";
+    else if (c < 0x20) { char bf[8]; snprintf(bf, sizeof bf, "\\u%04x", c); out += bf; }
+    else out.push_back((char)c);
+  }
+  out.push_back('"');
+}
+struct DocRows {
+  u32 n = 0;
+  std::vector<u32> id_actor, id_ctr, obj_actor, obj_ctr, key_actor, key_ctr, key_off, key_len, vraw_off, succ_cnt;
+  std::vector<u8> insert, action, visible;
+  std::vector<u64> vmeta;
+  std::vector<i64> inc_sum;
+  const uint8_t* chunk = nullptr;
+  const DocDesc* D = nullptr;
+  std::vector<std::string> actor_hex;
+  std::map<u64, std::pair<u32, u32>> obj_range;  // object id -> [start, end) rows
+};
+static bool same_key_host(const DocRows& R, u32 a, u32 b) {
+  bool ap = R.key_len[a] != AMH_NULL32 && !R.insert[a], bp = R.key_len[b] != AMH_NULL32 && !R.insert[b];
+  if (ap != bp) return false;
+  if (ap) return R.key_len[a] == R.key_len[b] && memcmp(R.chunk + R.key_off[a], R.chunk + R.key_off[b], R.key_len[a]) == 0;
+  u32 aa = R.insert[a] ? R.id_actor[a] : R.key_actor[a], ac = R.insert[a] ? R.id_ctr[a] : R.key_ctr[a];
+  u32 ba = R.insert[b] ? R.id_actor[b] : R.key_actor[b], bc = R.insert[b] ? R.id_ctr[b] : R.key_ctr[b];
+  return aa == ba && ac == bc;
+}
+static i64 host_sleb(const uint8_t* p, size_t n, bool is_unsigned) {
+  u64 res = 0;
+  unsigned shift = 0;
+  uint8_t b = 0;
+  for (size_t i = 0; i < n; i++) {
+    b = p[i];
+    if (shift < 64) res |= (u64)(b & 0x7f) << shift;
+    shift += 7;
+  }
+  if (!is_unsigned && shift < 64 && (b & 0x40)) res |= ~(u64)0 << shift;
+  return (i64)res;
+}
+static void hydrate_obj(const DocRows& R, u64 obj, u8 objtype, std::string& out, int depth);
+static void hydrate_value(const DocRows& R, u32 r, std::string& out, int depth) {
+  out += "{\"id\":\"" + std::to_string(R.id_ctr[r]) + "@" + R.actor_hex[R.id_actor[r]] + "\",";
+  u8 a = R.action[r];
+  if (a == 0 || a == 2 || a == 4 || a == 6) {
+    const char* names[] = {"map", "", "list", "", "text", "", "table"};
+    out += std::string("\"") + names[a] + "\":";
+    hydrate_obj(R, ((u64)R.id_ctr[r] << 32) | R.id_actor[r], a, out, depth + 1);
+  } else {
+    u64 m = R.vmeta[r];
+    u32 t = (u32)(m & 15);
+    size_t l = (size_t)(m >> 4);
+    const uint8_t* raw = R.chunk + R.D->ocol[OC_VAL_RAW].off + R.vraw_off[r];
+    switch (t) {
+      case 0: out += "\"null\":null"; break;
+      case 1: out += "\"bool\":false"; break;
+      case 2: out += "\"bool\":true"; break;
+      case 3: out += "\"uint\":" + std::to_string((u64)host_sleb(raw, l, true)); break;
+      case 4: out += "\"int\":" + std::to_string(host_sleb(raw, l, false)); break;
+      case 5: out += "\"f64\":\"" + hexs(raw, l) + "\""; break;
+      case 6: out += "\"str\":"; json_str(out, raw, l); break;
+      case 7: out += "\"bytes\":\"" + hexs(raw, l) + "\""; break;
+      case 8: out += "\"counter\":" + std::to_string(host_sleb(raw, l, false) + R.inc_sum[r]); break;
+      case 9: out += "\"ts\":" + std::to_string(host_sleb(raw, l, false)); break;
+      default: out += "\"unknown\":[" + std::to_string(t) + ",\"" + hexs(raw, l) + "\"]"; break;
+    }
+  }
+  out += "}";
+}
+static void hydrate_obj(const DocRows& R, u64 obj, u8 objtype, std::string& out, int depth) {
+  if (depth > 200) { out += "null"; return; }
+  auto it = R.obj_range.find(obj);
+  u32 s = 0, e = 0;
+  if (it != R.obj_range.end()) { s = it->second.first; e = it->second.second; }
+  bool is_map = objtype == 0 || objtype == 6, is_text = objtype == 4;
+  if (is_text) {
+    std::string text;
+    u32 i = s;
+    while (i < e) {
+      u32 j = i;
+      int last = -1;
+      while (j < e && same_key_host(R, j, i)) { if (R.visible[j]) last = (int)j; j++; }
+      if (last >= 0) {
+        if (R.action[last] == 1 && (R.vmeta[last] & 15) == 6)
+          text.append((const char*)R.chunk + R.D->ocol[OC_VAL_RAW].off + R.vraw_off[last], (size_t)(R.vmeta[last] >> 4));
+        else text += "\xef\xbf\xbc";
+      }
+      i = j;
+    }
+    json_str(out, (const uint8_t*)text.data(), text.size());
+    return;
+  }
+  out += is_map ? "{" : "[";
+  bool first = true;
+  u32 i = s;
+  while (i < e) {
+    u32 j = i;
+    std::vector<u32> vis;
+    while (j < e && same_key_host(R, j, i)) { if (R.visible[j]) vis.push_back(j); j++; }
+    if (!vis.empty()) {
+      if (!first) out += ",";
+      first = false;
+      if (is_map) { json_str(out, R.chunk + R.key_off[i], R.key_len[i]); out += ":"; }
+      out += "[";
+      for (size_t k = 0; k < vis.size(); k++) { if (k) out += ","; hydrate_value(R, vis[k], out, depth); }
+      out += "]";
+    }
+    i = j;
+  }
+  out += is_map ? "}" : "]";
+}
+
+extern "C" int amh_hydrate_json(const amh_batch* b, uint32_t doc, amh_bytes_out* out) {
+  if (!b || doc >= b->B.n_docs || !out) return AMH_ERR_INVALID_ARG;
+  if (b->status[doc]) return AMH_ERR_DOC_FAILED;
+  if (!ensure_chg(b)) return AMH_ERR_DEVICE;
+  const HostView& hv = b->hv;
+  const BatchDev& B = b->B;
+  DocRows R;
+  R.n = hv.cnt[doc].n_rows;
+  u32 rb = hv.row_base[doc];
+  bool ok = fetch(b, R.id_actor, B.r_id_actor + rb, R.n) && fetch(b, R.id_ctr, B.r_id_ctr + rb, R.n) &&
+            fetch(b, R.obj_actor, B.r_obj_actor + rb, R.n) && fetch(b, R.obj_ctr, B.r_obj_ctr + rb, R.n) &&
+            fetch(b, R.key_actor, B.r_key_actor + rb, R.n) && fetch(b, R.key_ctr, B.r_key_ctr + rb, R.n) &&
+            fetch(b, R.key_off, B.r_key_off + rb, R.n) && fetch(b, R.key_len, B.r_key_len + rb, R.n) &&
+            fetch(b, R.vraw_off, B.r_vraw_off + rb, R.n) && fetch(b, R.succ_cnt, B.r_succ_cnt + rb, R.n) &&
+            fetch(b, R.insert, B.r_insert + rb, R.n) && fetch(b, R.action, B.r_action + rb, R.n) &&
+            fetch(b, R.visible, B.r_visible + rb, R.n) && fetch(b, R.vmeta, B.r_vmeta + rb, R.n) &&
+            fetch(b, R.inc_sum, B.r_inc_sum + rb, R.n);
+  if (!ok) return AMH_ERR_DEVICE;
+  R.chunk = b->staged->h_arena.data() + b->staged->h_doc_off[2 * (size_t)doc];
+  R.D = &hv.desc[doc];
+  u32 ab = hv.actor_base[doc];
+  for (u32 a = 0; a < R.D->n_actors; a++) R.actor_hex.push_back(hexs(R.chunk + hv.actor_off[ab + a], hv.actor_len[ab + a]));
+  u32 i = 0;
+  while (i < R.n) {
+    u32 j = i;
+    while (j < R.n && R.obj_ctr[j] == R.obj_ctr[i] && R.obj_actor[j] == R.obj_actor[i]) j++;
+    R.obj_range[((u64)R.obj_ctr[i] << 32) | R.obj_actor[i]] = {i, j};
+    i = j;
+  }
+  std::string s;
+  hydrate_obj(R, 0, 0, s, 0);
+  out->data = (uint8_t*)malloc(s.size() + 1);
+  if (!out->data) return AMH_ERR_OOM;
+  memcpy(out->data, s.data(), s.size());
+  out->data[s.size()] = 0;
+  out->len = s.size();
+  return AMH_SUCCESS;
+}
+
+extern "C" void amh_bytes_free(amh_bytes_out* o) {
+  if (!o) return;
+  free(o->data);
+  o->data = nullptr;
+  o->len = 0;
+}
+extern "C" void amh_u64_free(uint64_t* p) { free(p); }
+
+// ---------------------------------------------------------------------------------------------
+// boundary entry points declared for the path but not built in this round: they fail loudly
+// ---------------------------------------------------------------------------------------------
+extern "C" int amh_merge_batch(amh_ctx* ctx, amh_batch*, const amh_batch*, const uint32_t*, const uint32_t*, size_t) {
+  set_error(ctx, "amh_merge_batch: not implemented in this round");
+  return AMH_ERR_UNIMPLEMENTED;
+}
+extern "C" int amh_apply_changes(amh_ctx* ctx, amh_batch*, uint32_t, const uint8_t* const*, const size_t*, size_t) {
+  set_error(ctx, "amh_apply_changes: not implemented in this round");
+  return AMH_ERR_UNIMPLEMENTED;
+}
+extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch*, const amh_save_opts*, amh_bytes_out*) {
+  set_error(ctx, "amh_save_batch: not implemented in this round");
+  return AMH_ERR_UNIMPLEMENTED;
+}
+extern "C" int amh_sync_summaries(amh_ctx* ctx, const amh_batch*, amh_bytes_out*) {
+  set_error(ctx, "amh_sync_summaries: not implemented in this round");
+  return AMH_ERR_UNIMPLEMENTED;
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" amh_ctx* amh_ctx_create(const int* gpu_ids, int n_gpus) {
+  if (n_gpus != 1 || !gpu_ids) { set_error(nullptr, "amh_ctx_create: exactly one GPU per context (one process per GPU)"); return nullptr; }
+  auto* ctx = new amh_ctx();
+  ctx->device = gpu_ids[0];
+  std::string err;
+  if (!rt_init(ctx->device, &ctx->stream, err)) {
+    set_error(nullptr, err);
+    delete ctx;
+    return nullptr;
+  }
+  return ctx;
+}
+extern "C" void amh_ctx_destroy(amh_ctx* ctx) {
+  if (!ctx) return;
+  rt_sync(ctx->stream);
+  ctx->pool.trim();
+  rt_shutdown(ctx->stream);
+  delete ctx;
+}
+extern "C" const char* amh_last_error(const amh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
+extern "C" int amh_ctx_set_profiling(amh_ctx* ctx, int enable) {
+  if (!ctx) return AMH_ERR_INVALID_ARG;
+  ctx->profiling = enable != 0;
+  return AMH_SUCCESS;
+}
+extern "C" int amh_ctx_num_kernels(void) { return AK_NUM; }
+extern "C" const char* amh_ctx_kernel_name(int k) { return (k >= 0 && k < AK_NUM) ? AMH_KERNEL_NAMES[k] : nullptr; }
+extern "C" int amh_ctx_kernel_time(amh_ctx* ctx, int k, double* ms, uint64_t* launches) {
+  if (!ctx || k < 0 || k >= AK_NUM) return AMH_ERR_INVALID_ARG;
+  if (ms) *ms = ctx->kernel_ms[k];
+  if (launches) *launches = ctx->kernel_calls[k];
+  return AMH_SUCCESS;
+}
+extern "C" int amh_ctx_reset_profile(amh_ctx* ctx) {
+  if (!ctx) return AMH_ERR_INVALID_ARG;
+  for (int k = 0; k < AK_NUM; k++) { ctx->kernel_ms[k] = 0; ctx->kernel_calls[k] = 0; }
+  return AMH_SUCCESS;
+}

@@ -1,0 +1,1381 @@
+// Per-thread bodies of the batched document-load kernels.  One function = one kernel; the thread's
+// global index is passed in.  Included by amh_kernels.hip (HIP launch wrappers) and by the host
+// emulation used in the CPU-only test tier.  Reference citations are relative to
+// /root/reference/rust/automerge/src.
+//
+// Index spaces:  d = document, c = change (global), r = op row (global, document order),
+// e = succ entry (global), t = op (t < tot_rows: row r = t; otherwise synthesized delete in slot
+// t - tot_rows of the delete table), a = actor slot (global).
+#pragma once
+#include "amh_dev.h"
+
+#define AMH_EMPTY32 0xFFFFFFFFu
+#define AMH_NCOLS 14  // change op columns in write order (change_op_columns.rs:253-329)
+
+AMH_DEV u64 amh_mix64(u64 x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+AMH_DEV u64 pack_id(u32 ctr, u32 actor) { return ((u64)ctr << 32) | actor; }
+
+// id -> row lookup in the document's region of the open-addressing table. AMH_EMPTY32 = absent.
+AMH_DEV u32 ht_find(const BatchDev& B, u32 d, u64 id) {
+  u64 base = B.ht_base[d], size = B.ht_base[d + 1] - base;
+  if (size == 0) return AMH_EMPTY32;
+  u64 key = id + 1, mask = size - 1, h = amh_mix64(key) & mask;
+  for (u64 i = 0; i < size; i++) {
+    u64 k = B.ht_key[base + h];
+    if (k == key) return B.ht_val[base + h];
+    if (k == 0) return AMH_EMPTY32;
+    h = (h + 1) & mask;
+  }
+  return AMH_EMPTY32;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1a  chunk header + document prefix parse — chunk.rs:223-266, document.rs:113-154,
+//      raw_column.rs:205-272, columns.rs:134-355, doc_op_columns.rs:398-504,
+//      doc_change_columns.rs:272-338.  One thread per document.
+// ------------------------------------------------------------------------------------------
+struct RawColDev { u32 spec; u64 len; };
+#define AMH_MAX_RAW_COLS 64
+
+// walks raw columns through the layout state machine and records the slots this path knows
+template <bool IS_OPS>
+AMH_DEV int map_columns(const RawColDev* raw, u32 n, u64 data_rel_off, u64 data_len, ColRef* slots) {
+  // state: 0 ready, 1 in value, 2 in group
+  int st = 0;
+  u32 cur_id = 0, cur_type = 0;
+  u64 cur_s = 0, cur_e = 0, cur_rs = 0, cur_re = 0;
+  u32 nkids = 0, kid_type[2] = {0, 0};
+  u64 kid_s[2] = {0, 0}, kid_e[2] = {0, 0};
+  bool g_in_value = false;
+  u64 off = 0;
+  bool bad = false;
+  auto set = [&](int slot, u64 s, u64 e) {
+    slots[slot].off = (u32)(data_rel_off + s);
+    slots[slot].len = (u32)(e - s);
+  };
+  auto emit_simple = [&](u32 id, u32 type, u64 s, u64 e) {
+    if (IS_OPS) {
+      if (id == 0 && type == 1) set(OC_OBJ_ACTOR, s, e);
+      else if (id == 0 && type == 2) set(OC_OBJ_CTR, s, e);
+      else if (id == 1 && type == 1) set(OC_KEY_ACTOR, s, e);
+      else if (id == 1 && type == 3) set(OC_KEY_CTR, s, e);
+      else if (id == 1 && type == 5) set(OC_KEY_STR, s, e);
+      else if (id == 2 && type == 1) set(OC_ID_ACTOR, s, e);
+      else if (id == 2 && type == 3) set(OC_ID_CTR, s, e);
+      else if (id == 3 && type == 4) set(OC_INSERT, s, e);
+      else if (id == 4 && type == 2) set(OC_ACTION, s, e);
+      else if (id == 9 && type == 4) set(OC_EXPAND, s, e);
+      else if (id == 10 && type == 5) set(OC_MARK_NAME, s, e);
+    } else {
+      if (id == 0 && type == 1) set(CC_ACTOR, s, e);
+      else if (id == 0 && type == 3) set(CC_SEQ, s, e);
+      else if (id == 1 && type == 3) set(CC_MAX_OP, s, e);
+      else if (id == 2 && type == 3) set(CC_TIME, s, e);
+      else if (id == 3 && type == 5) set(CC_MESSAGE, s, e);
+    }
+  };
+  auto emit_value = [&]() {
+    if (cur_id == 5) {
+      set(IS_OPS ? (int)OC_VAL_META : (int)CC_EXTRA_META, cur_s, cur_e);
+      set(IS_OPS ? (int)OC_VAL_RAW : (int)CC_EXTRA_RAW, cur_rs, cur_re);
+    }
+  };
+  auto emit_group = [&]() {
+    if (IS_OPS && cur_id == 8) {
+      set(OC_SUCC_NUM, cur_s, cur_e);
+      if (nkids == 0) { set(OC_SUCC_ACTOR, 0, 0); set(OC_SUCC_CTR, 0, 0); }
+      else if (nkids == 2 && (kid_type[0] == 1 || kid_type[0] == 2) && kid_type[1] == 3) {
+        set(OC_SUCC_ACTOR, kid_s[0], kid_e[0]);
+        set(OC_SUCC_CTR, kid_s[1], kid_e[1]);
+      } else bad = true;  // MismatchingColumn
+    } else if (!IS_OPS && cur_id == 4) {
+      set(CC_DEPS_NUM, cur_s, cur_e);
+      if (nkids == 0) set(CC_DEPS_IDX, 0, 0);
+      else if (nkids == 1 && kid_type[0] == 3) set(CC_DEPS_IDX, kid_s[0], kid_e[0]);
+      else bad = true;
+    }
+  };
+  auto add_kid = [&](u32 type, u64 s, u64 e) {
+    if (nkids < 2) { kid_type[nkids] = type; kid_s[nkids] = s; kid_e[nkids] = e; }
+    nkids++;
+  };
+  for (u32 i = 0; i < n; i++) {
+    u32 id = raw[i].spec >> 4, type = raw[i].spec & 7;
+    u64 s = off, e = off + raw[i].len;
+    if (e > data_len || e < s) return 1;  // DataOutOfRange
+    off = e;
+    bool again = true;
+    while (again) {
+      again = false;
+      if (st == 0) {
+        if (type == 0) { st = 2; cur_id = id; cur_type = 0; cur_s = s; cur_e = e; nkids = 0; g_in_value = false; }
+        else if (type == 6) { st = 1; cur_id = id; cur_s = s; cur_e = e; cur_rs = cur_re = 0; }
+        else if (type == 7) return 1;  // LoneRawValueColumn
+        else emit_simple(id, type, s, e);
+      } else if (st == 1) {
+        if (type == 7) {
+          if (cur_id != id) return 1;  // MismatchingValueMetadataId
+          cur_rs = s; cur_re = e;
+          emit_value();
+          st = 0;
+        } else { emit_value(); st = 0; again = true; }
+      } else {
+        if (cur_id != id) { emit_group(); st = 0; again = true; }
+        else if (!g_in_value) {
+          if (type == 0 || type == 7) return 1;  // NestedGroup / LoneRawValueColumn
+          if (type == 6) g_in_value = true;      // a value column inside a group: not a shape this path maps
+          else add_kid(type, s, e);
+        } else {
+          g_in_value = false;
+          add_kid(6, 0, 0);
+          if (type != 7) again = true;
+        }
+      }
+    }
+  }
+  (void)cur_type;
+  if (st == 1) emit_value();
+  else if (st == 2) { if (g_in_value) add_kid(6, 0, 0); emit_group(); }
+  return bad ? 1 : 0;
+}
+
+AMH_DEV void k_parse(const BatchDev& B, u32 d) {
+  DocDesc& D = B.desc[d];
+  DocCounts& C = B.cnt[d];
+  C.n_rows = C.n_succ = C.n_chg = C.n_deps = 0;
+  D.n_actors = D.n_heads = 0;
+  for (int i = 0; i < CC_COUNT; i++) { D.ccol[i].off = 0; D.ccol[i].len = 0; }
+  for (int i = 0; i < OC_COUNT; i++) { D.ocol[i].off = 0; D.ocol[i].len = 0; }
+  u64 start = B.doc_off[2 * (u64)d], avail = B.doc_off[2 * (u64)d + 1] - start;  // [start, end) pairs: chunk starts are 16-byte aligned
+  D.chunk_off = start;
+  D.chunk_len = 0;
+  D.data_off = D.data_len = 0;
+  D.actors_off = D.heads_off = D.suffix_off = D.suffix_len = 0;
+  if (avail == 0) return;  // empty input = empty document (automerge.rs:605-608)
+  if (avail >= 0xFFFFFFF0ull) { amh_fail(B, d, AMH_E_TOO_LARGE); return; }
+  const u8* p = B.arena + start;
+  u64 pos = 0, end = avail;
+  if (avail < 9 || p[0] != 0x85 || p[1] != 0x6f || p[2] != 0x4a || p[3] != 0x83) { amh_fail(B, d, AMH_E_PARSE); return; }
+  u8 type = p[8];
+  if (type > 2) { amh_fail(B, d, AMH_E_PARSE); return; }
+  pos = 9;
+  u64 len;
+  if (rd_uleb_strict(p, pos, end, len)) { amh_fail(B, d, AMH_E_PARSE); return; }
+  if (len > end - pos) { amh_fail(B, d, AMH_E_PARSE); return; }
+  D.data_off = (u32)pos;
+  D.data_len = (u32)len;
+  D.chunk_len = (u32)(pos + len);
+  // this round's device path loads exactly one document chunk per input; change chunks (first or
+  // trailing) go through apply_changes, which is not on the device yet
+  if (type != 0 || D.chunk_len != avail) { amh_fail(B, d, AMH_E_UNSUPPORTED); return; }
+  end = pos + len;
+  u64 n;
+  if (rd_uleb_strict(p, pos, end, n)) { amh_fail(B, d, AMH_E_PARSE); return; }
+  if (n > len) { amh_fail(B, d, AMH_E_PARSE); return; }
+  D.actors_off = (u32)pos;
+  for (u64 i = 0; i < n; i++) {
+    u64 al;
+    if (rd_uleb_strict(p, pos, end, al) || al > end - pos) { amh_fail(B, d, AMH_E_PARSE); return; }
+    pos += al;
+  }
+  D.n_actors = (u32)n;
+  if (rd_uleb_strict(p, pos, end, n)) { amh_fail(B, d, AMH_E_PARSE); return; }
+  if (n > (end - pos) / 32) { amh_fail(B, d, AMH_E_PARSE); return; }
+  D.heads_off = (u32)pos;
+  D.n_heads = (u32)n;
+  pos += 32 * n;
+  RawColDev craw[AMH_MAX_RAW_COLS], oraw[AMH_MAX_RAW_COLS];
+  u32 ncraw = 0, noraw = 0;
+  for (int which = 0; which < 2; which++) {
+    RawColDev* raw = which ? oraw : craw;
+    u64 nc;
+    if (rd_uleb_strict(p, pos, end, nc)) { amh_fail(B, d, AMH_E_PARSE); return; }
+    if (nc > AMH_MAX_RAW_COLS) { amh_fail(B, d, nc > len ? AMH_E_PARSE : AMH_E_UNSUPPORTED); return; }
+    u32 prev_norm = 0;
+    for (u64 i = 0; i < nc; i++) {
+      u64 spec, clen;
+      if (rd_uleb_strict(p, pos, end, spec) || spec > 0xFFFFFFFFull || rd_uleb_strict(p, pos, end, clen)) { amh_fail(B, d, AMH_E_PARSE); return; }
+      u32 norm = (u32)spec & ~8u;
+      if (i > 0 && norm < prev_norm) { amh_fail(B, d, AMH_E_PARSE); return; }  // NotInNormalOrder
+      prev_norm = norm;
+      // ingest inflates deflated columns on the host (compression.rs:51-74) before upload
+      if (spec & 8) { amh_fail(B, d, AMH_E_PARSE); return; }  // a column that ingest could not inflate (ParseError::Deflate)
+      if (clen > len) { amh_fail(B, d, AMH_E_PARSE); return; }
+      raw[i].spec = (u32)spec;
+      raw[i].len = clen;
+    }
+    if (which) noraw = (u32)nc; else ncraw = (u32)nc;
+  }
+  u64 ctot = 0, otot = 0;
+  for (u32 i = 0; i < ncraw; i++) ctot += craw[i].len;
+  for (u32 i = 0; i < noraw; i++) otot += oraw[i].len;
+  if (ctot > end - pos) { amh_fail(B, d, AMH_E_PARSE); return; }
+  u64 cdata = pos;
+  pos += ctot;
+  if (otot > end - pos) { amh_fail(B, d, AMH_E_PARSE); return; }
+  u64 odata = pos;
+  pos += otot;
+  D.suffix_off = (u32)pos;
+  D.suffix_len = (u32)(end - pos);
+  if (pos < end) {  // head indices: must be exactly n_heads strict ulebs (document.rs:140-154; chunk.rs:72-74)
+    for (u32 i = 0; i < D.n_heads; i++) {
+      u64 hi;
+      if (rd_uleb_strict(p, pos, end, hi)) { amh_fail(B, d, AMH_E_PARSE); return; }
+    }
+    if (pos != end) { amh_fail(B, d, AMH_E_PARSE); return; }
+  }
+  if (map_columns<false>(craw, ncraw, cdata, ctot, D.ccol) || map_columns<true>(oraw, noraw, odata, otot, D.ocol)) {
+    amh_fail(B, d, AMH_E_PARSE);
+    return;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1b  SHA-256 of the document chunk and checksum check — chunk.rs:277-293.  Thread per document.
+// ------------------------------------------------------------------------------------------
+AMH_DEV void k_sha_doc(const BatchDev& B, u32 d) {
+  if (B.status[d]) return;
+  const DocDesc& D = B.desc[d];
+  if (D.chunk_len == 0) return;
+  const u8* p = B.arena + D.chunk_off;
+  Sha256Dev s;
+  sha_init(s);
+  sha_update(s, p + 8, D.data_off - 8);  // type byte + uleb(len) exactly as stored (strict parse => canonical)
+  sha_update(s, p + D.data_off, D.data_len);
+  u8 h[32];
+  sha_finish(s, h);
+  for (int i = 0; i < 32; i++) B.doc_hash[(u64)d * 32 + i] = h[i];
+  if (h[0] != p[4] || h[1] != p[5] || h[2] != p[6] || h[3] != p[7]) amh_fail(B, d, AMH_E_BAD_CHECKSUM);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2  count pass: rows (items of the id-counter column, doc_op_columns.rs:327-331), succ entries,
+//     change rows and dep entries.  Thread per document.
+// ------------------------------------------------------------------------------------------
+AMH_DEV void k_count(const BatchDev& B, u32 d) {
+  if (B.status[d]) return;
+  const DocDesc& D = B.desc[d];
+  DocCounts& C = B.cnt[d];
+  if (D.chunk_len == 0) return;
+  const u8* p = B.arena + D.chunk_off;
+  u64 v; u32 aux; bool isnull;
+  {
+    RleDec r;
+    rle_init(r, p, D.ocol[OC_ID_CTR].off, D.ocol[OC_ID_CTR].len);
+    u64 rows = 0;
+    // count run lengths without expanding: headers only
+    while (r.pos < r.end) {
+      i64 n;
+      if (!rd_sleb_lenient(r.p, r.pos, r.end, n)) { amh_fail(B, d, AMH_E_READ_OP); return; }
+      if (n > 0) {
+        if (!rle_read_value<1>(r, v, aux)) { amh_fail(B, d, AMH_E_READ_OP); return; }
+        rows += (u64)n;
+      } else if (n < 0) {
+        u64 k = (n == INT64_MIN) ? (u64)INT64_MAX : (u64)(-n);
+        if (k > r.end - r.pos) { amh_fail(B, d, AMH_E_READ_OP); return; }  // each literal takes >= 1 byte
+        for (u64 i = 0; i < k; i++)
+          if (!rle_read_value<1>(r, v, aux)) { amh_fail(B, d, AMH_E_READ_OP); return; }
+        rows += k;
+      } else {
+        u64 nulls;
+        if (!rd_uleb_lenient(r.p, r.pos, r.end, nulls)) { amh_fail(B, d, AMH_E_READ_OP); return; }
+        if (nulls) { amh_fail(B, d, AMH_E_READ_OP); return; }  // a null id is "unexpected null" (opid.rs:114-117)
+      }
+      if (rows > AMH_MAX_ROWS_PER_DOC) { amh_fail(B, d, AMH_E_TOO_LARGE); return; }
+    }
+    C.n_rows = (u32)rows;
+    rle_init(r, p, D.ocol[OC_SUCC_NUM].off, D.ocol[OC_SUCC_NUM].len);
+    u64 succ = 0;
+    for (u64 i = 0; i < rows; i++) {
+      int rc = rle_next<0>(r, v, aux, isnull);
+      if (rc != 0 || isnull) { amh_fail(B, d, AMH_E_READ_OP); return; }
+      succ += v;
+      if (v > AMH_MAX_ROWS_PER_DOC || succ > AMH_MAX_ROWS_PER_DOC) { amh_fail(B, d, AMH_E_TOO_LARGE); return; }
+    }
+    C.n_succ = (u32)succ;
+  }
+  {
+    RleDec r, dn;
+    rle_init(r, p, D.ccol[CC_ACTOR].off, D.ccol[CC_ACTOR].len);
+    rle_init(dn, p, D.ccol[CC_DEPS_NUM].off, D.ccol[CC_DEPS_NUM].len);
+    u64 chg = 0, deps = 0;
+    for (;;) {
+      int rc = rle_next<0>(r, v, aux, isnull);
+      if (rc < 0) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+      if (rc == 1 || isnull) break;
+      chg++;
+      rc = rle_next<0>(dn, v, aux, isnull);
+      if (rc != 0 || isnull) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+      deps += v;
+      if (chg > AMH_MAX_ROWS_PER_DOC || v > AMH_MAX_ROWS_PER_DOC || deps > AMH_MAX_ROWS_PER_DOC) { amh_fail(B, d, AMH_E_TOO_LARGE); return; }
+    }
+    C.n_chg = (u32)chg;
+    C.n_deps = (u32)deps;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3  actor table + bytewise rank (document.rs:121; lamport tie-break types.rs:517-521).
+//     Thread per document.
+// ------------------------------------------------------------------------------------------
+AMH_DEV void k_actors(const BatchDev& B, u32 d) {
+  if (B.status[d]) return;
+  const DocDesc& D = B.desc[d];
+  const u8* p = B.arena + D.chunk_off;
+  u32 base = B.actor_base[d];
+  u64 pos = D.actors_off, end = D.data_off + (u64)D.data_len;
+  for (u32 i = 0; i < D.n_actors; i++) {
+    u64 al = 0;
+    rd_uleb_strict(p, pos, end, al);
+    B.actor_off[base + i] = (u32)pos;
+    B.actor_len[base + i] = (u32)al;
+    pos += al;
+    B.a_first_chg[base + i] = AMH_EMPTY32;
+    B.a_last_chg[base + i] = AMH_EMPTY32;
+  }
+  bool dup = false;
+  for (u32 i = 0; i < D.n_actors; i++) {
+    u32 rank = 0;
+    for (u32 j = 0; j < D.n_actors; j++) {
+      if (j == i) continue;
+      int c = amh_memcmp(p + B.actor_off[base + j], B.actor_len[base + j], p + B.actor_off[base + i], B.actor_len[base + i]);
+      if (c < 0) rank++;
+      if (c == 0) dup = true;
+    }
+    B.actor_rank[base + i] = rank;
+  }
+  if (dup) { amh_fail(B, d, AMH_E_UNSUPPORTED); return; }  // duplicate actor ids in one table: not a shape writers produce
+  for (u32 i = 0; i < D.n_actors; i++) B.actor_by_rank[base + B.actor_rank[base + i]] = i;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4  change metadata rows in lock-step — doc_change_columns.rs:183-270, deps.rs:45-102.
+//     Thread per document.
+// ------------------------------------------------------------------------------------------
+AMH_DEV void k_decode_chg(const BatchDev& B, u32 d) {
+  if (B.status[d]) return;
+  const DocDesc& D = B.desc[d];
+  const DocCounts& C = B.cnt[d];
+  if (D.chunk_len == 0) return;
+  const u8* p = B.arena + D.chunk_off;
+  RleDec actors, dnum, msg, emeta;
+  DeltaDec seq, maxop, time, didx;
+  rle_init(actors, p, D.ccol[CC_ACTOR].off, D.ccol[CC_ACTOR].len);
+  rle_init(dnum, p, D.ccol[CC_DEPS_NUM].off, D.ccol[CC_DEPS_NUM].len);
+  rle_init(msg, p, D.ccol[CC_MESSAGE].off, D.ccol[CC_MESSAGE].len);
+  rle_init(emeta, p, D.ccol[CC_EXTRA_META].off, D.ccol[CC_EXTRA_META].len);
+  delta_init(seq, p, D.ccol[CC_SEQ].off, D.ccol[CC_SEQ].len);
+  delta_init(maxop, p, D.ccol[CC_MAX_OP].off, D.ccol[CC_MAX_OP].len);
+  delta_init(time, p, D.ccol[CC_TIME].off, D.ccol[CC_TIME].len);
+  delta_init(didx, p, D.ccol[CC_DEPS_IDX].off, D.ccol[CC_DEPS_IDX].len);
+  bool has_msg = D.ccol[CC_MESSAGE].len != 0;
+  u32 cb = B.chg_base[d], db = B.dep_base[d];
+  u32 ndep = 0;
+  u64 extra_off = 0;
+  u64 v; u32 aux; bool isnull; i64 sv;
+  for (u32 i = 0; i < C.n_chg; i++) {
+    u32 c = cb + i;
+    if (rle_next<0>(actors, v, aux, isnull) != 0 || isnull) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+    if (v >= D.n_actors) { amh_fail(B, d, AMH_E_COLLECT_MISSING_ACTOR); return; }  // change_collector.rs:185-192
+    B.c_actor[c] = (u32)v;
+    if (delta_next(seq, sv, isnull) != 0 || isnull || sv < 0) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+    B.c_seq[c] = (u64)sv;
+    if (delta_next(maxop, sv, isnull) != 0 || isnull || sv < 0) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+    B.c_max_op[c] = (u64)sv;
+    if (delta_next(time, sv, isnull) != 0 || isnull) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+    B.c_time[c] = sv;
+    B.c_msg_off[c] = 0;
+    B.c_msg_len[c] = AMH_NULL32;
+    if (has_msg) {
+      int rc = rle_next<2>(msg, v, aux, isnull);
+      if (rc < 0) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+      if (rc == 0 && !isnull) { B.c_msg_off[c] = (u32)v; B.c_msg_len[c] = aux; }
+    }
+    if (rle_next<0>(dnum, v, aux, isnull) != 0 || isnull) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+    B.c_ndeps[c] = (u32)v;
+    B.c_dep_base[c] = db + ndep;
+    for (u64 k = 0; k < v; k++) {
+      if (ndep >= C.n_deps) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+      if (delta_next(didx, sv, isnull) != 0 || isnull || sv < 0) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+      if ((u64)sv >= i) { amh_fail(B, d, AMH_E_MISSING_CHANGE); return; }  // change_collector.rs:163-177
+      B.dep_idx[db + ndep] = (u32)sv;
+      ndep++;
+    }
+    // extra bytes: must be a Bytes value when present (doc_change_columns.rs:256-270)
+    B.c_extra_off[c] = 0;
+    B.c_extra_len[c] = 0;
+    int rc = rle_next<0>(emeta, v, aux, isnull);
+    if (rc < 0) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+    if (rc == 0) {
+      if (isnull || (v & 15) != 7) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+      u64 el = v >> 4;
+      if (el > D.ccol[CC_EXTRA_RAW].len || extra_off > D.ccol[CC_EXTRA_RAW].len - el) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+      B.c_extra_off[c] = (u32)(D.ccol[CC_EXTRA_RAW].off + extra_off);
+      B.c_extra_len[c] = (u32)el;
+      extra_off += el;
+    }
+  }
+  // termination quirk (doc_change_columns.rs:196-207, 243-253): the actor column ran out or produced
+  // a null; the row set is complete only if at least one other column is exhausted as well
+  {
+    bool s_none = delta_next(seq, sv, isnull) == 1;
+    bool m_none = delta_next(maxop, sv, isnull) == 1;
+    bool t_none = delta_next(time, sv, isnull) == 1;
+    bool d_none = rle_next<0>(dnum, v, aux, isnull) == 1;
+    if (!(s_none || m_none || t_none || d_none)) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+  }
+  // per-actor chains in file order + ordering checks (change_collector.rs:56-62, 105-118)
+  u32 ab = B.actor_base[d];
+  for (u32 i = 0; i < C.n_chg; i++) {
+    u32 c = cb + i, a = ab + B.c_actor[c];
+    u32 last = B.a_last_chg[a];
+    if (last == AMH_EMPTY32) {
+      B.a_first_chg[a] = c;
+      if (B.c_seq[c] != 1) { amh_fail(B, d, AMH_E_CHANGES_OUT_OF_ORDER); return; }
+    } else {
+      if (B.c_max_op[last] > B.c_max_op[c]) { amh_fail(B, d, AMH_E_CHANGES_OUT_OF_ORDER); return; }
+      if (B.c_seq[last] != B.c_seq[c] - 1) { amh_fail(B, d, AMH_E_CHANGES_OUT_OF_ORDER); return; }
+      B.c_next_same_actor[last] = c;
+    }
+    B.a_last_chg[a] = c;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5  op column decode — rle.rs:175-210, delta.rs:79-95, boolean.rs:84-101, value.rs:209-272
+//     (meta only).  Thread per (document, column stream); each stream expands its runs into the
+//     column array of the batch-wide SoA.  Null / exhausted = AMH_NULL32.
+// ------------------------------------------------------------------------------------------
+AMH_DEV void k_decode_ops(const BatchDev& B, u32 gid) {
+  u32 d = gid / OC_COUNT, col = gid % OC_COUNT;
+  if (d >= B.n_docs || B.status[d]) return;
+  const DocDesc& D = B.desc[d];
+  const DocCounts& C = B.cnt[d];
+  if (C.n_rows == 0) return;
+  const u8* p = B.arena + D.chunk_off;
+  u32 rb = B.row_base[d], n = C.n_rows;
+  u32 off = D.ocol[col].off, len = D.ocol[col].len;
+  u64 v; u32 aux; bool isnull; i64 sv;
+  switch (col) {
+    case OC_OBJ_ACTOR: case OC_OBJ_CTR: case OC_KEY_ACTOR: case OC_ID_ACTOR: case OC_ACTION: {
+      RleDec r;
+      rle_init(r, p, off, len);
+      u32* out32 = col == OC_OBJ_ACTOR ? B.r_obj_actor : col == OC_OBJ_CTR ? B.r_obj_ctr : col == OC_KEY_ACTOR ? B.r_key_actor : B.r_id_actor;
+      for (u32 i = 0; i < n; i++) {
+        int rc = rle_next<0>(r, v, aux, isnull);
+        if (rc < 0) { amh_fail(B, d, AMH_E_READ_OP); return; }
+        bool none = rc == 1 || isnull;
+        if (col == OC_ACTION) {
+          if (none) { amh_fail(B, d, AMH_E_READ_OP); return; }
+          if (v > 7) { amh_fail(B, d, AMH_E_INVALID_OP); return; }
+          B.r_action[rb + i] = (u8)v;
+        } else {
+          if (!none && v >= 0xFFFFFFFFull) { amh_fail(B, d, col == OC_OBJ_CTR ? AMH_E_READ_OP : AMH_E_MISSING_ACTOR); return; }
+          out32[rb + i] = none ? AMH_NULL32 : (u32)v;
+        }
+      }
+      break;
+    }
+    case OC_KEY_CTR: case OC_ID_CTR: {
+      DeltaDec r;
+      delta_init(r, p, off, len);
+      u32* out32 = col == OC_KEY_CTR ? B.r_key_ctr : B.r_id_ctr;
+      for (u32 i = 0; i < n; i++) {
+        int rc = delta_next(r, sv, isnull);
+        if (rc < 0) { amh_fail(B, d, AMH_E_READ_OP); return; }
+        bool none = rc == 1 || isnull;
+        if (!none && (sv < 0 || sv >= 0xFFFFFFFFll)) { amh_fail(B, d, AMH_E_READ_OP); return; }  // key.rs:172-179, opid.rs:107-113
+        out32[rb + i] = none ? AMH_NULL32 : (u32)sv;
+      }
+      break;
+    }
+    case OC_KEY_STR: case OC_MARK_NAME: {
+      RleDec r;
+      rle_init(r, p, off, len);
+      u32* o_off = col == OC_KEY_STR ? B.r_key_off : B.r_mark_off;
+      u32* o_len = col == OC_KEY_STR ? B.r_key_len : B.r_mark_len;
+      for (u32 i = 0; i < n; i++) {
+        int rc = rle_next<2>(r, v, aux, isnull);
+        if (rc < 0) { amh_fail(B, d, AMH_E_READ_OP); return; }
+        bool none = rc == 1 || isnull;
+        o_off[rb + i] = none ? 0 : (u32)v;
+        o_len[rb + i] = none ? AMH_NULL32 : aux;
+      }
+      break;
+    }
+    case OC_INSERT: {
+      BoolDec r;
+      bool_init(r, p, off, len);
+      for (u32 i = 0; i < n; i++) {
+        bool b;
+        int rc = bool_next(r, b);
+        if (rc != 0) { amh_fail(B, d, AMH_E_READ_OP); return; }  // exhausted = unexpected null (column_decoder.rs:44-50)
+        B.r_insert[rb + i] = b;
+      }
+      break;
+    }
+    case OC_EXPAND: {
+      BoolDec r;
+      bool_init(r, p, off, len);
+      for (u32 i = 0; i < n; i++) {
+        bool b = false;
+        if (len) {
+          int rc = bool_next(r, b);
+          if (rc < 0) { amh_fail(B, d, AMH_E_READ_OP); return; }
+          if (rc == 1) b = false;
+        }
+        B.r_expand[rb + i] = b;
+      }
+      break;
+    }
+    case OC_VAL_META: {
+      RleDec r;
+      rle_init(r, p, off, len);
+      u64 raw_off = 0, raw_len = D.ocol[OC_VAL_RAW].len;
+      for (u32 i = 0; i < n; i++) {
+        int rc = rle_next<0>(r, v, aux, isnull);
+        if (rc != 0 || isnull) { amh_fail(B, d, AMH_E_READ_OP); return; }
+        B.r_vmeta[rb + i] = v;
+        B.r_vraw_off[rb + i] = (u32)raw_off;
+        if ((v & 15) >= 3) {  // null / bool never touch the raw column (value.rs:221-224)
+          u64 l = v >> 4;
+          if (l > raw_len || raw_off > raw_len - l) { amh_fail(B, d, AMH_E_READ_OP); return; }
+          raw_off += l;
+        }
+      }
+      break;
+    }
+    case OC_SUCC_NUM: {
+      RleDec r;
+      rle_init(r, p, off, len);
+      u32 sb = B.succ_base[d], run = 0;
+      for (u32 i = 0; i < n; i++) {
+        int rc = rle_next<0>(r, v, aux, isnull);
+        if (rc != 0 || isnull) { amh_fail(B, d, AMH_E_READ_OP); return; }
+        B.r_succ_cnt[rb + i] = (u32)v;
+        B.r_succ_base[rb + i] = sb + run;
+        for (u32 k = 0; k < (u32)v; k++) B.s_row[sb + run + k] = rb + i;
+        run += (u32)v;
+      }
+      break;
+    }
+    case OC_SUCC_ACTOR: {
+      RleDec r;
+      rle_init(r, p, off, len);
+      u32 sb = B.succ_base[d];
+      for (u32 i = 0; i < C.n_succ; i++) {
+        int rc = rle_next<0>(r, v, aux, isnull);
+        if (rc != 0 || isnull) { amh_fail(B, d, AMH_E_READ_OP); return; }
+        if (v >= 0xFFFFFFFFull) { amh_fail(B, d, AMH_E_MISSING_ACTOR); return; }
+        B.s_actor[sb + i] = (u32)v;
+      }
+      break;
+    }
+    case OC_SUCC_CTR: {
+      DeltaDec r;
+      delta_init(r, p, off, len);
+      u32 sb = B.succ_base[d];
+      for (u32 i = 0; i < C.n_succ; i++) {
+        int rc = delta_next(r, sv, isnull);
+        if (rc != 0 || isnull) { amh_fail(B, d, AMH_E_READ_OP); return; }
+        if (sv < 0 || sv >= 0xFFFFFFFFll) { amh_fail(B, d, AMH_E_READ_OP); return; }
+        B.s_ctr[sb + i] = (u32)sv;
+      }
+      break;
+    }
+    default: break;  // OC_VAL_RAW has no stream of its own
+  }
+}
+
+// parse the payload of an int-like value (types 3,4,8,9) strictly; false = malformed
+AMH_DEV bool val_int(const BatchDev& B, u32 r, i64& out) {
+  u32 d = B.r_doc[r];
+  const DocDesc& D = B.desc[d];
+  const u8* p = B.arena + D.chunk_off;
+  u64 m = B.r_vmeta[r], l = m >> 4;
+  u64 pos = (u64)D.ocol[OC_VAL_RAW].off + B.r_vraw_off[r], end = pos + l;
+  if ((m & 15) == 3) {
+    u64 u;
+    if (rd_uleb_strict(p, pos, end, u) || pos != end) return false;
+    out = (i64)u;
+    return true;
+  }
+  if (rd_sleb_strict(p, pos, end, out) || pos != end) return false;
+  return true;
+}
+
+AMH_DEV u32 find_doc(const u32* base, u32 n_docs, u32 idx) {  // largest d with base[d] <= idx
+  u32 lo = 0, hi = n_docs;
+  while (hi - lo > 1) {
+    u32 mid = (lo + hi) / 2;
+    if (base[mid] <= idx) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// ------------------------------------------------------------------------------------------
+// K6  row validation + normalisation + id table insert — composite iterators obj_id.rs:123-141,
+//     key.rs:146-187, opid.rs:95-120, value.rs:209-308; import_op reconstruct_document.rs:342-375.
+//     Thread per row.
+// ------------------------------------------------------------------------------------------
+AMH_DEV void k_rows(const BatchDev& B, u32 r) {
+  u32 d = find_doc(B.row_base, B.n_docs, r);
+  B.r_doc[r] = d;
+  B.t_pred_cnt[r] = 0;
+  B.r_inc_cnt[r] = 0;
+  B.r_inc_sum[r] = 0;
+  if (B.status[d]) return;
+  const DocDesc& D = B.desc[d];
+  u32 na = D.n_actors;
+  u32 ia = B.r_id_actor[r], ic = B.r_id_ctr[r];
+  if (ia == AMH_NULL32 || ic == AMH_NULL32) { amh_fail(B, d, AMH_E_READ_OP); return; }
+  if (ia >= na) { amh_fail(B, d, AMH_E_MISSING_ACTOR); return; }
+  amh_atomic_max(&B.doc_max_op[d], ic);
+  // object id
+  u32 oa = B.r_obj_actor[r], oc = B.r_obj_ctr[r];
+  if (D.ocol[OC_OBJ_ACTOR].len == 0 && D.ocol[OC_OBJ_CTR].len == 0) { oa = 0; oc = 0; }
+  else if (oa == AMH_NULL32 && oc == AMH_NULL32) { oa = 0; oc = 0; }
+  else if (oa != AMH_NULL32 && oc != AMH_NULL32) { if (oc == 0) oa = 0; }
+  else if (oc == 0) { oa = 0; }
+  else { amh_fail(B, d, AMH_E_READ_OP); return; }
+  if (oc != 0 && oa >= na) { amh_fail(B, d, AMH_E_MISSING_ACTOR); return; }
+  if (oc == 0 && na == 0) { amh_fail(B, d, AMH_E_MISSING_ACTOR); return; }  // check_opid(root) needs actor slot 0
+  B.r_obj_actor[r] = oa;
+  B.r_obj_ctr[r] = oc;
+  // key
+  u32 ka = B.r_key_actor[r], kc = B.r_key_ctr[r], kl = B.r_key_len[r];
+  bool an = ka == AMH_NULL32, cn = kc == AMH_NULL32, sn = kl == AMH_NULL32;
+  if (an && cn && !sn) { /* map key */ }
+  else if (an && !cn && kc == 0 && sn) { B.r_key_actor[r] = 0; }  // HEAD
+  else if (!an && !cn && sn) {
+    if (ka >= na) { amh_fail(B, d, AMH_E_MISSING_ACTOR); return; }
+    if (kc == 0 && ka != 0) { amh_fail(B, d, AMH_E_UNSUPPORTED); return; }  // ElemId(0@a), a != 0: not HEAD, never written
+  } else { amh_fail(B, d, AMH_E_READ_OP); return; }
+  // value payload
+  u64 m = B.r_vmeta[r];
+  u32 vt = (u32)(m & 15);
+  u64 vl = m >> 4;
+  const u8* p = B.arena + D.chunk_off;
+  if (vt == 3 || vt == 4 || vt == 8 || vt == 9) {
+    i64 tmp;
+    if (!val_int(B, r, tmp)) { amh_fail(B, d, AMH_E_READ_OP); return; }
+  } else if (vt == 5) {
+    if (vl != 8) { amh_fail(B, d, AMH_E_READ_OP); return; }
+  } else if (vt == 6) {
+    if (!amh_valid_utf8(p + D.ocol[OC_VAL_RAW].off + B.r_vraw_off[r], vl)) { amh_fail(B, d, AMH_E_READ_OP); return; }
+  }
+  u8 action = B.r_action[r];
+  if (action == 5 && vt != 3 && vt != 4) { amh_fail(B, d, AMH_E_INVALID_OP); return; }
+  // id -> row
+  u64 base = B.ht_base[d], size = B.ht_base[d + 1] - base, mask = size - 1;
+  u64 key = pack_id(ic, ia) + 1, h = amh_mix64(key) & mask;
+  for (u64 i = 0; i < size; i++) {
+    u64 old = amh_atomic_cas64(&B.ht_key[base + h], 0, key);
+    if (old == 0) { B.ht_val[base + h] = r; break; }
+    if (old == key) { amh_fail(B, d, AMH_E_UNSUPPORTED); return; }  // duplicate op id in one document
+    h = (h + 1) & mask;
+  }
+}
+
+AMH_DEV bool is_make(u8 action) { return action == 0 || action == 2 || action == 4 || action == 6; }
+
+// ------------------------------------------------------------------------------------------
+// K7  object order: every object is one contiguous run, runs ascend by (ctr, actor index), and the
+//     object's create op precedes its first use — reconstruct_document.rs:159-183.  Thread per row.
+// ------------------------------------------------------------------------------------------
+AMH_DEV void k_obj_order(const BatchDev& B, u32 r) {
+  u32 d = B.r_doc[r];
+  if (B.status[d]) return;
+  u32 oc = B.r_obj_ctr[r], oa = B.r_obj_actor[r];
+  u32 pc = 0, pa = 0;
+  if (r > B.row_base[d]) { pc = B.r_obj_ctr[r - 1]; pa = B.r_obj_actor[r - 1]; }
+  if (oc == pc && oa == pa) return;
+  u32 mk = ht_find(B, d, pack_id(oc, oa));
+  if (mk == AMH_EMPTY32 || mk >= r || !is_make(B.r_action[mk])) { amh_fail(B, d, AMH_E_OPS_OUT_OF_ORDER); return; }
+  if (pack_id(oc, oa) < pack_id(pc, pa)) { amh_fail(B, d, AMH_E_OPS_OUT_OF_ORDER); return; }
+}
+
+// delete-table insert-or-find; returns global slot, AMH_EMPTY32 if the table is full (cannot happen)
+AMH_DEV u32 dt_claim(const BatchDev& B, u32 d, u64 id) {
+  u64 base = B.dt_base[d], size = B.dt_base[d + 1] - base, mask = size - 1;
+  u64 key = id + 1, h = amh_mix64(key) & mask;
+  for (u64 i = 0; i < size; i++) {
+    u64 old = amh_atomic_cas64(&B.dt_key[base + h], 0, key);
+    if (old == 0 || old == key) return (u32)(base + h);
+    h = (h + 1) & mask;
+  }
+  return AMH_EMPTY32;
+}
+
+AMH_DEV int lamport_cmp(const BatchDev& B, u32 d, u32 c1, u32 a1, u32 c2, u32 a2) {
+  if (c1 != c2) return c1 < c2 ? -1 : 1;
+  u32 ab = B.actor_base[d];
+  u32 r1 = B.actor_rank[ab + a1], r2 = B.actor_rank[ab + a2];
+  return r1 < r2 ? -1 : (r1 > r2 ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// K8  succ entries: ordering check, pred = inverse of succ inside the object, counter folding,
+//     delete discovery — reconstruct_document.rs:141-143, 285-287, 299-310, 347-358.
+//     Thread per succ entry.
+// ------------------------------------------------------------------------------------------
+AMH_DEV void k_succ(const BatchDev& B, u32 e) {
+  B.s_target[e] = AMH_EMPTY32;
+  u32 r = B.s_row[e];
+  if (r == AMH_EMPTY32) return;  // owning document failed while decoding
+  u32 d = B.r_doc[r];
+  if (B.status[d]) return;
+  u32 sa = B.s_actor[e], sc = B.s_ctr[e];
+  if (sa >= B.desc[d].n_actors) { amh_fail(B, d, AMH_E_MISSING_ACTOR); return; }
+  amh_atomic_max(&B.doc_max_op[d], sc);
+  if (e > B.r_succ_base[r]) {
+    u32 pa = B.s_actor[e - 1], pc = B.s_ctr[e - 1];
+    if (pa >= B.desc[d].n_actors) return;  // flagged by that entry's own thread
+    if (lamport_cmp(B, d, pc, pa, sc, sa) >= 0) { amh_fail(B, d, AMH_E_SUCC_OUT_OF_ORDER); return; }
+  }
+  u32 tr = ht_find(B, d, pack_id(sc, sa));
+  if (tr != AMH_EMPTY32 && B.r_obj_ctr[tr] == B.r_obj_ctr[r] && B.r_obj_actor[tr] == B.r_obj_actor[r]) {
+    B.s_target[e] = tr;
+    amh_atomic_add(&B.t_pred_cnt[tr], 1);
+    if (B.r_action[r] == 1 && (B.r_vmeta[r] & 15) == 8 && B.r_action[tr] == 5) {
+      i64 inc = 0;
+      if (val_int(B, tr, inc)) {
+        amh_atomic_add_i64(&B.r_inc_sum[r], inc);
+        amh_atomic_add(&B.r_inc_cnt[r], 1);
+      }
+    }
+  } else {
+    u32 slot = dt_claim(B, d, pack_id(sc, sa));
+    if (slot == AMH_EMPTY32) { amh_fail(B, d, AMH_E_UNSUPPORTED); return; }
+    u32 t = B.tot_rows + slot;
+    B.d_doc[slot] = d;
+    amh_atomic_min(&B.d_first_pred_row[slot], r);
+    amh_atomic_add(&B.t_pred_cnt[t], 1);
+    B.s_target[e] = t;
+  }
+}
+
+// accessors over the unified op index space -------------------------------------------------
+AMH_DEV bool op_is_del(const BatchDev& B, u32 t) { return t >= B.tot_rows; }
+AMH_DEV u32 op_doc(const BatchDev& B, u32 t) { return t < B.tot_rows ? B.r_doc[t] : B.d_doc[t - B.tot_rows]; }
+AMH_DEV void op_id(const BatchDev& B, u32 t, u32& ctr, u32& actor) {
+  if (t < B.tot_rows) { ctr = B.r_id_ctr[t]; actor = B.r_id_actor[t]; }
+  else { u64 k = B.dt_key[t - B.tot_rows] - 1; ctr = (u32)(k >> 32); actor = (u32)k; }
+}
+// the row whose object / key a synthesized delete inherits (reconstruct_document.rs:316-320, 270-279)
+AMH_DEV u32 op_key_row(const BatchDev& B, u32 t) { return t < B.tot_rows ? t : B.d_first_pred_row[t - B.tot_rows]; }
+
+// ------------------------------------------------------------------------------------------
+// K9  op -> change — change_collector.rs:81-96 (first change of the op's actor with max_op >= ctr).
+//     Also checks the delete's first pred is a Put/Make (reconstruct_document.rs:270, 317-320).
+//     Thread per op t.
+// ------------------------------------------------------------------------------------------
+AMH_DEV void k_bucket(const BatchDev& B, u32 t) {
+  B.t_chg[t] = AMH_EMPTY32;
+  if (op_is_del(B, t) && B.dt_key[t - B.tot_rows] == 0) return;
+  u32 d = op_doc(B, t);
+  if (B.status[d]) return;
+  if (op_is_del(B, t)) {
+    u32 fp = B.d_first_pred_row[t - B.tot_rows];
+    u8 a = B.r_action[fp];
+    if (!(a == 1 || is_make(a))) { amh_fail(B, d, AMH_E_MISSING_OPS); return; }
+  }
+  u32 ctr, actor;
+  op_id(B, t, ctr, actor);
+  u32 c = B.a_first_chg[B.actor_base[d] + actor];
+  if (c == AMH_EMPTY32) { amh_fail(B, d, AMH_E_COLLECT_MISSING_ACTOR); return; }
+  while (c != AMH_EMPTY32 && B.c_max_op[c] < ctr) c = B.c_next_same_actor[c];
+  if (c == AMH_EMPTY32) { amh_fail(B, d, AMH_E_MISSING_CHANGE); return; }
+  B.t_chg[t] = c;
+  amh_atomic_add(&B.c_nops[c], 1);
+}
+
+// K10  start_op per change — change_collector.rs:179, 194-202.  Thread per change.
+AMH_DEV void k_chg_finish(const BatchDev& B, u32 c) {
+  u32 d = B.c_doc[c];
+  B.c_start_op[c] = 1;
+  if (B.status[d]) { B.c_nops[c] = 0; return; }
+  u64 n = B.c_nops[c], mo = B.c_max_op[c];
+  if (n > mo) { amh_fail(B, d, AMH_E_INCORRECT_MAX_OP); B.c_nops[c] = 0; return; }
+  u64 start = mo - n + 1;
+  if (start == 0) { amh_fail(B, d, AMH_E_COLLECT_MISSING_OPS); B.c_nops[c] = 0; return; }
+  B.c_start_op[c] = start;
+}
+
+// ------------------------------------------------------------------------------------------
+// K11  order the ops of each change by id (change_collector.rs:180).  The ids of a well-formed
+//      change are exactly start_op..max_op of one actor, so the sorted position is ctr - start_op:
+//      a scatter, not a sort.  A gap or collision means the document is not of that shape.
+//      Thread per op t.
+// ------------------------------------------------------------------------------------------
+AMH_DEV void k_place(const BatchDev& B, u32 t) {
+  u32 c = B.t_chg[t];
+  if (c == AMH_EMPTY32) return;
+  u32 d = B.c_doc[c];
+  if (B.status[d]) return;
+  u32 ctr, actor;
+  op_id(B, t, ctr, actor);
+  u64 start = B.c_start_op[c];
+  if (ctr < start || ctr - start >= B.c_nops[c]) { amh_fail(B, d, AMH_E_UNSUPPORTED); return; }
+  u32 slot = B.c_op_base[c] + (u32)(ctr - start);
+  if (amh_atomic_cas(&B.ops_sorted[slot], AMH_EMPTY32, t) != AMH_EMPTY32) amh_fail(B, d, AMH_E_UNSUPPORTED);
+}
+
+// K12  pred lists: scatter each succ edge to its target, then order each list by lamport id
+//      (reconstruct_document.rs:299-301, 325).  Thread per succ entry / per op.
+AMH_DEV void k_pred_fill(const BatchDev& B, u32 e) {
+  u32 t = B.s_target[e];
+  if (t == AMH_EMPTY32) return;
+  u32 r = B.s_row[e];
+  if (r == AMH_EMPTY32 || B.status[B.r_doc[r]]) return;
+  u32 pos = B.t_pred_base[t] + amh_atomic_add(&B.t_pred_fill[t], 1);
+  B.pred_ids[pos] = pack_id(B.r_id_ctr[r], B.r_id_actor[r]);
+}
+AMH_DEV void k_pred_sort(const BatchDev& B, u32 t) {
+  u32 n = B.t_pred_cnt[t];
+  if (n < 2) return;
+  u32 d = op_doc(B, t);
+  if (B.status[d]) return;
+  u64* v = B.pred_ids + B.t_pred_base[t];
+  for (u32 i = 1; i < n; i++) {
+    u64 x = v[i];
+    u32 j = i;
+    while (j > 0 && lamport_cmp(B, d, (u32)(v[j - 1] >> 32), (u32)v[j - 1], (u32)(x >> 32), (u32)x) > 0) { v[j] = v[j - 1]; j--; }
+    v[j] = x;
+  }
+}
+
+// op views used by the actor table and the encoder -------------------------------------------
+struct OpKey { u8 kind; u32 actor, ctr, str_off, str_len; };  // kind 0 prop, 1 head, 2 elem
+AMH_DEV OpKey op_key(const BatchDev& B, u32 t) {
+  OpKey k;
+  u32 r = op_key_row(B, t);
+  k.actor = k.ctr = k.str_off = k.str_len = 0;
+  if (B.r_key_len[r] != AMH_NULL32) { k.kind = 0; k.str_off = B.r_key_off[r]; k.str_len = B.r_key_len[r]; return k; }
+  if (op_is_del(B, t) && B.r_insert[r]) { k.kind = 2; k.actor = B.r_id_actor[r]; k.ctr = B.r_id_ctr[r]; return k; }
+  if (B.r_key_ctr[r] == 0) { k.kind = 1; return k; }
+  k.kind = 2; k.actor = B.r_key_actor[r]; k.ctr = B.r_key_ctr[r];
+  return k;
+}
+
+// K13  actors referenced by each change (change_actors.rs:74-97).  Thread per op t.
+AMH_DEV void k_actor_mark(const BatchDev& B, u32 t) {
+  u32 c = B.t_chg[t];
+  if (c == AMH_EMPTY32) return;
+  u32 d = B.c_doc[c];
+  if (B.status[d]) return;
+  u32* map = B.chg_actor_map + B.c_map_base[c];
+  OpKey k = op_key(B, t);
+  if (k.kind == 2) map[k.actor] = 1;
+  u32 kr = op_key_row(B, t);
+  if (B.r_obj_ctr[kr] != 0) map[B.r_obj_actor[kr]] = 1;
+  u32 n = B.t_pred_cnt[t];
+  const u64* pv = B.pred_ids + B.t_pred_base[t];
+  for (u32 i = 0; i < n; i++) map[(u32)pv[i]] = 1;
+}
+// K14  change actor table: author first, the others in bytewise order (change_actors.rs:98-106).
+//      Thread per change.
+AMH_DEV void k_actor_rank(const BatchDev& B, u32 c) {
+  u32 d = B.c_doc[c];
+  B.c_n_other[c] = 0;
+  if (B.status[d]) return;
+  u32 na = B.desc[d].n_actors, ab = B.actor_base[d];
+  u32* map = B.chg_actor_map + B.c_map_base[c];
+  u32 author = B.c_actor[c], next = 1;
+  for (u32 k = 0; k < na; k++) {
+    u32 a = B.actor_by_rank[ab + k];
+    if (a == author) { map[a] = 0; continue; }
+    if (map[a] == 1) map[a] = next++;
+    else map[a] = AMH_EMPTY32;
+  }
+  B.c_n_other[c] = next - 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// K15  per-change column encode — change_op_columns.rs:146-251 driving rle.rs:8-141,
+//      delta.rs:10-43, boolean.rs:11-51,105-138, key.rs:236-257, obj_id.rs:158-172,
+//      opid_list.rs:244-254, value.rs:320-369,412-432; op views per op_as_changeop.rs:86-145.
+//      Thread per (change, column).  Runs twice: size pass (out == null) and store pass.
+// ------------------------------------------------------------------------------------------
+struct ColWriter {
+  u8* out;   // null = size only
+  u32 pos;
+};
+AMH_DEV void cw_uleb(ColWriter& w, u64 v) { w.pos += wr_uleb(w.out ? w.out + w.pos : (u8*)0, v); }
+AMH_DEV void cw_sleb(ColWriter& w, i64 v) { w.pos += wr_sleb(w.out ? w.out + w.pos : (u8*)0, v); }
+AMH_DEV void cw_bytes(ColWriter& w, const u8* p, u32 n) {
+  if (w.out) for (u32 i = 0; i < n; i++) w.out[w.pos + i] = p[i];
+  w.pos += n;
+}
+
+// RLE state machine restated with O(1) state: a literal run's values are streamed behind a
+// one-byte header slot which is widened in place if the run turns out longer than 64 values.
+// KIND 0 = u64, 1 = i64, 2 = string (value = pointer + length)
+struct RleVal { u64 v; const u8* s; u32 n; };
+template <int KIND> AMH_DEV bool rv_eq(const RleVal& a, const RleVal& b) {
+  if (KIND != 2) return a.v == b.v;
+  if (a.n != b.n) return false;
+  for (u32 i = 0; i < a.n; i++) if (a.s[i] != b.s[i]) return false;
+  return true;
+}
+template <int KIND> AMH_DEV void rv_write(ColWriter& w, const RleVal& x) {
+  if (KIND == 0) cw_uleb(w, x.v);
+  else if (KIND == 1) cw_sleb(w, (i64)x.v);
+  else { cw_uleb(w, x.n); cw_bytes(w, x.s, x.n); }
+}
+template <int KIND> struct RleEnc {
+  int st;        // 0 Empty 1 InitialNullRun 2 NullRun 3 LiteralRun 4 LoneVal 5 Run
+  u64 n;         // run / null-run length
+  RleVal val;    // LoneVal / Run value / LiteralRun "last"
+  u32 lit_pos;   // header slot of the open literal run
+  u64 lit_cnt;   // values already streamed into it
+};
+template <int KIND> AMH_DEV void re_init(RleEnc<KIND>& e) { e.st = 0; e.n = 0; e.lit_pos = 0; e.lit_cnt = 0; e.val.v = 0; e.val.s = 0; e.val.n = 0; }
+template <int KIND> AMH_DEV void re_lit_open(ColWriter& w, RleEnc<KIND>& e) { e.lit_pos = w.pos; w.pos += 1; e.lit_cnt = 0; }
+template <int KIND> AMH_DEV void re_lit_push(ColWriter& w, RleEnc<KIND>& e, const RleVal& x) { rv_write<KIND>(w, x); e.lit_cnt++; }
+template <int KIND> AMH_DEV void re_lit_close(ColWriter& w, RleEnc<KIND>& e) {
+  i64 hdr = -(i64)e.lit_cnt;
+  u32 h = sleb_size(hdr);
+  if (h > 1) {
+    if (w.out) for (u32 i = w.pos; i > e.lit_pos + 1; i--) w.out[i - 1 + (h - 1)] = w.out[i - 1];
+    w.pos += h - 1;
+  }
+  if (w.out) wr_sleb(w.out + e.lit_pos, hdr);
+}
+template <int KIND> AMH_DEV void re_flush_run(ColWriter& w, const RleVal& v, u64 n) { cw_sleb(w, (i64)n); rv_write<KIND>(w, v); }
+AMH_DEV void re_flush_nulls(ColWriter& w, u64 n) { cw_sleb(w, 0); cw_uleb(w, n); }
+template <int KIND> AMH_DEV void re_null(ColWriter& w, RleEnc<KIND>& e) {  // rle.rs:71-90
+  switch (e.st) {
+    case 0: e.st = 1; e.n = 1; break;
+    case 1: case 2: e.n++; break;
+    case 4: re_lit_open(w, e); re_lit_push(w, e, e.val); re_lit_close(w, e); e.st = 2; e.n = 1; break;
+    case 5: re_flush_run<KIND>(w, e.val, e.n); e.st = 2; e.n = 1; break;
+    case 3: re_lit_push(w, e, e.val); re_lit_close(w, e); e.st = 2; e.n = 1; break;
+  }
+}
+template <int KIND> AMH_DEV void re_value(ColWriter& w, RleEnc<KIND>& e, const RleVal& x) {  // rle.rs:92-126
+  switch (e.st) {
+    case 0: e.st = 4; e.val = x; break;
+    case 4:
+      if (rv_eq<KIND>(e.val, x)) { e.st = 5; e.n = 2; }
+      else { re_lit_open(w, e); re_lit_push(w, e, e.val); e.val = x; e.st = 3; }
+      break;
+    case 5:
+      if (rv_eq<KIND>(e.val, x)) e.n++;
+      else { re_flush_run<KIND>(w, e.val, e.n); e.st = 4; e.val = x; }
+      break;
+    case 3:
+      if (rv_eq<KIND>(e.val, x)) { re_lit_close(w, e); e.st = 5; e.n = 2; }
+      else { re_lit_push(w, e, e.val); e.val = x; }
+      break;
+    case 1: case 2: re_flush_nulls(w, e.n); e.st = 4; e.val = x; break;
+  }
+}
+template <int KIND> AMH_DEV void re_finish(ColWriter& w, RleEnc<KIND>& e) {  // rle.rs:31-46
+  switch (e.st) {
+    case 2: re_flush_nulls(w, e.n); break;
+    case 4: re_lit_open(w, e); re_lit_push(w, e, e.val); re_lit_close(w, e); break;
+    case 5: re_flush_run<KIND>(w, e.val, e.n); break;
+    case 3: re_lit_push(w, e, e.val); re_lit_close(w, e); break;
+    default: break;  // Empty, InitialNullRun: nothing (rle.rs:33)
+  }
+}
+struct DeltaEnc { RleEnc<1> r; i64 abs; };
+AMH_DEV void de_value(ColWriter& w, DeltaEnc& e, i64 v) {  // delta.rs:23-27
+  i64 dlt;
+  if (__builtin_sub_overflow(v, e.abs, &dlt)) dlt = v > e.abs ? INT64_MAX : INT64_MIN;
+  RleVal x; x.v = (u64)dlt; x.s = 0; x.n = 0;
+  re_value<1>(w, e.r, x);
+  e.abs = v;
+}
+
+// the value an op carries into a change (op_as_changeop.rs:94-103): kind 0 = null, 1 = stored
+// bytes as they are, 2 = integer re-encoded as Int (increments)
+struct OpVal { int kind; u64 meta; const u8* raw; u32 raw_len; i64 i; };
+AMH_DEV OpVal op_val(const BatchDev& B, u32 t) {
+  OpVal v; v.kind = 0; v.meta = 0; v.raw = 0; v.raw_len = 0; v.i = 0;
+  if (op_is_del(B, t)) return v;
+  u8 a = B.r_action[t];
+  if (is_make(a) || a == 3) return v;
+  if (a == 7 && B.r_mark_len[t] == AMH_NULL32) return v;
+  if (a == 5) {
+    val_int(B, t, v.i);
+    v.kind = 2;
+    v.meta = ((u64)sleb_size(v.i) << 4) | 4;
+    return v;
+  }
+  u64 m = B.r_vmeta[t];
+  u32 vt = (u32)(m & 15);
+  v.kind = 1;
+  if (vt <= 2) { v.meta = vt; return v; }
+  const DocDesc& D = B.desc[B.r_doc[t]];
+  v.meta = m;
+  v.raw = B.arena + D.chunk_off + D.ocol[OC_VAL_RAW].off + B.r_vraw_off[t];
+  v.raw_len = (u32)(m >> 4);
+  return v;
+}
+
+// encode one column of one change; returns its length
+AMH_DEV u32 encode_change_col(const BatchDev& B, u32 c, u32 col, u8* out) {
+  u32 d = B.c_doc[c];
+  const u8* chunk = B.arena + B.desc[d].chunk_off;
+  const u32* ops = B.ops_sorted + B.c_op_base[c];
+  const u32* amap = B.chg_actor_map + B.c_map_base[c];
+  u32 n = B.c_nops[c];
+  ColWriter w; w.out = out; w.pos = 0;
+  RleVal x; x.v = 0; x.s = 0; x.n = 0;
+  switch (col) {
+    case 0: case 1: {  // objActor / objCtr (obj_id.rs:158-172); both vanish when every op is on the root
+      RleEnc<0> e; re_init(e);
+      for (u32 i = 0; i < n; i++) {
+        u32 kr = op_key_row(B, ops[i]);
+        if (B.r_obj_ctr[kr] == 0) re_null(w, e);
+        else { x.v = col == 0 ? amap[B.r_obj_actor[kr]] : B.r_obj_ctr[kr]; re_value(w, e, x); }
+      }
+      re_finish(w, e);
+      break;
+    }
+    case 2: {  // keyActor
+      RleEnc<0> e; re_init(e);
+      for (u32 i = 0; i < n; i++) {
+        OpKey k = op_key(B, ops[i]);
+        if (k.kind == 2) { x.v = amap[k.actor]; re_value(w, e, x); } else re_null(w, e);
+      }
+      re_finish(w, e);
+      break;
+    }
+    case 3: {  // keyCtr (delta; HEAD = 0)
+      DeltaEnc e; re_init(e.r); e.abs = 0;
+      for (u32 i = 0; i < n; i++) {
+        OpKey k = op_key(B, ops[i]);
+        if (k.kind == 0) re_null(w, e.r);
+        else de_value(w, e, k.kind == 1 ? 0 : (i64)k.ctr);
+      }
+      re_finish(w, e.r);
+      break;
+    }
+    case 4: {  // keyStr
+      RleEnc<2> e; re_init(e);
+      for (u32 i = 0; i < n; i++) {
+        OpKey k = op_key(B, ops[i]);
+        if (k.kind == 0) { x.s = chunk + k.str_off; x.n = k.str_len; re_value(w, e, x); } else re_null(w, e);
+      }
+      re_finish(w, e);
+      break;
+    }
+    case 5: {  // insert (boolean.rs:35-50)
+      bool last = false; u64 cnt = 0;
+      for (u32 i = 0; i < n; i++) {
+        u32 t = ops[i];
+        bool v = op_is_del(B, t) ? false : B.r_insert[t] != 0;
+        if (v == last) cnt++; else { cw_uleb(w, cnt); last = v; cnt = 1; }
+      }
+      if (cnt > 0) cw_uleb(w, cnt);
+      break;
+    }
+    case 6: {  // action
+      RleEnc<0> e; re_init(e);
+      for (u32 i = 0; i < n; i++) { u32 t = ops[i]; x.v = op_is_del(B, t) ? 3 : B.r_action[t]; re_value(w, e, x); }
+      re_finish(w, e);
+      break;
+    }
+    case 7: {  // valMeta
+      RleEnc<0> e; re_init(e);
+      for (u32 i = 0; i < n; i++) { OpVal v = op_val(B, ops[i]); x.v = v.meta; re_value(w, e, x); }
+      re_finish(w, e);
+      break;
+    }
+    case 8: {  // valRaw
+      for (u32 i = 0; i < n; i++) {
+        OpVal v = op_val(B, ops[i]);
+        if (v.kind == 1) cw_bytes(w, v.raw, v.raw_len);
+        else if (v.kind == 2) cw_sleb(w, v.i);
+      }
+      break;
+    }
+    case 9: {  // predNum
+      RleEnc<0> e; re_init(e);
+      for (u32 i = 0; i < n; i++) { x.v = B.t_pred_cnt[ops[i]]; re_value(w, e, x); }
+      re_finish(w, e);
+      break;
+    }
+    case 10: {  // predActor over the flattened lists
+      RleEnc<0> e; re_init(e);
+      for (u32 i = 0; i < n; i++) {
+        u32 t = ops[i], pn = B.t_pred_cnt[t];
+        const u64* pv = B.pred_ids + B.t_pred_base[t];
+        for (u32 k = 0; k < pn; k++) { x.v = amap[(u32)pv[k]]; re_value(w, e, x); }
+      }
+      re_finish(w, e);
+      break;
+    }
+    case 11: {  // predCtr: one delta chain across the flattened lists (opid_list.rs:69-72)
+      DeltaEnc e; re_init(e.r); e.abs = 0;
+      for (u32 i = 0; i < n; i++) {
+        u32 t = ops[i], pn = B.t_pred_cnt[t];
+        const u64* pv = B.pred_ids + B.t_pred_base[t];
+        for (u32 k = 0; k < pn; k++) de_value(w, e, (i64)(pv[k] >> 32));
+      }
+      re_finish(w, e.r);
+      break;
+    }
+    case 12: {  // expand (MaybeBoolean: nothing unless some op is a mark with expand, boolean.rs:131-137)
+      bool any = false;
+      for (u32 i = 0; i < n && !any; i++) { u32 t = ops[i]; any = !op_is_del(B, t) && B.r_action[t] == 7 && B.r_expand[t]; }
+      if (!any) break;
+      bool last = false; u64 cnt = 0;
+      for (u32 i = 0; i < n; i++) {
+        u32 t = ops[i];
+        bool v = !op_is_del(B, t) && B.r_action[t] == 7 && B.r_expand[t];
+        if (v == last) cnt++; else { cw_uleb(w, cnt); last = v; cnt = 1; }
+      }
+      if (cnt > 0) cw_uleb(w, cnt);
+      break;
+    }
+    case 13: {  // markName
+      RleEnc<2> e; re_init(e);
+      for (u32 i = 0; i < n; i++) {
+        u32 t = ops[i];
+        if (!op_is_del(B, t) && B.r_action[t] == 7 && B.r_mark_len[t] != AMH_NULL32) { x.s = chunk + B.r_mark_off[t]; x.n = B.r_mark_len[t]; re_value(w, e, x); }
+        else re_null(w, e);
+      }
+      re_finish(w, e);
+      break;
+    }
+  }
+  return w.pos;
+}
+
+AMH_DEV u32 chg_spec(u32 col) {
+  const u32 specs[AMH_NCOLS] = {0x01, 0x02, 0x11, 0x13, 0x15, 0x34, 0x42, 0x56, 0x57, 0x70, 0x71, 0x73, 0x94, 0xA5};
+  return specs[col];
+}
+
+AMH_DEV void k_encode_size(const BatchDev& B, u32 gid) {
+  u32 c = gid / AMH_NCOLS, col = gid % AMH_NCOLS;
+  if (c >= B.tot_chg) return;
+  B.c_col_len[(u64)c * AMH_NCOLS + col] = 0;
+  if (B.status[B.c_doc[c]]) return;
+  B.c_col_len[(u64)c * AMH_NCOLS + col] = encode_change_col(B, c, col, (u8*)0);
+}
+
+// K16  chunk layout of each change — storage/change.rs:460-488, chunk.rs:181-221.  Thread per change.
+AMH_DEV void k_chg_layout(const BatchDev& B, u32 c) {
+  u32 d = B.c_doc[c];
+  B.c_out_len[c] = 0;
+  B.c_body_len[c] = 0;
+  B.c_cols_off[c] = 0;
+  if (B.status[d]) return;
+  u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
+  if (cl[0] == 0) cl[1] = 0;     // ObjIdRange::encode -> None (obj_id.rs:79-81)
+  if (cl[10] == 0) cl[11] = 0;   // pred actor/ctr only when there are entries (change_op_columns.rs:304-315)
+  u32 ab = B.actor_base[d], na = B.desc[d].n_actors;
+  const u32* amap = B.chg_actor_map + B.c_map_base[c];
+  u64 len = 0;
+  len += uleb_size(B.c_ndeps[c]) + 32ull * B.c_ndeps[c];
+  u32 al = B.actor_len[ab + B.c_actor[c]];
+  len += uleb_size(al) + al;
+  len += uleb_size(B.c_seq[c]) + uleb_size(B.c_start_op[c]) + sleb_size(B.c_time[c]);
+  u32 ml = B.c_msg_len[c] == AMH_NULL32 ? 0 : B.c_msg_len[c];
+  len += uleb_size(ml) + ml;
+  len += uleb_size(B.c_n_other[c]);
+  for (u32 a = 0; a < na; a++)
+    if (amap[a] != AMH_EMPTY32 && amap[a] != 0) len += uleb_size(B.actor_len[ab + a]) + B.actor_len[ab + a];
+  u32 ncols = 0;
+  u64 meta = 0, data = 0;
+  for (u32 k = 0; k < AMH_NCOLS; k++)
+    if (cl[k]) { ncols++; meta += uleb_size(chg_spec(k)) + uleb_size(cl[k]); data += cl[k]; }
+  len += uleb_size(ncols) + meta;
+  u64 cols_off = len;
+  len += data + B.c_extra_len[c];
+  if (len > 0x7FFFFFF0ull) { amh_fail(B, d, AMH_E_TOO_LARGE); return; }
+  u32 hdr = 4 + 4 + 1 + uleb_size(len);
+  B.c_body_len[c] = (u32)len;
+  B.c_out_len[c] = hdr + (u32)len;
+  B.c_cols_off[c] = hdr + (u32)cols_off;
+}
+
+AMH_DEV void k_encode_store(const BatchDev& B, u32 gid) {
+  u32 c = gid / AMH_NCOLS, col = gid % AMH_NCOLS;
+  if (c >= B.tot_chg) return;
+  if (B.status[B.c_doc[c]]) return;
+  const u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
+  if (cl[col] == 0) return;
+  u64 off = B.c_out_off[c] + B.c_cols_off[c];
+  for (u32 k = 0; k < col; k++) off += cl[k];
+  encode_change_col(B, c, col, B.out_arena + off);
+}
+
+// ------------------------------------------------------------------------------------------
+// K17  assemble every change chunk of a document in file order (deps hashes come from earlier
+//      changes) and hash it — storage/change.rs:460-495, chunk.rs:181-193, 286-293;
+//      change_collector.rs:121-133.  Thread per document.
+// ------------------------------------------------------------------------------------------
+AMH_DEV void k_assemble_hash(const BatchDev& B, u32 d) {
+  if (B.status[d]) return;
+  const DocDesc& D = B.desc[d];
+  const u8* chunk = B.arena + D.chunk_off;
+  u32 cb = B.chg_base[d], nchg = B.cnt[d].n_chg, ab = B.actor_base[d], na = D.n_actors;
+  for (u32 i = 0; i < nchg; i++) {
+    u32 c = cb + i;
+    u8* out = B.out_arena + B.c_out_off[c];
+    u32 body_len = B.c_body_len[c];
+    u32 hdr = B.c_out_len[c] - body_len;
+    u32 pos = hdr;
+    // deps: hashes of earlier changes, sorted (change_collector.rs:178; change.rs:335-341)
+    u32 nd = B.c_ndeps[c];
+    pos += wr_uleb(out + pos, nd);
+    u8* deps = out + pos;
+    for (u32 k = 0; k < nd; k++) {
+      const u8* h = B.c_hash + (u64)(cb + B.dep_idx[B.c_dep_base[c] + k]) * 32;
+      // insertion sort by bytes
+      u32 j = k;
+      while (j > 0 && amh_memcmp(deps + 32 * (j - 1), 32, h, 32) > 0) {
+        for (int b = 0; b < 32; b++) deps[32 * j + b] = deps[32 * (j - 1) + b];
+        j--;
+      }
+      for (int b = 0; b < 32; b++) deps[32 * j + b] = h[b];
+    }
+    pos += 32 * nd;
+    u32 a = ab + B.c_actor[c];
+    pos += wr_uleb(out + pos, B.actor_len[a]);
+    for (u32 b = 0; b < B.actor_len[a]; b++) out[pos++] = chunk[B.actor_off[a] + b];
+    pos += wr_uleb(out + pos, B.c_seq[c]);
+    pos += wr_uleb(out + pos, B.c_start_op[c]);
+    pos += wr_sleb(out + pos, B.c_time[c]);
+    u32 ml = B.c_msg_len[c] == AMH_NULL32 ? 0 : B.c_msg_len[c];
+    pos += wr_uleb(out + pos, ml);
+    for (u32 b = 0; b < ml; b++) out[pos++] = chunk[B.c_msg_off[c] + b];
+    pos += wr_uleb(out + pos, B.c_n_other[c]);
+    const u32* amap = B.chg_actor_map + B.c_map_base[c];
+    for (u32 k = 0; k < na; k++) {  // other actors in bytewise order
+      u32 oa = B.actor_by_rank[ab + k];
+      if (amap[oa] == AMH_EMPTY32 || amap[oa] == 0) continue;
+      pos += wr_uleb(out + pos, B.actor_len[ab + oa]);
+      for (u32 b = 0; b < B.actor_len[ab + oa]; b++) out[pos++] = chunk[B.actor_off[ab + oa] + b];
+    }
+    const u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
+    u32 ncols = 0, data = 0;
+    for (u32 k = 0; k < AMH_NCOLS; k++) if (cl[k]) ncols++;
+    pos += wr_uleb(out + pos, ncols);
+    for (u32 k = 0; k < AMH_NCOLS; k++)
+      if (cl[k]) { pos += wr_uleb(out + pos, chg_spec(k)); pos += wr_uleb(out + pos, cl[k]); data += cl[k]; }
+    // column data was written by the store pass at c_cols_off
+    pos += data;
+    for (u32 b = 0; b < B.c_extra_len[c]; b++) out[pos++] = chunk[B.c_extra_off[c] + b];
+    // header + hash
+    out[0] = 0x85; out[1] = 0x6f; out[2] = 0x4a; out[3] = 0x83;
+    out[8] = 1;
+    wr_uleb(out + 9, body_len);
+    Sha256Dev s;
+    sha_init(s);
+    sha_update(s, out + 8, hdr - 8);
+    sha_update(s, out + hdr, body_len);
+    u8* h = B.c_hash + (u64)c * 32;
+    sha_finish(s, h);
+    out[4] = h[0]; out[5] = h[1]; out[6] = h[2]; out[7] = h[3];
+  }
+  // heads: hashes nobody depends on, compared as a set with the stored heads
+  // (change_collector.rs:121-133; reconstruct_document.rs:211-221)
+  u32 derived = 0;
+  bool ok = true;
+  for (u32 i = 0; i < nchg && ok; i++) {
+    bool is_dep = false;
+    for (u32 j = i + 1; j < nchg && !is_dep; j++) {
+      u32 c2 = cb + j;
+      for (u32 k = 0; k < B.c_ndeps[c2]; k++) if (B.dep_idx[B.c_dep_base[c2] + k] == i) { is_dep = true; break; }
+    }
+    if (is_dep) continue;
+    // distinct hashes only (BTreeSet): skip if an earlier head has the same hash
+    const u8* h = B.c_hash + (u64)(cb + i) * 32;
+    derived++;
+    bool found = false;
+    for (u32 k = 0; k < D.n_heads && !found; k++) found = amh_memcmp(chunk + D.heads_off + 32 * k, 32, h, 32) == 0;
+    if (!found) ok = false;
+  }
+  // stored heads must all be derived heads as well
+  u32 distinct_stored = 0;
+  for (u32 k = 0; k < D.n_heads && ok; k++) {
+    const u8* h = chunk + D.heads_off + 32 * k;
+    bool dupe = false;
+    for (u32 j = 0; j < k && !dupe; j++) dupe = amh_memcmp(chunk + D.heads_off + 32 * j, 32, h, 32) == 0;
+    if (!dupe) distinct_stored++;
+  }
+  if (ok && distinct_stored != derived) ok = false;
+  B.heads_ok[d] = ok;
+  if (!ok && B.check_heads) amh_fail(B, d, AMH_E_MISMATCHING_HEADS);
+}
+
+// ------------------------------------------------------------------------------------------
+// K18  visibility and per-key winner — types.rs:712-720, 792-798; iter/top_ops.rs:58-65.
+//      Thread per row.
+// ------------------------------------------------------------------------------------------
+AMH_DEV bool row_visible(const BatchDev& B, u32 r) {
+  u8 a = B.r_action[r];
+  if (a == 5 || a == 7) return false;
+  if (a == 1 && (B.r_vmeta[r] & 15) == 8) return B.r_succ_cnt[r] <= B.r_inc_cnt[r];
+  return B.r_succ_cnt[r] == 0;
+}
+AMH_DEV bool same_group(const BatchDev& B, u32 a, u32 b) {  // same object and same elemid_or_key
+  if (B.r_doc[a] != B.r_doc[b]) return false;
+  if (B.r_obj_ctr[a] != B.r_obj_ctr[b] || B.r_obj_actor[a] != B.r_obj_actor[b]) return false;
+  bool ap = B.r_key_len[a] != AMH_NULL32 && !B.r_insert[a], bp = B.r_key_len[b] != AMH_NULL32 && !B.r_insert[b];
+  if (ap != bp) return false;
+  if (ap) {
+    const u8* chunk = B.arena + B.desc[B.r_doc[a]].chunk_off;
+    return amh_memcmp(chunk + B.r_key_off[a], B.r_key_len[a], chunk + B.r_key_off[b], B.r_key_len[b]) == 0;
+  }
+  u32 aa = B.r_insert[a] ? B.r_id_actor[a] : B.r_key_actor[a], ac = B.r_insert[a] ? B.r_id_ctr[a] : B.r_key_ctr[a];
+  u32 ba = B.r_insert[b] ? B.r_id_actor[b] : B.r_key_actor[b], bc = B.r_insert[b] ? B.r_id_ctr[b] : B.r_key_ctr[b];
+  return aa == ba && ac == bc;
+}
+AMH_DEV void k_visible(const BatchDev& B, u32 r) {
+  u32 d = B.r_doc[r];
+  B.r_visible[r] = 0;
+  B.r_winner[r] = 0;
+  if (B.status[d]) return;
+  bool vis = row_visible(B, r);
+  B.r_visible[r] = vis;
+  if (!vis) return;
+  u32 end = B.row_base[d] + B.cnt[d].n_rows;
+  bool win = true;
+  for (u32 j = r + 1; j < end && same_group(B, r, j); j++)
+    if (row_visible(B, j)) { win = false; break; }
+  B.r_winner[r] = win;
+}
+
+// ------------------------------------------------------------------------------------------
+// small glue kernels
+// ------------------------------------------------------------------------------------------
+AMH_DEV u32 amh_pow2_at_least(u32 v) { u32 p = 1; while (p < v) p <<= 1; return p; }
+// per-document sizes, written into the *_base arrays and scanned in place afterwards
+AMH_DEV void k_extract(const BatchDev& B, u32 d) {
+  bool ok = B.status[d] == 0;
+  const DocCounts& C = B.cnt[d];
+  u32 rows = ok ? C.n_rows : 0, succ = ok ? C.n_succ : 0, chg = ok ? C.n_chg : 0, deps = ok ? C.n_deps : 0;
+  u32 na = ok ? B.desc[d].n_actors : 0;
+  B.row_base[d] = rows;
+  B.succ_base[d] = succ;
+  B.chg_base[d] = chg;
+  B.dep_base[d] = deps;
+  B.actor_base[d] = na;
+  B.ht_base[d] = rows ? amh_pow2_at_least(2 * rows) : 0;
+  B.dt_base[d] = succ ? amh_pow2_at_least(2 * succ) : 0;
+  u64 m = (u64)chg * na;
+  B.map_base[d] = m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)m;
+  B.doc_max_op[d] = 0;
+  B.heads_ok[d] = 0;
+}
+AMH_DEV void k_chg_init(const BatchDev& B, u32 c) {
+  u32 d = find_doc(B.chg_base, B.n_docs, c);
+  B.c_doc[c] = d;
+  B.c_nops[c] = 0;
+  B.c_next_same_actor[c] = AMH_EMPTY32;
+  B.c_map_base[c] = B.map_base[d] + (c - B.chg_base[d]) * B.desc[d].n_actors;
+  B.c_ndeps[c] = 0;
+  B.c_extra_len[c] = 0;
+  B.c_msg_len[c] = AMH_NULL32;
+}

@@ -1,0 +1,21 @@
+// Launch interface between the host orchestration and the kernels.  amh_kernels.hip implements it
+// with HIP launches on a stream; tests/emu implements it with host loops (CPU-only test tier).
+#pragma once
+#include "amh_types.h"
+
+enum AmhKernel {
+  AK_PARSE = 0, AK_SHA_DOC, AK_COUNT, AK_EXTRACT, AK_ACTORS, AK_CHG_INIT, AK_DECODE_CHG, AK_DECODE_OPS, AK_ROWS,
+  AK_OBJ_ORDER, AK_SUCC, AK_BUCKET, AK_CHG_FINISH, AK_PLACE, AK_PRED_FILL, AK_PRED_SORT, AK_ACTOR_MARK,
+  AK_ACTOR_RANK, AK_ENCODE_SIZE, AK_CHG_LAYOUT, AK_ENCODE_STORE, AK_ASSEMBLE_HASH, AK_VISIBLE, AK_SCAN, AK_NUM
+};
+static const char* const AMH_KERNEL_NAMES[AK_NUM] = {
+  "parse", "sha_doc", "count", "extract", "actors", "chg_init", "decode_chg", "decode_ops", "rows",
+  "obj_order", "succ", "bucket", "chg_finish", "place", "pred_fill", "pred_sort", "actor_mark",
+  "actor_rank", "encode_size", "chg_layout", "encode_store", "assemble_hash", "visible", "scan"};
+
+// run kernel `k` over n threads
+void amh_launch(int k, const BatchDev& B, u32 n, void* stream);
+// in-place exclusive scan of data[0..n), total written to data[n] (saturating at 0xFFFFFFFF).
+// tmp must hold amh_scan_tmp_words(n) u32 words.
+void amh_scan_inplace(u32* data, u32 n, u32* tmp, void* stream);
+u32 amh_scan_tmp_words(u32 n);

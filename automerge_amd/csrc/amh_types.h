@@ -1,0 +1,146 @@
+// Plain-data layouts shared by the host orchestration and the HIP kernels of the batched
+// load path.  Everything is structure-of-arrays over the whole batch ("all docs, all rows"),
+// segmented by per-document base offsets — see DESIGN.md "Data layout in HBM".
+#pragma once
+#include <stdint.h>
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
+
+#define AMH_NULL32 0xFFFFFFFFu
+#define AMH_MAX_ROWS_PER_DOC (1u << 28)
+
+// per-document status = the reference's per-document Result (error.rs:7-62, storage/load.rs:15-30,
+// reconstruct_document.rs:14-32, change_collector.rs:19-33).  0 = Ok.
+enum AmhStatus : i32 {
+  AMH_OK = 0,
+  AMH_E_PARSE = 1,                 // load::Error::Parse (chunk / column metadata level)
+  AMH_E_BAD_CHECKSUM = 2,          // load::Error::BadChecksum
+  AMH_E_INVALID_CHANGE_COLUMNS = 3,
+  AMH_E_READ_OP = 20,              // InflateDocument(ReadOp)
+  AMH_E_OPS_OUT_OF_ORDER = 21,     // InflateDocument(OpsOutOfOrder)
+  AMH_E_MISSING_ACTOR = 22,        // InflateDocument(MissingActor)
+  AMH_E_MISMATCHING_HEADS = 23,    // InflateDocument(MismatchingHeads)
+  AMH_E_MISSING_OPS = 24,          // InflateDocument(MissingOps)
+  AMH_E_SUCC_OUT_OF_ORDER = 25,    // InflateDocument(SuccOutOfOrder)
+  AMH_E_INVALID_OP = 26,           // invalid action / non numeric increment
+  AMH_E_CHANGES_OUT_OF_ORDER = 30, // InvalidChanges(ChangesOutOfOrder)
+  AMH_E_MISSING_CHANGE = 31,       // InvalidChanges(MissingChange)
+  AMH_E_READ_CHANGE = 32,          // InvalidChanges(ReadChange)
+  AMH_E_INCORRECT_MAX_OP = 33,     // InvalidChanges(IncorrectMaxOp)
+  AMH_E_COLLECT_MISSING_ACTOR = 34,
+  AMH_E_COLLECT_MISSING_OPS = 35,
+  AMH_E_MISSING_DEPS = 5,          // AutomergeError::MissingDeps
+  AMH_E_DUPLICATE_SEQ = 6,         // AutomergeError::DuplicateSeqNumber
+  // not reference errors: limits of this engine, reported instead of guessing
+  AMH_E_TOO_LARGE = 90,            // document exceeds AMH_MAX_ROWS_PER_DOC / 4 GiB chunk
+  AMH_E_UNSUPPORTED = 91,          // well-formed for the reference but outside what this round handles
+};
+
+// op-column slots of a document chunk (doc_op_columns.rs:24-32) in decode-stream order
+enum OpCol {
+  OC_OBJ_ACTOR = 0, OC_OBJ_CTR, OC_KEY_ACTOR, OC_KEY_CTR, OC_KEY_STR, OC_ID_ACTOR, OC_ID_CTR, OC_INSERT, OC_ACTION,
+  OC_VAL_META, OC_VAL_RAW, OC_SUCC_NUM, OC_SUCC_ACTOR, OC_SUCC_CTR, OC_EXPAND, OC_MARK_NAME, OC_COUNT
+};
+// change-metadata column slots (doc_change_columns.rs:18-24)
+enum ChgCol {
+  CC_ACTOR = 0, CC_SEQ, CC_MAX_OP, CC_TIME, CC_MESSAGE, CC_DEPS_NUM, CC_DEPS_IDX, CC_EXTRA_META, CC_EXTRA_RAW, CC_COUNT
+};
+
+struct ColRef {
+  u32 off;  // byte offset relative to the start of the document's chunk
+  u32 len;
+};
+
+// Result of the prefix parse of one document chunk (document.rs:113-154)
+struct DocDesc {
+  u64 chunk_off;    // offset of the chunk in the batch arena
+  u32 chunk_len;    // header + data
+  u32 data_off;     // relative to chunk start
+  u32 data_len;
+  u32 n_actors;
+  u32 actors_off;   // relative offset of the first length-prefixed actor
+  u32 n_heads;
+  u32 heads_off;    // relative offset of heads[32 x n]
+  u32 suffix_off;   // head indices (may be absent)
+  u32 suffix_len;
+  ColRef ccol[CC_COUNT];
+  ColRef ocol[OC_COUNT];
+};
+
+// per-document segment bases (exclusive scans of the counts)
+struct DocCounts {
+  u32 n_rows, n_succ, n_chg, n_deps;
+};
+
+// everything the kernels touch, as one POD so that launches take a single argument block
+struct BatchDev {
+  u32 n_docs;
+  u32 tot_rows, tot_succ, tot_chg, tot_deps, tot_actors, tot_dt, tot_ops;
+  u32 check_heads;         // VerificationMode::Check (reconstruct_document.rs:86-90)
+  const u8* arena;
+  const u64* doc_off;      // [2 * n_docs] (start, end) byte range of each input in the arena
+  i32* status;             // [n_docs]
+  DocDesc* desc;           // [n_docs]
+  DocCounts* cnt;          // [n_docs]
+  // [n_docs + 1] exclusive scans of the per-document counts
+  u32 *row_base, *succ_base, *chg_base, *dep_base, *actor_base, *ht_base, *dt_base, *map_base;
+  u8* doc_hash;            // [n_docs * 32] SHA-256 of the document chunk
+  u32* doc_max_op;         // [n_docs] max counter over op ids and succ ids (reconstruct_document.rs:136-143)
+  u32* heads_ok;           // [n_docs]
+  // actors [tot_actors]
+  u32 *actor_off, *actor_len;    // bytes, relative to chunk start
+  u32 *actor_rank, *actor_by_rank;  // bytewise rank inside the document (lamport tie-break, types.rs:517-521)
+  u32 *a_first_chg, *a_last_chg; // per-actor change chain in file order
+  // change metadata rows (file order) [tot_chg]
+  u32* c_actor;
+  u64 *c_seq, *c_max_op;
+  i64* c_time;
+  u32 *c_msg_off, *c_msg_len;    // len = AMH_NULL32 for "no message"
+  u32 *c_ndeps, *c_dep_base;     // dep_base: index into dep_idx (global)
+  u32 *c_extra_off, *c_extra_len;
+  u32* c_doc;
+  u32* dep_idx;                  // [tot_deps] document-local change index
+  // derived per change
+  u32* c_nops;
+  u64* c_start_op;
+  u32* c_op_base;                // [tot_chg + 1] slot base in ops_sorted
+  u32* c_next_same_actor;
+  u8* c_hash;                    // [tot_chg * 32]
+  u32* c_out_off;                // [tot_chg + 1] offset of the re-derived change chunk in out_arena
+  u32 *c_out_len, *c_body_len, *c_cols_off;
+  u32* c_col_len;                // [tot_chg * 14] encoded column lengths
+  u32* c_map_base;               // base into chg_actor_map
+  u32* c_n_other;
+  u32* chg_actor_map;            // [sum over changes of n_actors(doc)]: index in the change's actor table
+  // op rows (document order) [tot_rows]
+  u32 *r_id_actor, *r_id_ctr, *r_obj_actor, *r_obj_ctr, *r_key_actor, *r_key_ctr;
+  u32 *r_key_off, *r_key_len;    // key string (relative to chunk), len = AMH_NULL32 when not a map key
+  u8 *r_insert, *r_action, *r_expand;
+  u64* r_vmeta;
+  u32* r_vraw_off;               // offset inside the value-raw column
+  u32 *r_mark_off, *r_mark_len;  // AMH_NULL32 len = none
+  u32 *r_succ_cnt, *r_succ_base; // base is global
+  u32* r_doc;
+  u32* r_inc_cnt;
+  i64* r_inc_sum;
+  u8 *r_visible, *r_winner;
+  // succ entries [tot_succ]
+  u32 *s_actor, *s_ctr;
+  u32* s_row;                    // owning row (global)
+  u32* s_target;                 // op index t of the op this entry names
+  // id -> row hash tables (one power-of-two region per document) [tot_ht]
+  u64* ht_key;                   // (ctr << 32 | actor) + 1, 0 = empty
+  u32* ht_val;
+  // synthesized deletes live in the slots of a second table [tot_dt]
+  u64* dt_key;
+  u32 *d_doc, *d_first_pred_row;
+  // unified op space t in [0, tot_rows + tot_dt)
+  u32 *t_pred_cnt, *t_pred_base, *t_pred_fill, *t_chg;
+  u64* pred_ids;                 // [tot_succ] (ctr << 32 | actor)
+  u32* ops_sorted;               // [tot_ops] ops grouped by change in id order
+  u8* out_arena;                 // re-derived change chunks
+};

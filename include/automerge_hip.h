@@ -1,0 +1,178 @@
+/* automerge_hip.h — C ABI of libautomerge_hip.so: the MI355X-native batched load / merge / save
+ * engine for Automerge documents.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to
+ * /root/reference/rust, reference = aasthaagarwal2003/automerge, `automerge` 0.5.2).  A batch is N
+ * independent documents; entry point X over a batch == the reference call per document, and a
+ * failing document never aborts the batch (its per-document status carries the reference's error
+ * kind).  The single-document calls of the reference are the n = 1 case.
+ *
+ * Ownership: inputs are caller-owned and only read during the call.  Outputs are library-owned until
+ * the matching *_free (mirrors AMresultFree, automerge-c/src/result.rs:532).  A context is used from
+ * one host thread at a time; one context drives one GPU (one process per GPU under torch.distributed).
+ * There is no CPU fallback: without a HIP device every call fails with AMH_ERR_NO_DEVICE.
+ */
+#ifndef AUTOMERGE_HIP_H
+#define AUTOMERGE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct amh_ctx amh_ctx;
+typedef struct amh_batch amh_batch;
+typedef struct amh_staged amh_staged;
+
+/* call-level status (per-document results are in amh_doc_status) */
+enum {
+  AMH_SUCCESS = 0,
+  AMH_ERR_INVALID_ARG = -1,
+  AMH_ERR_NO_DEVICE = -2,      /* HIP runtime / device missing */
+  AMH_ERR_DEVICE = -3,         /* a HIP call failed */
+  AMH_ERR_OOM = -4,
+  AMH_ERR_BATCH_TOO_LARGE = -5,/* more than 2^32-1 rows / bytes of derived data in one batch */
+  AMH_ERR_UNIMPLEMENTED = -6,  /* declared by the boundary, not built in this round */
+  AMH_ERR_DOC_FAILED = -7      /* the addressed document is in an error state */
+};
+
+/* per-document error kinds: AutomergeError (automerge/src/error.rs:7-62) with the nested
+ * storage::load::Error (automerge/src/storage/load.rs:15-30), reconstruct_document::Error
+ * (storage/load/reconstruct_document.rs:14-32) and change_collector::Error
+ * (storage/load/change_collector.rs:19-33) discriminants flattened. */
+enum {
+  AMH_DOC_OK = 0,
+  AMH_DOC_PARSE = 1,
+  AMH_DOC_BAD_CHECKSUM = 2,
+  AMH_DOC_INVALID_CHANGE_COLUMNS = 3,
+  AMH_DOC_MISSING_DEPS = 5,
+  AMH_DOC_DUPLICATE_SEQ = 6,
+  AMH_DOC_READ_OP = 20,
+  AMH_DOC_OPS_OUT_OF_ORDER = 21,
+  AMH_DOC_MISSING_ACTOR = 22,
+  AMH_DOC_MISMATCHING_HEADS = 23,
+  AMH_DOC_MISSING_OPS = 24,
+  AMH_DOC_SUCC_OUT_OF_ORDER = 25,
+  AMH_DOC_INVALID_OP = 26,
+  AMH_DOC_CHANGES_OUT_OF_ORDER = 30,
+  AMH_DOC_MISSING_CHANGE = 31,
+  AMH_DOC_READ_CHANGE = 32,
+  AMH_DOC_INCORRECT_MAX_OP = 33,
+  AMH_DOC_COLLECT_MISSING_ACTOR = 34,
+  AMH_DOC_COLLECT_MISSING_OPS = 35,
+  AMH_DOC_TOO_LARGE = 90,      /* engine limit, not a reference error */
+  AMH_DOC_UNSUPPORTED = 91     /* valid for the reference, not handled by this round's device path */
+};
+
+/* LoadOptions (automerge/src/automerge.rs:58-135).  verify_heads = VerificationMode::Check. */
+typedef struct amh_load_opts {
+  int verify_heads;        /* default 1 */
+  int on_partial_load;     /* 0 = Error (default), 1 = Ignore */
+} amh_load_opts;
+
+/* SaveOptions (automerge/src/automerge.rs:1816-1830) */
+typedef struct amh_save_opts {
+  int deflate;             /* default 1 */
+  int retain_orphans;      /* default 1 */
+} amh_save_opts;
+
+typedef struct amh_bytes_out {
+  uint8_t* data;
+  size_t len;
+} amh_bytes_out;
+
+/* Change accessors of automerge/src/change.rs:47-117 as one view; pointers are into the batch. */
+typedef struct amh_change_view {
+  const uint8_t* hash;       /* 32 bytes — Change::hash */
+  const uint8_t* raw_bytes;  /* uncompressed change chunk — Change::raw_bytes */
+  size_t raw_len;
+  const uint8_t* actor;      /* Change::actor_id */
+  size_t actor_len;
+  uint64_t seq;              /* Change::seq */
+  uint64_t start_op;         /* Change::start_op */
+  uint64_t num_ops;          /* Change::len */
+  int64_t timestamp;         /* Change::timestamp */
+  uint32_t num_deps;         /* Change::deps().len(); the hashes are inside raw_bytes */
+} amh_change_view;
+
+typedef struct amh_batch_stats {
+  uint64_t n_docs, n_ok;
+  uint64_t ops_loaded;       /* sum of Change::len over documents that loaded (SURVEY.md 8d "ops") */
+  uint64_t op_rows, succ_entries, changes, delete_ops;
+  uint64_t encoded_bytes;    /* input bytes */
+  uint64_t change_bytes;     /* re-derived change chunk bytes */
+} amh_batch_stats;
+
+/* ---- context ----------------------------------------------------------------------------- */
+/* n_gpus must be 1: one context (and one process) per GPU; multi-GPU = one rank per GPU sharding
+ * the batch by document. */
+amh_ctx* amh_ctx_create(const int* gpu_ids, int n_gpus);
+void amh_ctx_destroy(amh_ctx*);
+const char* amh_last_error(const amh_ctx*);   /* message of the last failed call (may be NULL ctx) */
+
+/* ---- load ------------------------------------------------------------------------------------
+ * == Automerge::load_with_options per document (automerge/src/automerge.rs:601-705; C precedent
+ *    AMload, automerge-c/src/doc.rs:512).
+ * amh_load_batch = amh_stage_batch (host ingest: inflate of DEFLATEd columns, document.rs /
+ * compression.rs:51-74, + one H2D copy) followed by amh_load_staged (the device pipeline). */
+amh_staged* amh_stage_batch(amh_ctx*, const uint8_t* const* docs, const size_t* lens, size_t n);
+void amh_staged_free(amh_staged*);
+amh_batch* amh_load_staged(amh_ctx*, const amh_staged*, const amh_load_opts*);
+amh_batch* amh_load_batch(amh_ctx*, const uint8_t* const* docs, const size_t* lens, size_t n, const amh_load_opts*);
+void amh_batch_free(amh_batch*);
+void amh_bytes_free(amh_bytes_out*);
+
+/* per-document Result: Ok / AutomergeError kind (automerge/src/error.rs:7-62) */
+int amh_doc_status(const amh_batch*, uint32_t doc, int* err_kind, const char** msg);
+int amh_batch_get_stats(const amh_batch*, amh_batch_stats* out);
+
+/* == Automerge::get_heads (automerge.rs:1300-1304; AMgetHeads, automerge-c/src/doc.rs:402): sorted */
+int amh_heads(const amh_batch*, uint32_t doc, const uint8_t** hashes32, size_t* n);
+/* == Automerge::get_changes(&[]) (automerge.rs:1306; AMgetChanges): history order.
+ * On input *n = capacity of out (0 to query the count), on output the number of changes. */
+int amh_changes(const amh_batch*, uint32_t doc, amh_change_view* out, size_t* n);
+/* canonical materialization for parity == hydrate / get_all (automerge/src/hydrate.rs:128-167,
+ * automerge.rs:1528-1565, iter/top_ops.rs:43-102); format in DESIGN.md */
+int amh_hydrate_json(const amh_batch*, uint32_t doc, amh_bytes_out* out);
+/* max op counter of the document (Automerge::max_op, automerge.rs:181) */
+int amh_doc_max_op(const amh_batch*, uint32_t doc, uint64_t* max_op);
+
+/* ---- merge / apply / save (boundary declared; device path lands in a later round) ------------
+ * == dst[i].merge(&mut src[j]) (automerge.rs:917-940; AMmerge, automerge-c/src/doc.rs:564) */
+int amh_merge_batch(amh_ctx*, amh_batch* dst, const amh_batch* src, const uint32_t* dst_idx, const uint32_t* src_idx, size_t n_pairs);
+/* == Automerge::apply_changes (automerge.rs:785; AMapplyChanges, automerge-c/src/doc.rs:84) */
+int amh_apply_changes(amh_ctx*, amh_batch*, uint32_t doc, const uint8_t* const* changes, const size_t* lens, size_t n);
+/* == Automerge::save_with_options (automerge.rs:943-965; AMsave, automerge-c/src/doc.rs:751);
+ * out = array of n_docs amh_bytes_out */
+int amh_save_batch(amh_ctx*, const amh_batch*, const amh_save_opts*, amh_bytes_out* out);
+
+/* ---- sync summaries ---------------------------------------------------------------------------
+ * per document: sorted heads (get_heads) + Bloom filter over all change hashes
+ * (sync.rs:243-250 make_bloom_filter with last_sync = [], sync/bloom.rs:38-47,69-90,125-146).
+ * Record layout per document: u32 doc, u32 n_heads, heads[32 x n], u32 bloom_len, bloom bytes.
+ * The all-gather across ranks is done by the caller's torch.distributed group. */
+int amh_sync_summaries(amh_ctx*, const amh_batch*, amh_bytes_out* out);
+
+/* ---- measurement ------------------------------------------------------------------------------
+ * HIP-event timing of every kernel launch of the context's stream (for bench.py's roofline leg). */
+int amh_ctx_set_profiling(amh_ctx*, int enable);
+int amh_ctx_num_kernels(void);
+const char* amh_ctx_kernel_name(int k);
+/* accumulated milliseconds and launch count since the last reset */
+int amh_ctx_kernel_time(amh_ctx*, int k, double* ms, uint64_t* launches);
+int amh_ctx_reset_profile(amh_ctx*);
+
+/* ---- synthetic workloads --------------------------------------------------------
+ * Deterministic generator of reference-format documents (save_nocompress form): `n_docs` map
+ * documents of n_actors x changes_per_actor x ops_per_change ops on the root map and one nested map,
+ * keys drawn Zipf from `n_keys` strings (BASELINE.json configs[1]).  Output: concatenated documents
+ * + offsets[n_docs + 1]; free both with amh_bytes_free / amh_u64_free. */
+int amh_gen_map_docs(uint64_t seed, uint32_t n_docs, uint32_t n_actors, uint32_t changes_per_actor,
+                     uint32_t ops_per_change, uint32_t n_keys, int threads, amh_bytes_out* docs, uint64_t** offsets);
+void amh_u64_free(uint64_t*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,32 @@
+// CPU-only test tier: runs the per-thread kernel bodies of automerge_amd/csrc/amh_kernels.inl in
+// host loops so that the kernel logic can be checked against the oracle where no GPU exists.
+// TEST INFRASTRUCTURE: built only by tests/emu/Makefile into tests/emu/libamh_emu_for_tests.so,
+// never part of libautomerge_hip.so and never loaded by the automerge_amd package.
+#define AMH_EMU
+#include "../../automerge_amd/csrc/amh_kernels.inl"
+#include "../../automerge_amd/csrc/amh_launch.h"
+
+void amh_launch(int k, const BatchDev& B, u32 n, void*) {
+#define L(id, name) case id: for (u32 i = 0; i < n; i++) name(B, i); break;
+  switch (k) {
+    L(AK_PARSE, k_parse) L(AK_SHA_DOC, k_sha_doc) L(AK_COUNT, k_count) L(AK_EXTRACT, k_extract)
+    L(AK_ACTORS, k_actors) L(AK_CHG_INIT, k_chg_init) L(AK_DECODE_CHG, k_decode_chg)
+    L(AK_DECODE_OPS, k_decode_ops) L(AK_ROWS, k_rows) L(AK_OBJ_ORDER, k_obj_order) L(AK_SUCC, k_succ)
+    L(AK_BUCKET, k_bucket) L(AK_CHG_FINISH, k_chg_finish) L(AK_PLACE, k_place) L(AK_PRED_FILL, k_pred_fill)
+    L(AK_PRED_SORT, k_pred_sort) L(AK_ACTOR_MARK, k_actor_mark) L(AK_ACTOR_RANK, k_actor_rank)
+    L(AK_ENCODE_SIZE, k_encode_size) L(AK_CHG_LAYOUT, k_chg_layout) L(AK_ENCODE_STORE, k_encode_store)
+    L(AK_ASSEMBLE_HASH, k_assemble_hash) L(AK_VISIBLE, k_visible)
+    default: break;
+  }
+#undef L
+}
+u32 amh_scan_tmp_words(u32) { return 2; }
+void amh_scan_inplace(u32* data, u32 n, u32*, void*) {
+  u64 run = 0;
+  for (u32 i = 0; i < n; i++) {
+    u32 v = data[i];
+    data[i] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)run;
+    run += v;
+  }
+  data[n] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)run;
+}
