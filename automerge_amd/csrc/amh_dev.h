@@ -12,6 +12,7 @@
 #if defined(AMH_EMU) || defined(AMH_HOST_HELPERS)
 #include <string.h>
 #define AMH_DEV static inline
+#define AMH_DEV_NOINLINE static
 static inline u32 amh_atomic_add(u32* p, u32 v) { u32 o = *p; *p = o + v; return o; }
 static inline void amh_atomic_add_i64(i64* p, i64 v) { *p += v; }
 static inline u32 amh_atomic_min(u32* p, u32 v) { u32 o = *p; if (v < o) *p = v; return o; }
@@ -22,6 +23,9 @@ static inline i32 amh_atomic_cas_i32(i32* p, i32 cmp, i32 val) { i32 o = *p; if 
 #else
 #include <hip/hip_runtime.h>
 #define AMH_DEV __device__ __forceinline__
+// out-of-line helpers: keep the callers' control flow small (a large fully inlined decoder made the
+// gfx950 backend drop a value on one path of the string decoder)
+#define AMH_DEV_NOINLINE __device__ __noinline__ static
 AMH_DEV u32 amh_atomic_add(u32* p, u32 v) { return atomicAdd(p, v); }
 AMH_DEV void amh_atomic_add_i64(i64* p, i64 v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 AMH_DEV u32 amh_atomic_min(u32* p, u32 v) { return atomicMin(p, v); }
@@ -34,7 +38,10 @@ AMH_DEV i32 amh_atomic_cas_i32(i32* p, i32 cmp, i32 val) { return atomicCAS(p, c
 #endif
 
 // first error wins; any non-zero status makes every later stage skip the document
-AMH_DEV void amh_fail(const BatchDev& B, u32 doc, i32 code) { amh_atomic_cas_i32(&B.status[doc], 0, code); }
+AMH_DEV void amh_fail_at(const BatchDev& B, u32 doc, i32 code, u32 line) {
+  if (amh_atomic_cas_i32(&B.status[doc], 0, code) == 0) B.fail_line[doc] = line;  // where in amh_kernels.inl: diagnostics
+}
+#define amh_fail(B, doc, code) amh_fail_at(B, doc, code, __LINE__)
 
 // ---------------------------------------------------------------------------------------------
 // LEB128.  lenient = what the reference's column decoders accept (the `leb128` crate:
@@ -149,7 +156,7 @@ AMH_DEV u32 wr_sleb(u8* out, i64 v) {
 }
 
 // Rust str::from_utf8 acceptance
-AMH_DEV bool amh_valid_utf8(const u8* s, u64 n) {
+AMH_DEV_NOINLINE bool amh_valid_utf8(const u8* s, u64 n) {
   u64 i = 0;
   while (i < n) {
     u8 b = s[i];
@@ -223,7 +230,9 @@ AMH_DEV int rle_next(RleDec& d, u64& v, u32& aux, bool& is_null) {
     if (!rd_sleb_lenient(d.p, d.pos, d.end, n)) return -1;
     if (n > 0) {
       d.count = n;
-      if (!rle_read_value<KIND>(d, d.last, d.last_aux)) return -1;
+      u64 lv = 0; u32 la = 0;
+      if (!rle_read_value<KIND>(d, lv, la)) return -1;
+      d.last = lv; d.last_aux = la;
       d.last_null = false;
       d.literal = false;
     } else if (n < 0) {
@@ -240,7 +249,9 @@ AMH_DEV int rle_next(RleDec& d, u64& v, u32& aux, bool& is_null) {
   }
   d.count--;
   if (d.literal) {
-    if (!rle_read_value<KIND>(d, v, aux)) return -1;
+    u64 lv = 0; u32 la = 0;
+    if (!rle_read_value<KIND>(d, lv, la)) return -1;
+    v = lv; aux = la;
     is_null = false;
   } else {
     v = d.last;

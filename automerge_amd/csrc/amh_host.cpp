@@ -2,6 +2,7 @@
 // (include/automerge_hip.h).  The host stages bytes, sizes buffers and launches kernels; every
 // per-op / per-change computation happens in the kernels of amh_kernels.inl.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -118,6 +119,8 @@ struct amh_batch {
   BatchDev B{};
   std::vector<DevAlloc> allocs;
   std::vector<i32> status;
+  std::vector<u32> fail_line;
+  mutable std::string msg_buf;
   u32 tot_ht = 0, tot_map = 0, tot_out = 0;
   mutable HostView hv;
 };
@@ -125,8 +128,10 @@ struct amh_batch {
 // ---------------------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------------------
+static int g_dbg_stop_after = -1;  // AMH_DEBUG_STOP_AFTER=<kernel id>: skip every kernel with a larger id (diagnostics)
 static void launch(amh_ctx* ctx, int k, const BatchDev& B, u32 n) {
   if (n == 0) return;
+  if (g_dbg_stop_after >= 0 && k > g_dbg_stop_after) return;
   if (ctx->profiling) {
     amh_ctx::Pending p;
     p.k = k;
@@ -256,6 +261,7 @@ extern "C" void amh_batch_free(amh_batch* b) {
 extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts) {
   if (!ctx || !st_c) { set_error(ctx, "invalid argument"); return nullptr; }
   amh_staged* st = const_cast<amh_staged*>(st_c);
+  if (const char* e = getenv("AMH_DEBUG_STOP_AFTER")) g_dbg_stop_after = atoi(e);
   auto* b = new amh_batch();
   b->ctx = ctx;
   b->staged = st;
@@ -274,6 +280,7 @@ extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, cons
     return nullptr;
   };
   B.status = balloc<i32>(b, n + 1, &ok);
+  B.fail_line = balloc<u32>(b, n + 1, &ok);
   B.desc = balloc<DocDesc>(b, n + 1, &ok);
   B.cnt = balloc<DocCounts>(b, n + 1, &ok);
   u32** bases[8] = {&B.row_base, &B.succ_base, &B.chg_base, &B.dep_base, &B.actor_base, &B.ht_base, &B.dt_base, &B.map_base};
@@ -283,6 +290,7 @@ extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, cons
   B.heads_ok = balloc<u32>(b, n + 1, &ok);
   if (!ok) return fail("device out of memory");
   rt_memset(B.status, 0, (n + 1) * sizeof(i32), ctx->stream);
+  rt_memset(B.fail_line, 0, (n + 1) * sizeof(u32), ctx->stream);
   launch(ctx, AK_PARSE, B, n);
   launch(ctx, AK_SHA_DOC, B, n);
   launch(ctx, AK_COUNT, B, n);
@@ -382,7 +390,8 @@ extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, cons
   launch(ctx, AK_ASSEMBLE_HASH, B, n);
   launch(ctx, AK_VISIBLE, B, B.tot_rows);
   b->status.resize(n);
-  if (!rt_d2h(b->status.data(), B.status, n * sizeof(i32), ctx->stream) || !rt_sync(ctx->stream))
+  b->fail_line.resize(n);
+  if (!rt_d2h(b->status.data(), B.status, n * sizeof(i32), ctx->stream) || !rt_d2h(b->fail_line.data(), B.fail_line, n * sizeof(u32), ctx->stream) || !rt_sync(ctx->stream))
     return fail(std::string("device pipeline failed: ") + rt_last_error());
   collect_profile(ctx);
   return b;
@@ -462,7 +471,11 @@ static const char* status_msg(int s) {
 extern "C" int amh_doc_status(const amh_batch* b, uint32_t doc, int* err_kind, const char** msg) {
   if (!b || doc >= b->B.n_docs) return AMH_ERR_INVALID_ARG;
   if (err_kind) *err_kind = b->status[doc];
-  if (msg) *msg = status_msg(b->status[doc]);
+  if (msg) {
+    b->msg_buf = status_msg(b->status[doc]);
+    if (b->status[doc]) b->msg_buf += " [check at amh_kernels.inl:" + std::to_string(b->fail_line[doc]) + "]";
+    *msg = b->msg_buf.c_str();
+  }
   return AMH_SUCCESS;
 }
 
@@ -726,6 +739,53 @@ extern "C" void amh_bytes_free(amh_bytes_out* o) {
   o->len = 0;
 }
 extern "C" void amh_u64_free(uint64_t* p) { free(p); }
+
+// ---------------------------------------------------------------------------------------------
+// diagnostics: copy one named device array of a batch to the host (tests compare the arrays of the
+// HIP build with those of the host emulation stage by stage)
+// ---------------------------------------------------------------------------------------------
+extern "C" int amh_debug_array(const amh_batch* b, const char* name, void* out, size_t cap, size_t* len) {
+  if (!b || !name || !len) return AMH_ERR_INVALID_ARG;
+  const BatchDev& B = b->B;
+  size_t n = B.n_docs, T = (size_t)B.tot_rows + B.tot_dt, NC = B.tot_chg, NR = B.tot_rows, NS = B.tot_succ;
+  struct Ent { const char* name; const void* p; size_t bytes; };
+  const Ent tab[] = {
+    {"status", B.status, n * 4}, {"fail_line", B.fail_line, n * 4}, {"desc", B.desc, n * sizeof(DocDesc)}, {"cnt", B.cnt, n * sizeof(DocCounts)},
+    {"row_base", B.row_base, (n + 1) * 4}, {"succ_base", B.succ_base, (n + 1) * 4}, {"chg_base", B.chg_base, (n + 1) * 4},
+    {"dep_base", B.dep_base, (n + 1) * 4}, {"actor_base", B.actor_base, (n + 1) * 4}, {"ht_base", B.ht_base, (n + 1) * 4},
+    {"dt_base", B.dt_base, (n + 1) * 4}, {"map_base", B.map_base, (n + 1) * 4}, {"doc_hash", B.doc_hash, n * 32},
+    {"doc_max_op", B.doc_max_op, n * 4}, {"heads_ok", B.heads_ok, n * 4},
+    {"actor_off", B.actor_off, (size_t)B.tot_actors * 4}, {"actor_len", B.actor_len, (size_t)B.tot_actors * 4},
+    {"actor_rank", B.actor_rank, (size_t)B.tot_actors * 4}, {"actor_by_rank", B.actor_by_rank, (size_t)B.tot_actors * 4},
+    {"a_first_chg", B.a_first_chg, (size_t)B.tot_actors * 4}, {"a_last_chg", B.a_last_chg, (size_t)B.tot_actors * 4},
+    {"c_actor", B.c_actor, NC * 4}, {"c_seq", B.c_seq, NC * 8}, {"c_max_op", B.c_max_op, NC * 8}, {"c_time", B.c_time, NC * 8},
+    {"c_msg_off", B.c_msg_off, NC * 4}, {"c_msg_len", B.c_msg_len, NC * 4}, {"c_ndeps", B.c_ndeps, NC * 4},
+    {"c_dep_base", B.c_dep_base, NC * 4}, {"c_extra_off", B.c_extra_off, NC * 4}, {"c_extra_len", B.c_extra_len, NC * 4},
+    {"c_doc", B.c_doc, NC * 4}, {"dep_idx", B.dep_idx, (size_t)B.tot_deps * 4}, {"c_nops", B.c_nops, NC * 4},
+    {"c_start_op", B.c_start_op, NC * 8}, {"c_op_base", B.c_op_base, (NC + 1) * 4}, {"c_next_same_actor", B.c_next_same_actor, NC * 4},
+    {"c_hash", B.c_hash, NC * 32}, {"c_out_off", B.c_out_off, (NC + 1) * 4}, {"c_out_len", B.c_out_len, NC * 4},
+    {"c_body_len", B.c_body_len, NC * 4}, {"c_cols_off", B.c_cols_off, NC * 4}, {"c_col_len", B.c_col_len, NC * AMH_NCOLS * 4},
+    {"c_map_base", B.c_map_base, NC * 4}, {"c_n_other", B.c_n_other, NC * 4}, {"chg_actor_map", B.chg_actor_map, (size_t)b->tot_map * 4},
+    {"r_id_actor", B.r_id_actor, NR * 4}, {"r_id_ctr", B.r_id_ctr, NR * 4}, {"r_obj_actor", B.r_obj_actor, NR * 4},
+    {"r_obj_ctr", B.r_obj_ctr, NR * 4}, {"r_key_actor", B.r_key_actor, NR * 4}, {"r_key_ctr", B.r_key_ctr, NR * 4},
+    {"r_key_off", B.r_key_off, NR * 4}, {"r_key_len", B.r_key_len, NR * 4}, {"r_insert", B.r_insert, NR}, {"r_action", B.r_action, NR},
+    {"r_expand", B.r_expand, NR}, {"r_vmeta", B.r_vmeta, NR * 8}, {"r_vraw_off", B.r_vraw_off, NR * 4}, {"r_mark_off", B.r_mark_off, NR * 4},
+    {"r_mark_len", B.r_mark_len, NR * 4}, {"r_succ_cnt", B.r_succ_cnt, NR * 4}, {"r_succ_base", B.r_succ_base, NR * 4},
+    {"r_doc", B.r_doc, NR * 4}, {"r_inc_cnt", B.r_inc_cnt, NR * 4}, {"r_inc_sum", B.r_inc_sum, NR * 8}, {"r_visible", B.r_visible, NR},
+    {"r_winner", B.r_winner, NR}, {"s_actor", B.s_actor, NS * 4}, {"s_ctr", B.s_ctr, NS * 4}, {"s_row", B.s_row, NS * 4},
+    {"s_target", B.s_target, NS * 4}, {"t_pred_cnt", B.t_pred_cnt, T * 4}, {"t_pred_base", B.t_pred_base, (T + 1) * 4},
+    {"t_chg", B.t_chg, T * 4}, {"pred_ids", B.pred_ids, NS * 8}, {"ops_sorted", B.ops_sorted, (size_t)B.tot_ops * 4},
+    {"out_arena", B.out_arena, (size_t)b->tot_out},
+  };
+  for (const Ent& e : tab) {
+    if (strcmp(e.name, name) != 0) continue;
+    *len = e.bytes;
+    if (!out || cap < e.bytes) return cap == 0 ? AMH_SUCCESS : AMH_ERR_INVALID_ARG;
+    if (!e.p) { *len = 0; return AMH_SUCCESS; }
+    return rt_d2h(out, e.p, e.bytes, b->ctx->stream) ? AMH_SUCCESS : AMH_ERR_DEVICE;
+  }
+  return AMH_ERR_INVALID_ARG;
+}
 
 // ---------------------------------------------------------------------------------------------
 // boundary entry points declared for the path but not built in this round: they fail loudly

@@ -37,109 +37,159 @@ AMH_DEV u32 ht_find(const BatchDev& B, u32 d, u64 id) {
 //      raw_column.rs:205-272, columns.rs:134-355, doc_op_columns.rs:398-504,
 //      doc_change_columns.rs:272-338.  One thread per document.
 // ------------------------------------------------------------------------------------------
-struct RawColDev { u32 spec; u64 len; };
-#define AMH_MAX_RAW_COLS 64
-
-// walks raw columns through the layout state machine and records the slots this path knows
+// The column layout state machine of columns.rs:186-311, fed one raw column at a time (no per-thread
+// arrays: the metadata block is walked twice instead).  Out-of-line on purpose: it keeps k_parse's
+// control flow small (see AMH_DEV_NOINLINE).
+struct ColMapper {
+  int st;            // 0 ready, 1 in value, 2 in group
+  u32 cur_id;
+  u64 cur_s, cur_e, cur_rs, cur_re;
+  u32 nkids, kid0_type, kid1_type;
+  u64 kid0_s, kid0_e, kid1_s, kid1_e;
+  bool g_in_value, bad;
+  u64 off, data_rel_off, data_len;
+  ColRef* slots;
+};
+AMH_DEV void cm_set(ColMapper& m, int slot, u64 s, u64 e) {
+  m.slots[slot].off = (u32)(m.data_rel_off + s);
+  m.slots[slot].len = (u32)(e - s);
+}
 template <bool IS_OPS>
-AMH_DEV int map_columns(const RawColDev* raw, u32 n, u64 data_rel_off, u64 data_len, ColRef* slots) {
-  // state: 0 ready, 1 in value, 2 in group
-  int st = 0;
-  u32 cur_id = 0, cur_type = 0;
-  u64 cur_s = 0, cur_e = 0, cur_rs = 0, cur_re = 0;
-  u32 nkids = 0, kid_type[2] = {0, 0};
-  u64 kid_s[2] = {0, 0}, kid_e[2] = {0, 0};
-  bool g_in_value = false;
-  u64 off = 0;
-  bool bad = false;
-  auto set = [&](int slot, u64 s, u64 e) {
-    slots[slot].off = (u32)(data_rel_off + s);
-    slots[slot].len = (u32)(e - s);
-  };
-  auto emit_simple = [&](u32 id, u32 type, u64 s, u64 e) {
-    if (IS_OPS) {
-      if (id == 0 && type == 1) set(OC_OBJ_ACTOR, s, e);
-      else if (id == 0 && type == 2) set(OC_OBJ_CTR, s, e);
-      else if (id == 1 && type == 1) set(OC_KEY_ACTOR, s, e);
-      else if (id == 1 && type == 3) set(OC_KEY_CTR, s, e);
-      else if (id == 1 && type == 5) set(OC_KEY_STR, s, e);
-      else if (id == 2 && type == 1) set(OC_ID_ACTOR, s, e);
-      else if (id == 2 && type == 3) set(OC_ID_CTR, s, e);
-      else if (id == 3 && type == 4) set(OC_INSERT, s, e);
-      else if (id == 4 && type == 2) set(OC_ACTION, s, e);
-      else if (id == 9 && type == 4) set(OC_EXPAND, s, e);
-      else if (id == 10 && type == 5) set(OC_MARK_NAME, s, e);
-    } else {
-      if (id == 0 && type == 1) set(CC_ACTOR, s, e);
-      else if (id == 0 && type == 3) set(CC_SEQ, s, e);
-      else if (id == 1 && type == 3) set(CC_MAX_OP, s, e);
-      else if (id == 2 && type == 3) set(CC_TIME, s, e);
-      else if (id == 3 && type == 5) set(CC_MESSAGE, s, e);
-    }
-  };
-  auto emit_value = [&]() {
-    if (cur_id == 5) {
-      set(IS_OPS ? (int)OC_VAL_META : (int)CC_EXTRA_META, cur_s, cur_e);
-      set(IS_OPS ? (int)OC_VAL_RAW : (int)CC_EXTRA_RAW, cur_rs, cur_re);
-    }
-  };
-  auto emit_group = [&]() {
-    if (IS_OPS && cur_id == 8) {
-      set(OC_SUCC_NUM, cur_s, cur_e);
-      if (nkids == 0) { set(OC_SUCC_ACTOR, 0, 0); set(OC_SUCC_CTR, 0, 0); }
-      else if (nkids == 2 && (kid_type[0] == 1 || kid_type[0] == 2) && kid_type[1] == 3) {
-        set(OC_SUCC_ACTOR, kid_s[0], kid_e[0]);
-        set(OC_SUCC_CTR, kid_s[1], kid_e[1]);
-      } else bad = true;  // MismatchingColumn
-    } else if (!IS_OPS && cur_id == 4) {
-      set(CC_DEPS_NUM, cur_s, cur_e);
-      if (nkids == 0) set(CC_DEPS_IDX, 0, 0);
-      else if (nkids == 1 && kid_type[0] == 3) set(CC_DEPS_IDX, kid_s[0], kid_e[0]);
-      else bad = true;
-    }
-  };
-  auto add_kid = [&](u32 type, u64 s, u64 e) {
-    if (nkids < 2) { kid_type[nkids] = type; kid_s[nkids] = s; kid_e[nkids] = e; }
-    nkids++;
-  };
-  for (u32 i = 0; i < n; i++) {
-    u32 id = raw[i].spec >> 4, type = raw[i].spec & 7;
-    u64 s = off, e = off + raw[i].len;
-    if (e > data_len || e < s) return 1;  // DataOutOfRange
-    off = e;
-    bool again = true;
-    while (again) {
-      again = false;
-      if (st == 0) {
-        if (type == 0) { st = 2; cur_id = id; cur_type = 0; cur_s = s; cur_e = e; nkids = 0; g_in_value = false; }
-        else if (type == 6) { st = 1; cur_id = id; cur_s = s; cur_e = e; cur_rs = cur_re = 0; }
-        else if (type == 7) return 1;  // LoneRawValueColumn
-        else emit_simple(id, type, s, e);
-      } else if (st == 1) {
-        if (type == 7) {
-          if (cur_id != id) return 1;  // MismatchingValueMetadataId
-          cur_rs = s; cur_re = e;
-          emit_value();
-          st = 0;
-        } else { emit_value(); st = 0; again = true; }
-      } else {
-        if (cur_id != id) { emit_group(); st = 0; again = true; }
-        else if (!g_in_value) {
-          if (type == 0 || type == 7) return 1;  // NestedGroup / LoneRawValueColumn
-          if (type == 6) g_in_value = true;      // a value column inside a group: not a shape this path maps
-          else add_kid(type, s, e);
-        } else {
-          g_in_value = false;
-          add_kid(6, 0, 0);
-          if (type != 7) again = true;
-        }
-      }
-    }
+AMH_DEV void cm_emit_simple(ColMapper& m, u32 id, u32 type, u64 s, u64 e) {
+  int slot = -1;
+  if (IS_OPS) {
+    if (id == 0 && type == 1) slot = OC_OBJ_ACTOR;
+    else if (id == 0 && type == 2) slot = OC_OBJ_CTR;
+    else if (id == 1 && type == 1) slot = OC_KEY_ACTOR;
+    else if (id == 1 && type == 3) slot = OC_KEY_CTR;
+    else if (id == 1 && type == 5) slot = OC_KEY_STR;
+    else if (id == 2 && type == 1) slot = OC_ID_ACTOR;
+    else if (id == 2 && type == 3) slot = OC_ID_CTR;
+    else if (id == 3 && type == 4) slot = OC_INSERT;
+    else if (id == 4 && type == 2) slot = OC_ACTION;
+    else if (id == 9 && type == 4) slot = OC_EXPAND;
+    else if (id == 10 && type == 5) slot = OC_MARK_NAME;
+  } else {
+    if (id == 0 && type == 1) slot = CC_ACTOR;
+    else if (id == 0 && type == 3) slot = CC_SEQ;
+    else if (id == 1 && type == 3) slot = CC_MAX_OP;
+    else if (id == 2 && type == 3) slot = CC_TIME;
+    else if (id == 3 && type == 5) slot = CC_MESSAGE;
   }
-  (void)cur_type;
-  if (st == 1) emit_value();
-  else if (st == 2) { if (g_in_value) add_kid(6, 0, 0); emit_group(); }
-  return bad ? 1 : 0;
+  if (slot >= 0) cm_set(m, slot, s, e);
+}
+template <bool IS_OPS>
+AMH_DEV void cm_emit_value(ColMapper& m) {
+  if (m.cur_id == 5) {
+    cm_set(m, IS_OPS ? (int)OC_VAL_META : (int)CC_EXTRA_META, m.cur_s, m.cur_e);
+    cm_set(m, IS_OPS ? (int)OC_VAL_RAW : (int)CC_EXTRA_RAW, m.cur_rs, m.cur_re);
+  }
+}
+template <bool IS_OPS>
+AMH_DEV void cm_emit_group(ColMapper& m) {
+  if (IS_OPS && m.cur_id == 8) {
+    cm_set(m, OC_SUCC_NUM, m.cur_s, m.cur_e);
+    if (m.nkids == 0) { cm_set(m, OC_SUCC_ACTOR, 0, 0); cm_set(m, OC_SUCC_CTR, 0, 0); }
+    else if (m.nkids == 2 && (m.kid0_type == 1 || m.kid0_type == 2) && m.kid1_type == 3) {
+      cm_set(m, OC_SUCC_ACTOR, m.kid0_s, m.kid0_e);
+      cm_set(m, OC_SUCC_CTR, m.kid1_s, m.kid1_e);
+    } else m.bad = true;  // MismatchingColumn
+  } else if (!IS_OPS && m.cur_id == 4) {
+    cm_set(m, CC_DEPS_NUM, m.cur_s, m.cur_e);
+    if (m.nkids == 0) cm_set(m, CC_DEPS_IDX, 0, 0);
+    else if (m.nkids == 1 && m.kid0_type == 3) cm_set(m, CC_DEPS_IDX, m.kid0_s, m.kid0_e);
+    else m.bad = true;
+  }
+}
+AMH_DEV void cm_add_kid(ColMapper& m, u32 type, u64 s, u64 e) {
+  if (m.nkids == 0) { m.kid0_type = type; m.kid0_s = s; m.kid0_e = e; }
+  else if (m.nkids == 1) { m.kid1_type = type; m.kid1_s = s; m.kid1_e = e; }
+  m.nkids++;
+}
+AMH_DEV void cm_init(ColMapper& m, u64 data_rel_off, u64 data_len, ColRef* slots) {
+  m.st = 0; m.cur_id = 0; m.cur_s = m.cur_e = m.cur_rs = m.cur_re = 0;
+  m.nkids = 0; m.kid0_type = m.kid1_type = 0; m.kid0_s = m.kid0_e = m.kid1_s = m.kid1_e = 0;
+  m.g_in_value = false; m.bad = false; m.off = 0; m.data_rel_off = data_rel_off; m.data_len = data_len; m.slots = slots;
+}
+// one raw column; 1 = layout error
+template <bool IS_OPS>
+AMH_DEV_NOINLINE int cm_feed(ColMapper& m, u32 spec, u64 len) {
+  u32 id = spec >> 4, type = spec & 7;
+  u64 s = m.off, e = m.off + len;
+  if (e > m.data_len || e < s) return 1;  // DataOutOfRange
+  m.off = e;
+  for (int pass = 0; pass < 2; pass++) {   // a column that closes a value / group is looked at again in the ready state
+    if (m.st == 0) {
+      if (type == 0) { m.st = 2; m.cur_id = id; m.cur_s = s; m.cur_e = e; m.nkids = 0; m.g_in_value = false; }
+      else if (type == 6) { m.st = 1; m.cur_id = id; m.cur_s = s; m.cur_e = e; m.cur_rs = m.cur_re = 0; }
+      else if (type == 7) return 1;  // LoneRawValueColumn
+      else cm_emit_simple<IS_OPS>(m, id, type, s, e);
+      return 0;
+    }
+    if (m.st == 1) {
+      if (type == 7) {
+        if (m.cur_id != id) return 1;  // MismatchingValueMetadataId
+        m.cur_rs = s; m.cur_re = e;
+        cm_emit_value<IS_OPS>(m);
+        m.st = 0;
+        return 0;
+      }
+      cm_emit_value<IS_OPS>(m);
+      m.st = 0;
+      continue;
+    }
+    // in group
+    if (m.cur_id != id) { cm_emit_group<IS_OPS>(m); m.st = 0; continue; }
+    if (!m.g_in_value) {
+      if (type == 0 || type == 7) return 1;  // NestedGroup / LoneRawValueColumn
+      if (type == 6) m.g_in_value = true;    // a value column inside a group: not a shape this path maps
+      else cm_add_kid(m, type, s, e);
+      return 0;
+    }
+    m.g_in_value = false;
+    cm_add_kid(m, 6, 0, 0);
+    if (type == 7) return 0;
+    // the raw half is missing: the column is a fresh child of the same group
+    if (type == 0) return 1;
+    if (type == 6) m.g_in_value = true;
+    else cm_add_kid(m, type, s, e);
+    return 0;
+  }
+  return 0;
+}
+template <bool IS_OPS>
+AMH_DEV_NOINLINE int cm_finish(ColMapper& m) {
+  if (m.st == 1) cm_emit_value<IS_OPS>(m);
+  else if (m.st == 2) { if (m.g_in_value) cm_add_kid(m, 6, 0, 0); cm_emit_group<IS_OPS>(m); }
+  return m.bad ? 1 : 0;
+}
+
+// one column-metadata block (raw_column.rs:205-272): count, then (spec, len) pairs in normal order.
+// mapper == null: validate and total the lengths; otherwise feed the layout machine.
+// 0 ok, 1 parse error, 2 too many columns for this engine
+template <bool IS_OPS>
+AMH_DEV_NOINLINE int parse_col_meta(const u8* p, u64& pos, u64 end, u64 chunk_data_len, u64& total, ColMapper* mapper) {
+  u64 nc;
+  if (rd_uleb_strict(p, pos, end, nc)) return 1;
+  if (nc > chunk_data_len) return 1;
+  if (nc > 4096) return 2;
+  u32 prev_norm = 0;
+  total = 0;
+  for (u64 i = 0; i < nc; i++) {
+    u64 spec, clen;
+    if (rd_uleb_strict(p, pos, end, spec)) return 1;
+    if (spec > 0xFFFFFFFFull) return 1;
+    if (rd_uleb_strict(p, pos, end, clen)) return 1;
+    u32 norm = (u32)spec & ~8u;
+    if (i > 0 && norm < prev_norm) return 1;  // NotInNormalOrder
+    prev_norm = norm;
+    // ingest inflates deflated columns on the host (compression.rs:51-74) before upload
+    if (spec & 8) return 1;  // a column that ingest could not inflate (ParseError::Deflate)
+    if (clen > chunk_data_len) return 1;
+    total += clen;
+    if (mapper && cm_feed<IS_OPS>(*mapper, (u32)spec, clen)) return 1;
+  }
+  return 0;
 }
 
 AMH_DEV void k_parse(const BatchDev& B, u32 d) {
@@ -187,31 +237,11 @@ AMH_DEV void k_parse(const BatchDev& B, u32 d) {
   D.heads_off = (u32)pos;
   D.n_heads = (u32)n;
   pos += 32 * n;
-  RawColDev craw[AMH_MAX_RAW_COLS], oraw[AMH_MAX_RAW_COLS];
-  u32 ncraw = 0, noraw = 0;
-  for (int which = 0; which < 2; which++) {
-    RawColDev* raw = which ? oraw : craw;
-    u64 nc;
-    if (rd_uleb_strict(p, pos, end, nc)) { amh_fail(B, d, AMH_E_PARSE); return; }
-    if (nc > AMH_MAX_RAW_COLS) { amh_fail(B, d, nc > len ? AMH_E_PARSE : AMH_E_UNSUPPORTED); return; }
-    u32 prev_norm = 0;
-    for (u64 i = 0; i < nc; i++) {
-      u64 spec, clen;
-      if (rd_uleb_strict(p, pos, end, spec) || spec > 0xFFFFFFFFull || rd_uleb_strict(p, pos, end, clen)) { amh_fail(B, d, AMH_E_PARSE); return; }
-      u32 norm = (u32)spec & ~8u;
-      if (i > 0 && norm < prev_norm) { amh_fail(B, d, AMH_E_PARSE); return; }  // NotInNormalOrder
-      prev_norm = norm;
-      // ingest inflates deflated columns on the host (compression.rs:51-74) before upload
-      if (spec & 8) { amh_fail(B, d, AMH_E_PARSE); return; }  // a column that ingest could not inflate (ParseError::Deflate)
-      if (clen > len) { amh_fail(B, d, AMH_E_PARSE); return; }
-      raw[i].spec = (u32)spec;
-      raw[i].len = clen;
-    }
-    if (which) noraw = (u32)nc; else ncraw = (u32)nc;
-  }
-  u64 ctot = 0, otot = 0;
-  for (u32 i = 0; i < ncraw; i++) ctot += craw[i].len;
-  for (u32 i = 0; i < noraw; i++) otot += oraw[i].len;
+  // walk 1: validate both metadata blocks and total their data
+  u64 meta_pos = pos, ctot = 0, otot = 0;
+  int rc = parse_col_meta<false>(p, pos, end, len, ctot, (ColMapper*)0);
+  if (rc == 0) rc = parse_col_meta<true>(p, pos, end, len, otot, (ColMapper*)0);
+  if (rc) { amh_fail(B, d, rc == 2 ? AMH_E_UNSUPPORTED : AMH_E_PARSE); return; }
   if (ctot > end - pos) { amh_fail(B, d, AMH_E_PARSE); return; }
   u64 cdata = pos;
   pos += ctot;
@@ -227,10 +257,13 @@ AMH_DEV void k_parse(const BatchDev& B, u32 d) {
     }
     if (pos != end) { amh_fail(B, d, AMH_E_PARSE); return; }
   }
-  if (map_columns<false>(craw, ncraw, cdata, ctot, D.ccol) || map_columns<true>(oraw, noraw, odata, otot, D.ocol)) {
-    amh_fail(B, d, AMH_E_PARSE);
-    return;
-  }
+  // walk 2: the column layout
+  ColMapper m;
+  u64 t2;
+  cm_init(m, cdata, ctot, D.ccol);
+  if (parse_col_meta<false>(p, meta_pos, end, len, t2, &m) || cm_finish<false>(m)) { amh_fail(B, d, AMH_E_PARSE); return; }
+  cm_init(m, odata, otot, D.ocol);
+  if (parse_col_meta<true>(p, meta_pos, end, len, t2, &m) || cm_finish<true>(m)) { amh_fail(B, d, AMH_E_PARSE); return; }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -84,6 +84,7 @@ struct BatchDev {
   const u8* arena;
   const u64* doc_off;      // [2 * n_docs] (start, end) byte range of each input in the arena
   i32* status;             // [n_docs]
+  u32* fail_line;          // [n_docs] source line of the check that failed the document (diagnostics)
   DocDesc* desc;           // [n_docs]
   DocCounts* cnt;          // [n_docs]
   // [n_docs + 1] exclusive scans of the per-document counts
