@@ -36,7 +36,7 @@ EXPORTS = [
     "amh_load_batch", "amh_batch_free", "amh_bytes_free", "amh_doc_status", "amh_batch_get_stats", "amh_heads",
     "amh_changes", "amh_hydrate_json", "amh_doc_max_op", "amh_merge_batch", "amh_apply_changes", "amh_save_batch",
     "amh_sync_summaries", "amh_ctx_set_profiling", "amh_ctx_num_kernels", "amh_ctx_kernel_name", "amh_ctx_kernel_time",
-    "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_u64_free",
+    "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free",
 ]
 
 DOC_ERRORS = {
@@ -79,6 +79,8 @@ def bind(lib):
     lib.amh_ctx_reset_profile.argtypes = [vp]
     lib.amh_gen_map_docs.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                      C.POINTER(BytesOut), C.POINTER(C.POINTER(C.c_uint64))]
+    lib.amh_gen_text_docs.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                      C.POINTER(BytesOut), C.POINTER(C.POINTER(C.c_uint64))]
     lib.amh_u64_free.argtypes = [C.POINTER(C.c_uint64)]
     lib.amh_sync_summaries.argtypes = [vp, vp, C.POINTER(BytesOut)]
     return lib
@@ -195,6 +197,32 @@ class Batch:
         return {name: getattr(s, name) for name, _ in BatchStats._fields_}
 
 
+class Arena:
+    """Concatenated documents + offsets[n + 1], owned by the library (generator output)."""
+
+    def __init__(self, engine, o, offs, n):
+        self.engine, self.o, self.offs, self.n = engine, o, offs, n
+
+    @property
+    def nbytes(self):
+        return self.o.len
+
+    def doc(self, i):
+        return C.string_at(C.cast(self.o.data, C.c_void_p).value + self.offs[i], self.offs[i + 1] - self.offs[i])
+
+    def close(self):
+        if self.o.data:
+            self.engine.lib.amh_bytes_free(C.byref(self.o))
+            self.engine.lib.amh_u64_free(self.offs)
+            self.offs = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Staged:
     def __init__(self, engine, handle, n):
         self.engine, self.h, self.n = engine, handle, n
@@ -249,6 +277,20 @@ class Engine:
             raise EngineError("amh_stage_batch failed: " + self._err())
         return Staged(self, h, n)
 
+    def stage_arena(self, arena):
+        """Stage the documents of an Arena (concatenated bytes + offsets) without copying them into Python objects."""
+        import numpy as np
+        n = arena.n
+        offs = np.ctypeslib.as_array(arena.offs, shape=(n + 1,)).astype(np.uint64)
+        base = C.cast(arena.o.data, C.c_void_p).value or 0
+        ptrs = (offs[:n] + np.uint64(base)).astype(np.uint64)
+        lens = (offs[1:] - offs[:n]).astype(np.uint64)
+        h = self.lib.amh_stage_batch(self.ctx, C.cast(ptrs.ctypes.data, C.POINTER(C.c_char_p)),
+                                     C.cast(lens.ctypes.data, C.POINTER(C.c_size_t)), n)
+        if not h:
+            raise EngineError("amh_stage_batch failed: " + self._err())
+        return Staged(self, h, n)
+
     def load_staged(self, staged, verify_heads=True):
         opts = LoadOpts(1 if verify_heads else 0, 0)
         h = self.lib.amh_load_staged(self.ctx, staged.h, C.byref(opts))
@@ -295,8 +337,30 @@ class Engine:
                                        C.byref(o), C.byref(offs))
         if rc != 0:
             raise EngineError(f"amh_gen_map_docs failed: {rc}")
+        return self._take(o, offs, n_docs)
+
+    def gen_map_arena(self, seed, n_docs, n_actors=4, changes_per_actor=5, ops_per_change=50, n_keys=128, threads=8):
+        """Like gen_map_docs, but the bytes stay in the C buffer (large batches)."""
+        o = BytesOut()
+        offs = C.POINTER(C.c_uint64)()
+        rc = self.lib.amh_gen_map_docs(seed, n_docs, n_actors, changes_per_actor, ops_per_change, n_keys, threads,
+                                       C.byref(o), C.byref(offs))
+        if rc != 0:
+            raise EngineError(f"amh_gen_map_docs failed: {rc}")
+        return Arena(self, o, offs, n_docs)
+
+    def _take(self, o, offs, n):
         blob = C.string_at(o.data, o.len)
-        offsets = [offs[i] for i in range(n_docs + 1)]
+        offsets = [offs[i] for i in range(n + 1)]
         self.lib.amh_bytes_free(C.byref(o))
         self.lib.amh_u64_free(offs)
         return blob, offsets
+
+    def gen_text_docs(self, seed, n_docs, n_replicas=8, base_len=1000, ops_per_replica=5000, ops_per_change=500, threads=8):
+        o = BytesOut()
+        offs = C.POINTER(C.c_uint64)()
+        rc = self.lib.amh_gen_text_docs(seed, n_docs, n_replicas, base_len, ops_per_replica, ops_per_change, threads,
+                                        C.byref(o), C.byref(offs))
+        if rc != 0:
+            raise EngineError(f"amh_gen_text_docs failed: {rc}")
+        return self._take(o, offs, n_docs * n_replicas)

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the batched document-load hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): `--docs` JSON-map documents of ~1k ops each (4 actors x 5
+concurrent rounds x 50 ops, Zipf keys, conflicts, counters, deletes, one nested map), synthetic,
+generated on the host in the reference's storage format.  One step = one pass of the device load
+pipeline (parse, checksum, column decode, op linking, change re-derivation + SHA-256, heads check,
+visibility) over the whole batch, with the encoded documents already resident in HBM.
+Multi-GPU: one process per GPU, the batch is sharded by document (weak scaling: every rank loads
+`--docs` documents of its own); no data-path collective.
+
+Prints ONE JSON line (rank 0).  `value` = ops loaded per second over all ranks, ops = sum of
+Change::len over the loaded documents."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(st, cols):
+    """Compulsory HBM bytes of each kernel for one pass (DESIGN.md 'Kernels'): what it must read and
+    write once, independent of the implementation.  R op rows, S succ entries, T ops (rows + deletes),
+    C changes, D documents, P dep entries; column bytes from the parsed descriptors."""
+    R, S, T, C, D = st["op_rows"], st["succ_entries"], st["ops_loaded"], st["changes"], st["n_docs"]
+    Ein, Eout = st["encoded_bytes"], st["change_bytes"]
+    return {
+        "parse": cols["meta"] + 216 * D,
+        "sha_doc": Ein + 32 * D,
+        "count": cols["count"] + 16 * D,
+        "extract": 16 * D + 40 * D,
+        "actors": cols["actors"] + 24 * st["actors"],
+        "chg_init": 28 * C,
+        "decode_chg": cols["chg"] + 72 * C,
+        "decode_ops": cols["ops"] + 44 * R + 8 * S,          # E + 44 + 8s per op row
+        "rows": 44 * R + 12 * R + 4 * R,                     # row in, id table entry out, r_doc
+        "obj_order": 8 * R,
+        "succ": 2 * 8 * S + 12 * R,                          # SURVEY 8d link/visibility
+        "bucket": (8 + 4) * T,                               # SURVEY 8d change bucketing
+        "chg_finish": 24 * C,
+        "place": 8 * T,
+        "pred_fill": 12 * S,
+        "pred_sort": 16 * S,
+        "actor_mark": 12 * T,
+        "actor_rank": 8 * C + 4 * st["actor_map"],
+        "encode_size": 44 * T + 56 * C,                      # SURVEY 8d re-encode: 44 + E' (size pass: no E')
+        "chg_layout": 100 * C,
+        "encode_store": 44 * T + Eout,
+        "assemble_hash": 2 * Eout + 32 * C,
+        "visible": 12 * R + 2 * R,
+        "scan": 8 * (9 * D + 2 * C + T),
+    }
+
+
+def column_bytes(eng, batch, n_docs):
+    """Encoded bytes each decode kernel has to read, from the parsed per-document descriptors."""
+    import ctypes as C
+    import numpy as np
+    lib = eng.lib
+    lib.amh_debug_array.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    n = C.c_size_t()
+    lib.amh_debug_array(batch.h, b"desc", None, 0, C.byref(n))
+    buf = np.empty(n.value, dtype=np.uint8)
+    lib.amh_debug_array(batch.h, b"desc", buf.ctypes.data, n.value, C.byref(n))
+    dt = np.dtype({"names": ["chunk_off", "hdr", "ccol", "ocol"], "formats": ["<u8", ("<u4", (9,)), ("<u4", (9, 2)), ("<u4", (16, 2))],
+                   "offsets": [0, 8, 44, 116], "itemsize": 248})   # struct DocDesc (amh_types.h)
+    d = buf.view(dt)
+    ccol, ocol = d["ccol"][:, :, 1].astype(np.int64), d["ocol"][:, :, 1].astype(np.int64)
+    hdr = d["hdr"].astype(np.int64)  # chunk_len, data_off, data_len, n_actors, actors_off, n_heads, heads_off, suffix_off, suffix_len
+    data_start = np.minimum(d["ccol"][:, :, 0].astype(np.int64).max(axis=1), hdr[:, 1] + hdr[:, 2])
+    return {
+        "meta": int((hdr[:, 1] + hdr[:, 2] - ccol.sum(axis=1) - ocol.sum(axis=1)).sum()),
+        "count": int(ocol[:, 6].sum() + ocol[:, 11].sum() + ccol[:, 0].sum() + ccol[:, 5].sum()),
+        "actors": int((hdr[:, 6] - hdr[:, 4]).clip(min=0).sum()),
+        "chg": int(ccol.sum()),
+        "ops": int(ocol.sum()),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--docs", type=int, default=100000, help="documents per GPU (configs[1]: 100k)")
+    ap.add_argument("--cpu-sample", type=int, default=4000, help="documents of the same workload timed on the CPU oracle")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from automerge_amd import Engine
+    eng = Engine(gpu=local_rank)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "16")) if world == 1 else max(2, int(os.environ.get("OMP_NUM_THREADS", "16")) // max(1, world))
+    threads = max(1, min(threads, 32))
+    seed = 0xA070 + rank * args.docs
+    t0 = time.time()
+    arena = eng.gen_map_arena(seed, args.docs, 4, 5, 50, 128, threads)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    staged = eng.stage_arena(arena)   # host ingest + H2D: not part of the timed region (inputs resident in HBM)
+    t_stage = time.time() - t0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.load_staged(staged).close()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        b = eng.load_staged(staged)   # returns after the stream has drained (per-document status is read back)
+        b.close()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # one more, profiled pass: HIP events around every kernel launch on the pipeline's own stream
+    eng.set_profiling(True)
+    eng.reset_profile()
+    batch = eng.load_staged(staged)
+    eng.set_profiling(False)
+    kt = eng.kernel_times()
+    st = batch.stats()
+    n_bad = st["n_docs"] - st["n_ok"]
+    if n_bad:
+        raise SystemExit(f"{n_bad} documents failed to load: the benchmark input must load cleanly")
+    ops = st["ops_loaded"]
+    tot = torch.tensor([float(elapsed), float(ops)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed_max, ops_all = float(tmax[0]), float(tot[1])
+    else:
+        elapsed_max, ops_all = elapsed, float(ops)
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    import ctypes as C
+    st["actors"] = 4 * st["n_docs"]
+    st["actor_map"] = 4 * st["changes"]
+    cols = column_bytes(eng, batch, st["n_docs"])
+    model = algorithmic_bytes(st, cols)
+    dom = max((k for k in kt if kt[k][1] > 0), key=lambda k: kt[k][0])
+    dom_ms, dom_calls = kt[dom]
+    per_launch_ms = dom_ms / dom_calls
+    per_launch_bytes = model[dom] / dom_calls
+    achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+    total_kernel_ms = sum(v[0] for v in kt.values())
+    kernels = {k: {"ms": round(v[0] / max(1, v[1]), 4), "launches": v[1],
+                   "GBps": round(model[k] / v[1] / (v[0] / v[1] * 1e-3) / 1e9, 2) if v[0] > 0 and v[1] > 0 else None}
+               for k, v in kt.items() if v[1] > 0}
+    out = {
+        "metric": "ops loaded+merged/sec (node)", "value": ops_all * args.steps / elapsed_max, "unit": "ops/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64", "data": "synthetic",
+        "config": {"workload": "configs[1]: JSON-map documents batch load + visibility on one MI355X per rank",
+                   "docs_per_gpu": args.docs, "ops_per_doc": ops / max(1, st["n_docs"]), "encoded_bytes_per_gpu": st["encoded_bytes"],
+                   "sharding": f"documents x{world}", "gen_s": round(t_gen, 2), "stage_s": round(t_stage, 2),
+                   "pcie_inclusive_ops_per_s": ops / (elapsed / args.steps + t_stage)},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": per_launch_bytes,
+                     "launch_ms": per_launch_ms, "kernel_ms_total": total_kernel_ms},
+        "kernels": kernels,
+    }
+    if not args.no_cpu and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as o   # CPU oracle: the reported baseline only (never the measured path)
+        import numpy as np
+        ns = min(args.cpu_sample, args.docs)
+        cores = max(1, min(threads, 16))
+        offs = np.ctypeslib.as_array(arena.offs, shape=(ns + 1,)).astype(np.uint64)
+        ops_c, fails = C.c_ulong(), C.c_ulong()
+        secs = o.lib.amo_bench_load_batch(C.cast(arena.o.data, C.c_char_p), C.cast(offs.ctypes.data, C.POINTER(C.c_uint64)), ns, cores, 1,
+                                          C.byref(ops_c), C.byref(fails))
+        out["cpu_baseline"] = {"value": ops_c.value / secs, "unit": "ops/s", "cores": cores, "kind": "port",
+                               "sample": f"first {ns} documents of the same batch, load + materialize, one document per thread "
+                                         f"(CPU restatement in oracle/, not the Rust reference: no toolchain)", "failures": fails.value}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

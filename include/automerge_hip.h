@@ -163,6 +163,12 @@ const char* amh_ctx_kernel_name(int k);
 int amh_ctx_kernel_time(amh_ctx*, int k, double* ms, uint64_t* launches);
 int amh_ctx_reset_profile(amh_ctx*);
 
+/* Diagnostics (no counterpart in the reference): copy one named device array of a batch to the host
+ * (names = fields of BatchDev, automerge_amd/csrc/amh_types.h).  *len receives the byte size; with
+ * cap == 0 only the size is returned.  Used by tests to diff the HIP build against the host
+ * emulation of the same kernel bodies stage by stage. */
+int amh_debug_array(const amh_batch*, const char* name, void* out, size_t cap, size_t* len);
+
 /* ---- synthetic workloads --------------------------------------------------------
  * Deterministic generator of reference-format documents (save_nocompress form): `n_docs` map
  * documents of n_actors x changes_per_actor x ops_per_change ops on the root map and one nested map,
@@ -170,6 +176,12 @@ int amh_ctx_reset_profile(amh_ctx*);
  * + offsets[n_docs + 1]; free both with amh_bytes_free / amh_u64_free. */
 int amh_gen_map_docs(uint64_t seed, uint32_t n_docs, uint32_t n_actors, uint32_t changes_per_actor,
                      uint32_t ops_per_change, uint32_t n_keys, int threads, amh_bytes_out* docs, uint64_t** offsets);
+/* Text documents (BASELINE.json configs[2], [3]): per document one base change (makeText + base_len
+ * characters) and n_replicas divergent replicas of ops_per_replica edits (70 % inserts in runs, 30 %
+ * deletes) in changes of ops_per_change ops.  Output: n_docs * n_replicas saved documents, replica r
+ * of document i at index i * n_replicas + r (base + that replica's changes). */
+int amh_gen_text_docs(uint64_t seed, uint32_t n_docs, uint32_t n_replicas, uint32_t base_len, uint32_t ops_per_replica,
+                      uint32_t ops_per_change, int threads, amh_bytes_out* docs, uint64_t** offsets);
 void amh_u64_free(uint64_t*);
 
 #ifdef __cplusplus

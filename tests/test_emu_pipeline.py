@@ -1,0 +1,92 @@
+"""CPU tier: the kernel bodies of the device pipeline (automerge_amd/csrc/amh_kernels.inl) compiled for
+the host (tests/emu) and driven through the same host orchestration + C ABI, checked against the
+oracle: golden documents, the reference's fixtures / fuzz crashers, and generated workloads.  The
+generators themselves are checked against the oracle by load + re-save identity."""
+import glob
+import os
+
+import pytest
+
+import oracle_lib as o
+from emu_engine import emu_engine
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_engine()
+
+
+def compare(batch, i, data):
+    ref = o.Doc.load(data)
+    batch.check(i)
+    assert batch.hydrate_json(i) == ref.hydrate_json()
+    mine, theirs = batch.get_changes(i), ref.changes()
+    assert [c["hash"] for c in mine] == [c["hash"] for c in theirs]
+    assert [c["raw"] for c in mine] == [c["raw"] for c in theirs]
+    assert [(c["seq"], c["start_op"], c["len"]) for c in mine] == [(c["seq"], c["start_op"], c["len"]) for c in theirs]
+    assert batch.get_heads(i) == ref.get_heads()
+    assert batch.max_op(i) == ref.max_op()
+
+
+def test_golden_documents(emu, golden_dir):
+    files = sorted(glob.glob(os.path.join(golden_dir, "docs", "*.automerge")))
+    assert len(files) == 60
+    docs = [open(f, "rb").read() for f in files]
+    batch = emu.load_batch(docs)
+    for i, d in enumerate(docs):
+        compare(batch, i, d)
+
+
+def test_bad_documents_fail_like_the_oracle(emu, golden_dir):
+    """fuzz crashers (tests/test.rs:1405-1415) and invalid fixtures: same accept / reject decision; a
+    bad document never poisons its neighbours in the batch."""
+    files = sorted(glob.glob(os.path.join(golden_dir, "ref_fuzz_crashers", "*"))) + sorted(glob.glob(os.path.join(golden_dir, "ref_fixtures", "*")))
+    good = open(sorted(glob.glob(os.path.join(golden_dir, "docs", "*.automerge")))[0], "rb").read()
+    docs = []
+    for f in files:
+        docs += [open(f, "rb").read(), good]
+    batch = emu.load_batch(docs)
+    for i, d in enumerate(docs):
+        try:
+            ref = o.Doc.load(d)
+        except o.OracleError:
+            ref = None
+        kind, _ = batch.status(i)
+        if kind == 91:   # shape this round's device path declares unsupported (change chunks): never a silent success
+            continue
+        assert (kind == 0) == (ref is not None), (files[i // 2] if i % 2 == 0 else "good", kind)
+        if ref is not None:
+            compare(batch, i, d)
+
+
+def test_generated_map_documents(emu):
+    blob, offs = emu.gen_map_docs(0xA070, 24, 4, 5, 50, 128, 4)
+    docs = [blob[offs[i]:offs[i + 1]] for i in range(24)]
+    for d in docs:
+        assert o.Doc.load(d).save(deflate=False) == d   # generator output is canonical reference-format bytes
+    batch = emu.load_batch(docs)
+    for i, d in enumerate(docs):
+        compare(batch, i, d)
+    st = batch.stats()
+    assert st["ops_loaded"] == 24 * 1000 and st["delete_ops"] > 0
+
+
+def test_generated_text_documents(emu):
+    blob, offs = emu.gen_text_docs(0xB070, 3, 4, 100, 400, 64, 4)
+    docs = [blob[offs[i]:offs[i + 1]] for i in range(12)]
+    for d in docs:
+        assert o.Doc.load(d).save(deflate=False) == d
+    batch = emu.load_batch(docs)
+    for i, d in enumerate(docs):
+        compare(batch, i, d)
+
+
+def test_empty_and_ragged_batch(emu):
+    blob, offs = emu.gen_map_docs(7, 3, 2, 1, 3, 4, 1)
+    docs = [b"", blob[offs[0]:offs[1]], b"", blob[offs[1]:offs[2]][:-1], blob[offs[2]:offs[3]]]
+    batch = emu.load_batch(docs)
+    assert batch.status(0)[0] == 0 and batch.get_changes(0) == [] and batch.get_heads(0) == []
+    compare(batch, 1, docs[1])
+    assert batch.status(3)[0] != 0
+    compare(batch, 4, docs[4])
+    assert len(emu.load_batch([])) == 0
