@@ -337,6 +337,7 @@ extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, cons
   rt_memset(B.dt_key, 0, ((size_t)B.tot_dt + 1) * 8, ctx->stream);
   rt_memset(B.d_first_pred_row, 0xFF, ((size_t)B.tot_dt + 1) * 4, ctx->stream);
   rt_memset(B.s_row, 0xFF, NS * 4, ctx->stream);
+  rt_memset(B.r_doc, 0xFF, NR * 4, ctx->stream);
   rt_memset(B.t_pred_cnt, 0, ((size_t)T + 2) * 4, ctx->stream);
   rt_memset(B.t_pred_fill, 0, ((size_t)T + 2) * 4, ctx->stream);
   rt_memset(B.chg_actor_map, 0, ((size_t)b->tot_map + 1) * 4, ctx->stream);
@@ -363,12 +364,12 @@ extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, cons
   if (!ok) return fail("device out of memory");
   rt_memset(B.ops_sorted, 0xFF, ((size_t)tot_ops + 1) * 4, ctx->stream);
   launch(ctx, AK_PLACE, B, T);
-#ifdef AMH_EMU
-  memcpy(B.t_pred_base, B.t_pred_cnt, (size_t)T * 4);
-#else
-  (void)hipMemcpyAsync(B.t_pred_base, B.t_pred_cnt, (size_t)T * 4, hipMemcpyDeviceToDevice, ctx->stream);
-#endif
-  if (!scan_inplace(b, B.t_pred_base, T, nullptr)) return fail("scan failed");
+  B.j_pred_base = balloc<u32>(b, (size_t)tot_ops + 2, &ok);
+  if (!ok) return fail("device out of memory");
+  rt_memset(B.t_pred_base, 0, ((size_t)T + 2) * 4, ctx->stream);
+  launch(ctx, AK_PRED_SLOT_CNT, B, tot_ops);
+  if (!scan_inplace(b, B.j_pred_base, tot_ops, nullptr)) return fail("scan failed");
+  launch(ctx, AK_PRED_SLOT_BASE, B, tot_ops);
   launch(ctx, AK_PRED_FILL, B, B.tot_succ);
   launch(ctx, AK_PRED_SORT, B, T);
   launch(ctx, AK_ACTOR_MARK, B, T);
@@ -774,7 +775,7 @@ extern "C" int amh_debug_array(const amh_batch* b, const char* name, void* out, 
     {"r_doc", B.r_doc, NR * 4}, {"r_inc_cnt", B.r_inc_cnt, NR * 4}, {"r_inc_sum", B.r_inc_sum, NR * 8}, {"r_visible", B.r_visible, NR},
     {"r_winner", B.r_winner, NR}, {"s_actor", B.s_actor, NS * 4}, {"s_ctr", B.s_ctr, NS * 4}, {"s_row", B.s_row, NS * 4},
     {"s_target", B.s_target, NS * 4}, {"t_pred_cnt", B.t_pred_cnt, T * 4}, {"t_pred_base", B.t_pred_base, (T + 1) * 4},
-    {"t_chg", B.t_chg, T * 4}, {"pred_ids", B.pred_ids, NS * 8}, {"ops_sorted", B.ops_sorted, (size_t)B.tot_ops * 4},
+    {"t_chg", B.t_chg, T * 4}, {"j_pred_base", B.j_pred_base, ((size_t)B.tot_ops + 1) * 4}, {"pred_ids", B.pred_ids, NS * 8}, {"ops_sorted", B.ops_sorted, (size_t)B.tot_ops * 4},
     {"out_arena", B.out_arena, (size_t)b->tot_out},
   };
   for (const Ent& e : tab) {

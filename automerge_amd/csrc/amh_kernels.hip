@@ -27,6 +27,8 @@ AMH_GLOBAL(k_succ)
 AMH_GLOBAL(k_bucket)
 AMH_GLOBAL(k_chg_finish)
 AMH_GLOBAL(k_place)
+AMH_GLOBAL(k_pred_slot_cnt)
+AMH_GLOBAL(k_pred_slot_base)
 AMH_GLOBAL(k_pred_fill)
 AMH_GLOBAL(k_pred_sort)
 AMH_GLOBAL(k_actor_mark)
@@ -37,16 +39,264 @@ AMH_GLOBAL(k_encode_store)
 AMH_GLOBAL(k_assemble_hash)
 AMH_GLOBAL(k_visible)
 
+// ------------------------------------------------------------------------------------------
+// Change re-encode, LDS-staged (replaces the thread-per-(change, column) kernels k_encode_size /
+// k_encode_store on the device; those remain the host-emulation form of the same encoders).
+//
+// One wave = 64 consecutive changes, lane = change.  The per-op fields a group of columns needs are
+// gathered cooperatively — consecutive threads take consecutive ops of ops_sorted, so the index reads
+// coalesce and the row gathers are independent loads instead of a dependent chain per lane — into
+// LDS tiles of ENC_K ops per change; each lane then runs the reference's run-length state machines
+// (rle.rs:31-133, delta.rs:10-43, boolean.rs:11-51) over its own change out of LDS.  Tiles are
+// padded to an odd stride so that the 64 lanes walk 64 different banks.
+// STORE = false: column sizes -> c_col_len;  STORE = true: bytes -> out_arena.
+// ------------------------------------------------------------------------------------------
+#define ENC_K 32
+#define ENC_STRIDE (ENC_K + 1)
+#define ENC_TILE (64 * ENC_STRIDE)
+
+struct EncShared {
+  u32 t0[ENC_TILE], t1[ENC_TILE], t2[ENC_TILE], t3[ENC_TILE];
+  u32 n[64], base[64], mapb[64], pbase[64], pn[64];
+};
+
+template <class F>
+__device__ __forceinline__ void enc_load_tile(const u32* cnt, u32 t0, F f) {
+  for (u32 l0 = 0; l0 < 64; l0 += 64 / ENC_K) {
+    u32 l = l0 + threadIdx.x / ENC_K, k = threadIdx.x % ENC_K;
+    if (t0 + k < cnt[l]) f(l, k, t0 + k);
+  }
+}
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+  for (int off = 32; off > 0; off >>= 1) { u32 o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+  return v;
+}
+__device__ __forceinline__ void bool_feed(ColWriter& w, bool& last, u64& cnt, bool v) {  // boolean.rs:35-50
+  if (v == last) cnt++; else { cw_uleb(w, cnt); last = v; cnt = 1; }
+}
+
+template <bool STORE>
+__global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
+  __shared__ EncShared S;
+  const u32 lane = threadIdx.x;
+  const u32 c = blockIdx.x * 64 + lane;
+  const bool live = c < B.tot_chg && B.status[B.c_doc[c]] == 0;
+  const u32 n = live ? B.c_nops[c] : 0;
+  const u32 base = live ? B.c_op_base[c] : 0;
+  const u32 d = live ? B.c_doc[c] : 0;
+  const u8* chunk = B.arena + B.desc[d].chunk_off;
+  const u32 raw_col = B.desc[d].ocol[OC_VAL_RAW].off;
+  u32* cl = B.c_col_len + (u64)(c < B.tot_chg ? c : 0) * AMH_NCOLS;
+  S.n[lane] = n;
+  S.base[lane] = base;
+  S.mapb[lane] = live ? B.c_map_base[c] : 0;
+  u32 pb = 0, pn = 0;
+  if (live && n) { pb = B.j_pred_base[base]; pn = B.j_pred_base[base + n] - pb; }
+  S.pbase[lane] = pb;
+  S.pn[lane] = pn;
+  __syncthreads();
+  const u32 n_max = wave_max_u32(n);
+  // output cursors of the store pass: columns back to back at c_cols_off (storage/change.rs:486-488)
+  u8* col_out[AMH_NCOLS];
+  {
+    u64 off = live ? (u64)B.c_out_off[c] + B.c_cols_off[c] : 0;
+#pragma unroll
+    for (int k = 0; k < AMH_NCOLS; k++) {
+      col_out[k] = (STORE && live && cl[k]) ? B.out_arena + off : (u8*)0;
+      if (STORE && live) off += cl[k];
+    }
+  }
+  u32 len_out[AMH_NCOLS];
+#pragma unroll
+  for (int k = 0; k < AMH_NCOLS; k++) len_out[k] = 0;
+  const u32 row = lane * ENC_STRIDE;
+  RleVal x; x.v = 0; x.s = 0; x.n = 0;
+
+  // ---- group 1: object id (columns 0, 1; obj_id.rs:158-172) -----------------------------------
+  {
+    RleEnc<0> ea, ec; re_init(ea); re_init(ec);
+    ColWriter wa, wc; wa.out = col_out[0]; wa.pos = 0; wc.out = col_out[1]; wc.pos = 0;
+    for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
+      enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
+        u32 t = B.ops_sorted[S.base[l] + i];
+        u32 kr = op_key_row(B, t);
+        u32 oc = B.r_obj_ctr[kr];
+        S.t0[l * ENC_STRIDE + k] = oc ? B.chg_actor_map[S.mapb[l] + B.r_obj_actor[kr]] : AMH_NULL32;
+        S.t1[l * ENC_STRIDE + k] = oc;
+      });
+      __syncthreads();
+      u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
+      for (u32 i = 0; i < cnt; i++) {
+        u32 oc = S.t1[row + i];
+        if (oc == 0) { re_null(wa, ea); re_null(wc, ec); }
+        else { x.v = S.t0[row + i]; re_value(wa, ea, x); x.v = oc; re_value(wc, ec, x); }
+      }
+      __syncthreads();
+    }
+    re_finish(wa, ea); re_finish(wc, ec);
+    len_out[0] = wa.pos; len_out[1] = wc.pos;
+  }
+  // ---- group 2: key (columns 2, 3, 4; key.rs:236-257) -----------------------------------------
+  {
+    RleEnc<0> ea; re_init(ea);
+    DeltaEnc ec; re_init(ec.r); ec.abs = 0;
+    RleEnc<2> es; re_init(es);
+    ColWriter wa, wc, ws; wa.out = col_out[2]; wa.pos = 0; wc.out = col_out[3]; wc.pos = 0; ws.out = col_out[4]; ws.pos = 0;
+    for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
+      enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
+        u32 t = B.ops_sorted[S.base[l] + i];
+        OpKey ky = op_key(B, t);
+        u32 o = l * ENC_STRIDE + k;
+        S.t0[o] = ky.kind == 2 ? B.chg_actor_map[S.mapb[l] + ky.actor] : AMH_NULL32;
+        S.t1[o] = ky.kind == 0 ? AMH_NULL32 : (ky.kind == 1 ? 0 : ky.ctr);
+        S.t2[o] = ky.str_off;
+        S.t3[o] = ky.kind == 0 ? ky.str_len : AMH_NULL32;
+      });
+      __syncthreads();
+      u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
+      for (u32 i = 0; i < cnt; i++) {
+        u32 ka = S.t0[row + i], kc = S.t1[row + i], kl = S.t3[row + i];
+        if (ka == AMH_NULL32) re_null(wa, ea); else { x.v = ka; re_value(wa, ea, x); }
+        if (kc == AMH_NULL32) re_null(wc, ec.r); else de_value(wc, ec, (i64)kc);
+        if (kl == AMH_NULL32) re_null(ws, es);
+        else { RleVal sv; sv.v = 0; sv.s = chunk + S.t2[row + i]; sv.n = kl; re_value(ws, es, sv); }
+      }
+      __syncthreads();
+    }
+    re_finish(wa, ea); re_finish(wc, ec.r); re_finish(ws, es);
+    len_out[2] = wa.pos; len_out[3] = wc.pos; len_out[4] = ws.pos;
+  }
+  // ---- group 3: insert, action, predNum, expand (columns 5, 6, 9, 12) -------------------------
+  {
+    bool ins_last = false, exp_last = false, exp_any = false;
+    u64 ins_cnt = 0, exp_cnt = 0;
+    RleEnc<0> eact, epn; re_init(eact); re_init(epn);
+    ColWriter wi, wact, wpn, wex; wi.out = col_out[5]; wi.pos = 0; wact.out = col_out[6]; wact.pos = 0;
+    wpn.out = col_out[9]; wpn.pos = 0; wex.out = col_out[12]; wex.pos = 0;
+    for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
+      enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
+        u32 t = B.ops_sorted[S.base[l] + i];
+        bool del = op_is_del(B, t);
+        u32 action = del ? 3 : B.r_action[t];
+        u32 ins = del ? 0 : (B.r_insert[t] != 0);
+        u32 ex = (!del && action == 7 && B.r_expand[t]) ? 1 : 0;
+        S.t0[l * ENC_STRIDE + k] = ins | (ex << 1) | (action << 8);
+        S.t1[l * ENC_STRIDE + k] = B.t_pred_cnt[t];
+      });
+      __syncthreads();
+      u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
+      for (u32 i = 0; i < cnt; i++) {
+        u32 f = S.t0[row + i];
+        bool_feed(wi, ins_last, ins_cnt, (f & 1) != 0);
+        x.v = f >> 8; re_value(wact, eact, x);
+        x.v = S.t1[row + i]; re_value(wpn, epn, x);
+        bool ex = (f & 2) != 0;
+        exp_any = exp_any || ex;
+        bool_feed(wex, exp_last, exp_cnt, ex);
+      }
+      __syncthreads();
+    }
+    if (ins_cnt > 0) cw_uleb(wi, ins_cnt);
+    re_finish(wact, eact); re_finish(wpn, epn);
+    if (exp_any && exp_cnt > 0) cw_uleb(wex, exp_cnt);   // MaybeBoolean: nothing unless a true was appended (boolean.rs:131-137)
+    len_out[5] = wi.pos; len_out[6] = wact.pos; len_out[9] = wpn.pos; len_out[12] = exp_any ? wex.pos : 0;
+  }
+  // ---- group 4: value (columns 7, 8; value.rs:320-369, op_as_changeop.rs:94-103) --------------
+  {
+    RleEnc<0> em; re_init(em);
+    ColWriter wm, wr; wm.out = col_out[7]; wm.pos = 0; wr.out = col_out[8]; wr.pos = 0;
+    for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
+      enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
+        u32 t = B.ops_sorted[S.base[l] + i];
+        OpVal v = op_val(B, t);
+        u32 o = l * ENC_STRIDE + k;
+        S.t0[o] = (u32)v.meta;
+        S.t1[o] = (u32)(v.meta >> 32) | ((u32)v.kind << 8);
+        if (v.kind == 2) { S.t2[o] = (u32)(u64)v.i; S.t3[o] = (u32)((u64)v.i >> 32); }
+        else { S.t2[o] = v.kind == 1 && v.raw_len ? B.desc[B.r_doc[t]].ocol[OC_VAL_RAW].off + B.r_vraw_off[t] : 0; S.t3[o] = v.raw_len; }
+      });
+      __syncthreads();
+      u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
+      for (u32 i = 0; i < cnt; i++) {
+        u32 hi = S.t1[row + i], kind = hi >> 8;
+        x.v = (u64)S.t0[row + i] | ((u64)(hi & 0xFF) << 32);
+        re_value(wm, em, x);
+        if (kind == 1) cw_bytes(wr, chunk + S.t2[row + i], S.t3[row + i]);
+        else if (kind == 2) cw_sleb(wr, (i64)((u64)S.t2[row + i] | ((u64)S.t3[row + i] << 32)));
+      }
+      __syncthreads();
+    }
+    re_finish(wm, em);
+    len_out[7] = wm.pos; len_out[8] = wr.pos;
+  }
+  // ---- group 5: flattened pred lists (columns 10, 11; opid_list.rs:52-78) ---------------------
+  {
+    RleEnc<0> ea; re_init(ea);
+    DeltaEnc ec; re_init(ec.r); ec.abs = 0;
+    ColWriter wa, wc; wa.out = col_out[10]; wa.pos = 0; wc.out = col_out[11]; wc.pos = 0;
+    const u32 p_max = wave_max_u32(pn);
+    for (u32 t0 = 0; t0 < p_max; t0 += ENC_K) {
+      enc_load_tile(S.pn, t0, [&](u32 l, u32 k, u32 i) {
+        u64 id = B.pred_ids[S.pbase[l] + i];
+        S.t0[l * ENC_STRIDE + k] = B.chg_actor_map[S.mapb[l] + (u32)id];
+        S.t1[l * ENC_STRIDE + k] = (u32)(id >> 32);
+      });
+      __syncthreads();
+      u32 cnt = pn > t0 ? (pn - t0 < ENC_K ? pn - t0 : ENC_K) : 0;
+      for (u32 i = 0; i < cnt; i++) {
+        x.v = S.t0[row + i]; re_value(wa, ea, x);
+        de_value(wc, ec, (i64)S.t1[row + i]);
+      }
+      __syncthreads();
+    }
+    re_finish(wa, ea); re_finish(wc, ec.r);
+    len_out[10] = wa.pos; len_out[11] = wc.pos;
+  }
+  // ---- group 6: mark names (column 13) — only when a document of this wave has a mark column ---
+  {
+    bool has_marks = live && B.desc[d].ocol[OC_MARK_NAME].len != 0;
+    if (__ballot(has_marks)) {
+      RleEnc<2> es; re_init(es);
+      ColWriter ws; ws.out = col_out[13]; ws.pos = 0;
+      for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
+        enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
+          u32 t = B.ops_sorted[S.base[l] + i];
+          bool m = !op_is_del(B, t) && B.r_action[t] == 7 && B.r_mark_len[t] != AMH_NULL32;
+          S.t0[l * ENC_STRIDE + k] = m ? B.r_mark_off[t] : 0;
+          S.t1[l * ENC_STRIDE + k] = m ? B.r_mark_len[t] : AMH_NULL32;
+        });
+        __syncthreads();
+        u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
+        for (u32 i = 0; i < cnt; i++) {
+          u32 ml = S.t1[row + i];
+          if (ml == AMH_NULL32) re_null(ws, es);
+          else { RleVal sv; sv.v = 0; sv.s = chunk + S.t0[row + i]; sv.n = ml; re_value(ws, es, sv); }
+        }
+        __syncthreads();
+      }
+      re_finish(ws, es);
+      len_out[13] = ws.pos;
+    }
+  }
+  if (!STORE && c < B.tot_chg) {
+#pragma unroll
+    for (int k = 0; k < AMH_NCOLS; k++) cl[k] = live ? len_out[k] : 0;
+  }
+  (void)raw_col;
+}
+
 void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
   if (n == 0) return;
   hipStream_t s = (hipStream_t)stream;
+  if (k == AK_ENCODE_SIZE) { hipLaunchKernelGGL((g_encode_lds<false>), dim3((B.tot_chg + 63) / 64), dim3(64), 0, s, B); return; }
+  if (k == AK_ENCODE_STORE) { hipLaunchKernelGGL((g_encode_lds<true>), dim3((B.tot_chg + 63) / 64), dim3(64), 0, s, B); return; }
   dim3 grid((n + AMH_BLOCK - 1) / AMH_BLOCK), block(AMH_BLOCK);
 #define L(id, name) case id: hipLaunchKernelGGL(g_##name, grid, block, 0, s, B, n); break;
   switch (k) {
     L(AK_PARSE, k_parse) L(AK_SHA_DOC, k_sha_doc) L(AK_COUNT, k_count) L(AK_EXTRACT, k_extract)
     L(AK_ACTORS, k_actors) L(AK_CHG_INIT, k_chg_init) L(AK_DECODE_CHG, k_decode_chg)
     L(AK_DECODE_OPS, k_decode_ops) L(AK_ROWS, k_rows) L(AK_OBJ_ORDER, k_obj_order) L(AK_SUCC, k_succ)
-    L(AK_BUCKET, k_bucket) L(AK_CHG_FINISH, k_chg_finish) L(AK_PLACE, k_place) L(AK_PRED_FILL, k_pred_fill)
+    L(AK_BUCKET, k_bucket) L(AK_CHG_FINISH, k_chg_finish) L(AK_PLACE, k_place) L(AK_PRED_SLOT_CNT, k_pred_slot_cnt) L(AK_PRED_SLOT_BASE, k_pred_slot_base) L(AK_PRED_FILL, k_pred_fill)
     L(AK_PRED_SORT, k_pred_sort) L(AK_ACTOR_MARK, k_actor_mark) L(AK_ACTOR_RANK, k_actor_rank)
     L(AK_ENCODE_SIZE, k_encode_size) L(AK_CHG_LAYOUT, k_chg_layout) L(AK_ENCODE_STORE, k_encode_store)
     L(AK_ASSEMBLE_HASH, k_assemble_hash) L(AK_VISIBLE, k_visible)

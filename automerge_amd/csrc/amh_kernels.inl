@@ -482,15 +482,30 @@ AMH_DEV void k_decode_chg(const BatchDev& B, u32 d) {
 //     (meta only).  Thread per (document, column stream); each stream expands its runs into the
 //     column array of the batch-wide SoA.  Null / exhausted = AMH_NULL32.
 // ------------------------------------------------------------------------------------------
-AMH_DEV void k_decode_ops(const BatchDev& B, u32 gid) {
-  u32 d = gid / OC_COUNT, col = gid % OC_COUNT;
-  if (d >= B.n_docs || B.status[d]) return;
+// byte range of the op columns inside the chunk, and the staging class of the document:
+// 0 = fits the 16 KB LDS image, 1 = fits the 64 KB image, 2 = decoded straight from HBM
+#define AMH_LDS_CLASS0 16384u
+#define AMH_LDS_CLASS1 65536u
+AMH_DEV u32 op_col_region(const DocDesc& D, u32& lo, u32& hi) {
+  lo = 0xFFFFFFFFu; hi = 0;
+  for (int i = 0; i < OC_COUNT; i++) {
+    if (D.ocol[i].len == 0) continue;
+    if (D.ocol[i].off < lo) lo = D.ocol[i].off;
+    if (D.ocol[i].off + D.ocol[i].len > hi) hi = D.ocol[i].off + D.ocol[i].len;
+  }
+  if (hi == 0) { lo = 0; return 0; }
+  u32 span = hi - (lo & ~15u);
+  return span <= AMH_LDS_CLASS0 ? 0 : (span <= AMH_LDS_CLASS1 ? 1 : 2);
+}
+
+// one column stream of one document.  `p` addresses the chunk bytes shifted by `bias`: p[x - bias] is
+// chunk byte x (bias = 0: the arena itself; otherwise an LDS image of the op-column region).
+AMH_DEV void decode_ops_stream(const BatchDev& B, u32 d, u32 col, const u8* p, u32 bias) {
   const DocDesc& D = B.desc[d];
   const DocCounts& C = B.cnt[d];
   if (C.n_rows == 0) return;
-  const u8* p = B.arena + D.chunk_off;
   u32 rb = B.row_base[d], n = C.n_rows;
-  u32 off = D.ocol[col].off, len = D.ocol[col].len;
+  u32 len = D.ocol[col].len, off = len ? D.ocol[col].off - bias : 0;
   u64 v; u32 aux; bool isnull; i64 sv;
   switch (col) {
     case OC_OBJ_ACTOR: case OC_OBJ_CTR: case OC_KEY_ACTOR: case OC_ID_ACTOR: case OC_ACTION: {
@@ -516,13 +531,16 @@ AMH_DEV void k_decode_ops(const BatchDev& B, u32 gid) {
       DeltaDec r;
       delta_init(r, p, off, len);
       u32* out32 = col == OC_KEY_CTR ? B.r_key_ctr : B.r_id_ctr;
+      u32 mx = 0;
       for (u32 i = 0; i < n; i++) {
         int rc = delta_next(r, sv, isnull);
         if (rc < 0) { amh_fail(B, d, AMH_E_READ_OP); return; }
         bool none = rc == 1 || isnull;
         if (!none && (sv < 0 || sv >= 0xFFFFFFFFll)) { amh_fail(B, d, AMH_E_READ_OP); return; }  // key.rs:172-179, opid.rs:107-113
         out32[rb + i] = none ? AMH_NULL32 : (u32)sv;
+        if (col == OC_ID_CTR) { B.r_doc[rb + i] = d; if (!none && (u32)sv > mx) mx = (u32)sv; }
       }
+      if (col == OC_ID_CTR) amh_atomic_max(&B.doc_max_op[d], mx);  // max_op over op ids (reconstruct_document.rs:136-140)
       break;
     }
     case OC_KEY_STR: case OC_MARK_NAME: {
@@ -534,7 +552,7 @@ AMH_DEV void k_decode_ops(const BatchDev& B, u32 gid) {
         int rc = rle_next<2>(r, v, aux, isnull);
         if (rc < 0) { amh_fail(B, d, AMH_E_READ_OP); return; }
         bool none = rc == 1 || isnull;
-        o_off[rb + i] = none ? 0 : (u32)v;
+        o_off[rb + i] = none ? 0 : (u32)v + bias;
         o_len[rb + i] = none ? AMH_NULL32 : aux;
       }
       break;
@@ -610,17 +628,25 @@ AMH_DEV void k_decode_ops(const BatchDev& B, u32 gid) {
     case OC_SUCC_CTR: {
       DeltaDec r;
       delta_init(r, p, off, len);
-      u32 sb = B.succ_base[d];
+      u32 sb = B.succ_base[d], mx = 0;
       for (u32 i = 0; i < C.n_succ; i++) {
         int rc = delta_next(r, sv, isnull);
         if (rc != 0 || isnull) { amh_fail(B, d, AMH_E_READ_OP); return; }
         if (sv < 0 || sv >= 0xFFFFFFFFll) { amh_fail(B, d, AMH_E_READ_OP); return; }
         B.s_ctr[sb + i] = (u32)sv;
+        if ((u32)sv > mx) mx = (u32)sv;
       }
+      amh_atomic_max(&B.doc_max_op[d], mx);  // ... and over succ ids (reconstruct_document.rs:141-143)
       break;
     }
     default: break;  // OC_VAL_RAW has no stream of its own
   }
+}
+AMH_DEV void k_decode_ops(const BatchDev& B, u32 gid) {
+  // column-major: the 64 lanes of a wave decode the same column of 64 documents (no switch divergence)
+  u32 col = gid / B.n_docs, d = gid % B.n_docs;
+  if (col >= OC_COUNT || B.status[d]) return;
+  decode_ops_stream(B, d, col, B.arena + B.desc[d].chunk_off, 0);
 }
 
 // parse the payload of an int-like value (types 3,4,8,9) strictly; false = malformed
@@ -655,18 +681,17 @@ AMH_DEV u32 find_doc(const u32* base, u32 n_docs, u32 idx) {  // largest d with 
 //     Thread per row.
 // ------------------------------------------------------------------------------------------
 AMH_DEV void k_rows(const BatchDev& B, u32 r) {
-  u32 d = find_doc(B.row_base, B.n_docs, r);
-  B.r_doc[r] = d;
+  u32 d = B.r_doc[r];   // written by the id-counter stream of k_decode_ops; AMH_NULL32 when that document failed earlier
   B.t_pred_cnt[r] = 0;
   B.r_inc_cnt[r] = 0;
   B.r_inc_sum[r] = 0;
+  if (d == AMH_NULL32) { B.r_doc[r] = find_doc(B.row_base, B.n_docs, r); return; }
   if (B.status[d]) return;
   const DocDesc& D = B.desc[d];
   u32 na = D.n_actors;
   u32 ia = B.r_id_actor[r], ic = B.r_id_ctr[r];
   if (ia == AMH_NULL32 || ic == AMH_NULL32) { amh_fail(B, d, AMH_E_READ_OP); return; }
   if (ia >= na) { amh_fail(B, d, AMH_E_MISSING_ACTOR); return; }
-  amh_atomic_max(&B.doc_max_op[d], ic);
   // object id
   u32 oa = B.r_obj_actor[r], oc = B.r_obj_ctr[r];
   if (D.ocol[OC_OBJ_ACTOR].len == 0 && D.ocol[OC_OBJ_CTR].len == 0) { oa = 0; oc = 0; }
@@ -763,7 +788,6 @@ AMH_DEV void k_succ(const BatchDev& B, u32 e) {
   if (B.status[d]) return;
   u32 sa = B.s_actor[e], sc = B.s_ctr[e];
   if (sa >= B.desc[d].n_actors) { amh_fail(B, d, AMH_E_MISSING_ACTOR); return; }
-  amh_atomic_max(&B.doc_max_op[d], sc);
   if (e > B.r_succ_base[r]) {
     u32 pa = B.s_actor[e - 1], pc = B.s_ctr[e - 1];
     if (pa >= B.desc[d].n_actors) return;  // flagged by that entry's own thread
@@ -855,6 +879,17 @@ AMH_DEV void k_place(const BatchDev& B, u32 t) {
   if (ctr < start || ctr - start >= B.c_nops[c]) { amh_fail(B, d, AMH_E_UNSUPPORTED); return; }
   u32 slot = B.c_op_base[c] + (u32)(ctr - start);
   if (amh_atomic_cas(&B.ops_sorted[slot], AMH_EMPTY32, t) != AMH_EMPTY32) amh_fail(B, d, AMH_E_UNSUPPORTED);
+}
+
+// K11b  pred lists are laid out in change order (slot order of ops_sorted), so that the flattened pred
+//       list of a change (opid_list.rs:52-78) is one contiguous run of pred_ids.  Thread per slot.
+AMH_DEV void k_pred_slot_cnt(const BatchDev& B, u32 j) {
+  u32 t = B.ops_sorted[j];
+  B.j_pred_base[j] = t == AMH_EMPTY32 ? 0 : B.t_pred_cnt[t];
+}
+AMH_DEV void k_pred_slot_base(const BatchDev& B, u32 j) {
+  u32 t = B.ops_sorted[j];
+  if (t != AMH_EMPTY32) B.t_pred_base[t] = B.j_pred_base[j];
 }
 
 // K12  pred lists: scatter each succ edge to its target, then order each list by lamport id
@@ -1188,8 +1223,8 @@ AMH_DEV u32 chg_spec(u32 col) {
 }
 
 AMH_DEV void k_encode_size(const BatchDev& B, u32 gid) {
-  u32 c = gid / AMH_NCOLS, col = gid % AMH_NCOLS;
-  if (c >= B.tot_chg) return;
+  u32 col = gid / B.tot_chg, c = gid % B.tot_chg;   // column-major: a wave encodes one column of 64 changes
+  if (col >= AMH_NCOLS) return;
   B.c_col_len[(u64)c * AMH_NCOLS + col] = 0;
   if (B.status[B.c_doc[c]]) return;
   B.c_col_len[(u64)c * AMH_NCOLS + col] = encode_change_col(B, c, col, (u8*)0);
@@ -1232,8 +1267,8 @@ AMH_DEV void k_chg_layout(const BatchDev& B, u32 c) {
 }
 
 AMH_DEV void k_encode_store(const BatchDev& B, u32 gid) {
-  u32 c = gid / AMH_NCOLS, col = gid % AMH_NCOLS;
-  if (c >= B.tot_chg) return;
+  u32 col = gid / B.tot_chg, c = gid % B.tot_chg;
+  if (col >= AMH_NCOLS) return;
   if (B.status[B.c_doc[c]]) return;
   const u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
   if (cl[col] == 0) return;

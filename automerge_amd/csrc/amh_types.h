@@ -143,5 +143,6 @@ struct BatchDev {
   u32 *t_pred_cnt, *t_pred_base, *t_pred_fill, *t_chg;
   u64* pred_ids;                 // [tot_succ] (ctr << 32 | actor)
   u32* ops_sorted;               // [tot_ops] ops grouped by change in id order
+  u32* j_pred_base;              // [tot_ops + 1] base of each slot's pred list in pred_ids (change order)
   u8* out_arena;                 // re-derived change chunks
 };

@@ -44,6 +44,8 @@ def algorithmic_bytes(st, cols):
         "bucket": (8 + 4) * T,                               # SURVEY 8d change bucketing
         "chg_finish": 24 * C,
         "place": 8 * T,
+        "pred_slot_cnt": 12 * T,
+        "pred_slot_base": 12 * T,
         "pred_fill": 12 * S,
         "pred_sort": 16 * S,
         "actor_mark": 12 * T,
