@@ -197,7 +197,8 @@ AMH_DEV int amh_memcmp(const u8* a, u32 an, const u8* b, u32 bn) {
 // next(): 0 = value produced, 1 = exhausted, -1 = malformed
 // ---------------------------------------------------------------------------------------------
 struct RleDec {
-  const u8* p;
+  const u8* p;    // where the LEB headers / values are read: the arena, or an LDS window over it
+  const u8* gp;   // the arena itself (string payloads are validated there)
   u64 pos, end;
   i64 count;
   u64 last;
@@ -206,7 +207,7 @@ struct RleDec {
   bool literal;
 };
 AMH_DEV void rle_init(RleDec& d, const u8* p, u64 off, u64 len) {
-  d.p = p; d.pos = off; d.end = off + len; d.count = 0; d.last = 0; d.last_aux = 0; d.last_null = true; d.literal = false;
+  d.p = p; d.gp = p; d.pos = off; d.end = off + len; d.count = 0; d.last = 0; d.last_aux = 0; d.last_null = true; d.literal = false;
 }
 AMH_DEV bool rle_done(const RleDec& d) { return d.pos >= d.end && d.count == 0; }
 template <int KIND>
@@ -216,7 +217,7 @@ AMH_DEV bool rle_read_value(RleDec& d, u64& v, u32& aux) {
   u64 len;
   if (!rd_uleb_lenient(d.p, d.pos, d.end, len)) return false;
   if (len > d.end - d.pos) return false;
-  if (!amh_valid_utf8(d.p + d.pos, len)) return false;
+  if (!amh_valid_utf8(d.gp + d.pos, len)) return false;
   v = d.pos;
   aux = (u32)len;
   d.pos += len;

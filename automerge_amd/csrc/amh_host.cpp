@@ -215,7 +215,7 @@ extern "C" amh_staged* amh_stage_batch(amh_ctx* ctx, const uint8_t* const* docs,
     off = (off + 15) & ~(u64)15;  // 16-byte aligned chunk starts: wide loads in the streaming kernels
   }
   st->h_doc_off[n] = off;
-  st->h_arena.assign(off + 64, 0);
+  st->h_arena.assign(off + 256, 0);  // tail padding: the staged decoders read whole windows
   {
     std::vector<std::thread> ts;
     for (unsigned t = 0; t < nthreads; t++)
@@ -374,6 +374,9 @@ extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, cons
   launch(ctx, AK_PRED_SORT, B, T);
   launch(ctx, AK_ACTOR_MARK, B, T);
   launch(ctx, AK_ACTOR_RANK, B, B.tot_chg);
+  for (int k = 0; k < 12; k++) B.cv[k] = balloc<u32>(b, (size_t)tot_ops + 1, &ok);
+  if (!ok) return fail("device out of memory");
+  launch(ctx, AK_CHANGE_VIEW, B, tot_ops);
   launch(ctx, AK_ENCODE_SIZE, B, B.tot_chg * AMH_NCOLS);
   launch(ctx, AK_CHG_LAYOUT, B, B.tot_chg);
 #ifdef AMH_EMU
@@ -777,6 +780,10 @@ extern "C" int amh_debug_array(const amh_batch* b, const char* name, void* out, 
     {"s_target", B.s_target, NS * 4}, {"t_pred_cnt", B.t_pred_cnt, T * 4}, {"t_pred_base", B.t_pred_base, (T + 1) * 4},
     {"t_chg", B.t_chg, T * 4}, {"j_pred_base", B.j_pred_base, ((size_t)B.tot_ops + 1) * 4}, {"pred_ids", B.pred_ids, NS * 8}, {"ops_sorted", B.ops_sorted, (size_t)B.tot_ops * 4},
     {"out_arena", B.out_arena, (size_t)b->tot_out},
+    {"cv0", B.cv[0], (size_t)B.tot_ops * 4}, {"cv1", B.cv[1], (size_t)B.tot_ops * 4}, {"cv2", B.cv[2], (size_t)B.tot_ops * 4},
+    {"cv3", B.cv[3], (size_t)B.tot_ops * 4}, {"cv4", B.cv[4], (size_t)B.tot_ops * 4}, {"cv5", B.cv[5], (size_t)B.tot_ops * 4},
+    {"cv6", B.cv[6], (size_t)B.tot_ops * 4}, {"cv7", B.cv[7], (size_t)B.tot_ops * 4}, {"cv8", B.cv[8], (size_t)B.tot_ops * 4},
+    {"cv9", B.cv[9], (size_t)B.tot_ops * 4}, {"cv10", B.cv[10], (size_t)B.tot_ops * 4}, {"cv11", B.cv[11], (size_t)B.tot_ops * 4},
   };
   for (const Ent& e : tab) {
     if (strcmp(e.name, name) != 0) continue;

@@ -33,11 +33,179 @@ AMH_GLOBAL(k_pred_fill)
 AMH_GLOBAL(k_pred_sort)
 AMH_GLOBAL(k_actor_mark)
 AMH_GLOBAL(k_actor_rank)
+AMH_GLOBAL(k_change_view)
 AMH_GLOBAL(k_encode_size)
 AMH_GLOBAL(k_chg_layout)
 AMH_GLOBAL(k_encode_store)
 AMH_GLOBAL(k_assemble_hash)
 AMH_GLOBAL(k_visible)
+
+// ------------------------------------------------------------------------------------------
+// Op-column decode, LDS-staged (device form of k_decode_ops; the stream decoders are the same
+// functions).  One wave = one column of 64 consecutive documents, lane = document, so the whole wave
+// runs one decoder.  Each lane reads its column through a DEC_W-byte window in LDS; windows are
+// refilled cooperatively with 4-byte coalesced loads whenever some lane is about to run out.  Decoded
+// values are collected DEC_K rows at a time in LDS and written back cooperatively, 64 contiguous
+// bytes per document per store, instead of one 4-byte store per lane per row.
+// ------------------------------------------------------------------------------------------
+#define DEC_W 64u          // window bytes per lane
+#define DEC_NEED 24u       // a decode step reads at most two LEB128 numbers past pos
+#define DEC_K 16u          // rows buffered per lane between write-backs
+#define DEC_KS (DEC_K + 1)
+
+struct DecShared {
+  u32 win[64][DEC_W / 4 + 1];
+  u32 o0[64 * DEC_KS], o1[64 * DEC_KS], o2[64 * DEC_KS];
+  u64 src[64];     // arena byte address of each lane's window
+  u32 rb[64], cnt[64];
+};
+
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+  for (int off = 32; off > 0; off >>= 1) { u32 o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+  return v;
+}
+__device__ __forceinline__ u32 obase_succ(const BatchDev& B, u32 d) { return B.succ_base[d]; }
+
+template <u32 COL>
+__global__ void __launch_bounds__(64) g_decode_col(BatchDev B) {
+  __shared__ DecShared S;
+  constexpr bool SUCC_ENTRY = COL == OC_SUCC_ACTOR || COL == OC_SUCC_CTR;
+  constexpr bool IS_DELTA = COL == OC_KEY_CTR || COL == OC_ID_CTR || COL == OC_SUCC_CTR;
+  constexpr bool IS_STR = COL == OC_KEY_STR || COL == OC_MARK_NAME;
+  constexpr bool IS_BOOL = COL == OC_INSERT || COL == OC_EXPAND;
+  const u32 lane = threadIdx.x;
+  const u32 d = blockIdx.x * 64 + lane;
+  bool live = d < B.n_docs && B.status[d] == 0;
+  const u32 dd = d < B.n_docs ? d : 0;
+  const DocDesc& D = B.desc[dd];
+  const u32 cnt = live ? (SUCC_ENTRY ? B.cnt[dd].n_succ : B.cnt[dd].n_rows) : 0;
+  const u32 obase = SUCC_ENTRY ? B.succ_base[dd] : B.row_base[dd];
+  const u8* chunk = B.arena + D.chunk_off;
+  const u32 off = D.ocol[COL].off, len = D.ocol[COL].len;
+  S.rb[lane] = obase;
+  S.cnt[lane] = cnt;
+  const u32 cnt_max = wave_max_u32(cnt);
+  if (cnt_max == 0) return;
+  if (COL == OC_EXPAND && !__ballot(cnt != 0 && len != 0)) {   // no expand column anywhere in this wave: all false
+    for (u32 i = 0; i < cnt; i++) B.r_expand[obase + i] = 0;   // (rare; only mark-free documents take this path)
+    return;
+  }
+  // decoder state
+  RleDec r; DeltaDec dl; BoolDec bd;
+  u32 wbase = off & ~3u;
+  const u8* wp = (const u8*)S.win[lane];
+  rle_init(r, wp - wbase, off, len); r.gp = chunk;
+  delta_init(dl, wp - wbase, off, len);
+  bool_init(bd, wp - wbase, off, len);
+  u64 raw_off = 0; const u64 raw_len = D.ocol[OC_VAL_RAW].len;   // VAL_META
+  u32 succ_run = 0;                                               // SUCC_NUM
+  u32 mx = 0;                                                     // ID_CTR / SUCC_CTR
+  bool failed = false;
+  i32 fail_code = 0;
+  bool first = true;
+  for (u32 i = 0; i < cnt_max; i++) {
+    // ---- window refill --------------------------------------------------------------------
+    u64 pos = IS_DELTA ? dl.r.pos : (IS_BOOL ? bd.pos : r.pos);
+    bool need = first || (live && !failed && i < cnt && pos + DEC_NEED > (u64)wbase + DEC_W && (u64)wbase + DEC_W < (u64)off + len);
+    if (__ballot(need)) {
+      first = false;
+      u32 nb = (pos > (u64)off + len ? off + len : (u32)pos) & ~3u;
+      wbase = nb;
+      S.src[lane] = D.chunk_off + nb;
+      __syncthreads();
+#pragma unroll 4
+      for (u32 l0 = 0; l0 < 64; l0 += 64 / (DEC_W / 4)) {
+        u32 l = l0 + lane / (DEC_W / 4), k = lane % (DEC_W / 4);
+        S.win[l][k] = *(const u32*)(B.arena + S.src[l] + 4 * k);   // the arena is padded: reading past a column is harmless
+      }
+      __syncthreads();
+      const u8* np = wp - wbase;
+      r.p = np; dl.r.p = np; bd.p = np;
+    }
+    // ---- one row per lane -------------------------------------------------------------------
+    if (i < cnt && !failed) {
+      u64 v = 0; u32 aux = 0; bool isnull = false; i64 sv = 0;
+      u32 slot = lane * DEC_KS + (i % DEC_K);
+      if (IS_DELTA) {
+        int rc = delta_next(dl, sv, isnull);
+        bool none = rc == 1 || isnull;
+        if (rc < 0 || (SUCC_ENTRY && none)) { failed = true; fail_code = AMH_E_READ_OP; }
+        else if (!none && (sv < 0 || sv >= 0xFFFFFFFFll)) { failed = true; fail_code = AMH_E_READ_OP; }
+        else { S.o0[slot] = none ? AMH_NULL32 : (u32)sv; if (!none && (u32)sv > mx) mx = (u32)sv; }
+      } else if (IS_STR) {
+        int rc = rle_next<2>(r, v, aux, isnull);
+        bool none = rc == 1 || isnull;
+        if (rc < 0) { failed = true; fail_code = AMH_E_READ_OP; }
+        else { S.o0[slot] = none ? 0 : (u32)v; S.o1[slot] = none ? AMH_NULL32 : aux; }
+      } else if (IS_BOOL) {
+        bool b = false;
+        int rc = len ? bool_next(bd, b) : 1;
+        if (COL == OC_INSERT ? rc != 0 : rc < 0) { failed = true; fail_code = AMH_E_READ_OP; }
+        else S.o0[slot] = (rc == 0 && b) ? 1 : 0;
+      } else if (COL == OC_VAL_META) {
+        int rc = rle_next<0>(r, v, aux, isnull);
+        if (rc != 0 || isnull) { failed = true; fail_code = AMH_E_READ_OP; }
+        else {
+          S.o0[slot] = (u32)v; S.o1[slot] = (u32)(v >> 32); S.o2[slot] = (u32)raw_off;
+          if ((v & 15) >= 3) {
+            u64 l = v >> 4;
+            if (l > raw_len || raw_off > raw_len - l) { failed = true; fail_code = AMH_E_READ_OP; }
+            raw_off += l;
+          }
+        }
+      } else if (COL == OC_SUCC_NUM) {
+        int rc = rle_next<0>(r, v, aux, isnull);
+        if (rc != 0 || isnull) { failed = true; fail_code = AMH_E_READ_OP; }
+        else { S.o0[slot] = (u32)v; S.o1[slot] = obase_succ(B, dd) + succ_run; succ_run += (u32)v; }
+      } else {  // plain RLE of u64: obj actor / ctr, key actor, id actor, action, succ actor
+        int rc = rle_next<0>(r, v, aux, isnull);
+        bool none = rc == 1 || isnull;
+        if (rc < 0) { failed = true; fail_code = AMH_E_READ_OP; }
+        else if (COL == OC_ACTION) {
+          if (none) { failed = true; fail_code = AMH_E_READ_OP; }
+          else if (v > 7) { failed = true; fail_code = AMH_E_INVALID_OP; }
+          else S.o0[slot] = (u32)v;
+        } else if (COL == OC_SUCC_ACTOR) {
+          if (none) { failed = true; fail_code = AMH_E_READ_OP; }
+          else if (v >= 0xFFFFFFFFull) { failed = true; fail_code = AMH_E_MISSING_ACTOR; }
+          else S.o0[slot] = (u32)v;
+        } else {
+          if (!none && v >= 0xFFFFFFFFull) { failed = true; fail_code = COL == OC_OBJ_CTR ? AMH_E_READ_OP : AMH_E_MISSING_ACTOR; }
+          else S.o0[slot] = none ? AMH_NULL32 : (u32)v;
+        }
+      }
+      if (failed) { amh_fail(B, dd, fail_code); S.cnt[lane] = i; }   // rows from i on are never written back
+    }
+    // ---- write-back every DEC_K rows ---------------------------------------------------------
+    if ((i % DEC_K) == DEC_K - 1 || i + 1 == cnt_max) {
+      u32 i0 = i - (i % DEC_K);
+      __syncthreads();
+#pragma unroll 4
+      for (u32 l0 = 0; l0 < 64; l0 += 64 / DEC_K) {
+        u32 l = l0 + lane / DEC_K, k = lane % DEC_K;
+        if (i0 + k >= S.cnt[l]) continue;
+        u32 o = S.rb[l] + i0 + k, sl = l * DEC_KS + k;
+        if (COL == OC_OBJ_ACTOR) B.r_obj_actor[o] = S.o0[sl];
+        else if (COL == OC_OBJ_CTR) B.r_obj_ctr[o] = S.o0[sl];
+        else if (COL == OC_KEY_ACTOR) B.r_key_actor[o] = S.o0[sl];
+        else if (COL == OC_KEY_CTR) B.r_key_ctr[o] = S.o0[sl];
+        else if (COL == OC_KEY_STR) { B.r_key_off[o] = S.o0[sl]; B.r_key_len[o] = S.o1[sl]; }
+        else if (COL == OC_ID_ACTOR) B.r_id_actor[o] = S.o0[sl];
+        else if (COL == OC_ID_CTR) { B.r_id_ctr[o] = S.o0[sl]; B.r_doc[o] = blockIdx.x * 64 + l; }
+        else if (COL == OC_INSERT) B.r_insert[o] = (u8)S.o0[sl];
+        else if (COL == OC_ACTION) B.r_action[o] = (u8)S.o0[sl];
+        else if (COL == OC_VAL_META) { B.r_vmeta[o] = (u64)S.o0[sl] | ((u64)S.o1[sl] << 32); B.r_vraw_off[o] = S.o2[sl]; }
+        else if (COL == OC_SUCC_NUM) { B.r_succ_cnt[o] = S.o0[sl]; B.r_succ_base[o] = S.o1[sl]; }
+        else if (COL == OC_SUCC_ACTOR) B.s_actor[o] = S.o0[sl];
+        else if (COL == OC_SUCC_CTR) B.s_ctr[o] = S.o0[sl];
+        else if (COL == OC_EXPAND) B.r_expand[o] = (u8)S.o0[sl];
+        else if (COL == OC_MARK_NAME) { B.r_mark_off[o] = S.o0[sl]; B.r_mark_len[o] = S.o1[sl]; }
+      }
+      __syncthreads();
+    }
+  }
+  if ((COL == OC_ID_CTR || COL == OC_SUCC_CTR) && live && !failed && cnt) amh_atomic_max(&B.doc_max_op[dd], mx);
+}
 
 // ------------------------------------------------------------------------------------------
 // Change re-encode, LDS-staged (replaces the thread-per-(change, column) kernels k_encode_size /
@@ -51,7 +219,9 @@ AMH_GLOBAL(k_visible)
 // padded to an odd stride so that the 64 lanes walk 64 different banks.
 // STORE = false: column sizes -> c_col_len;  STORE = true: bytes -> out_arena.
 // ------------------------------------------------------------------------------------------
-#define ENC_K 32
+#ifndef ENC_K
+#define ENC_K 8
+#endif
 #define ENC_STRIDE (ENC_K + 1)
 #define ENC_TILE (64 * ENC_STRIDE)
 
@@ -62,14 +232,11 @@ struct EncShared {
 
 template <class F>
 __device__ __forceinline__ void enc_load_tile(const u32* cnt, u32 t0, F f) {
+#pragma unroll 8
   for (u32 l0 = 0; l0 < 64; l0 += 64 / ENC_K) {
     u32 l = l0 + threadIdx.x / ENC_K, k = threadIdx.x % ENC_K;
     if (t0 + k < cnt[l]) f(l, k, t0 + k);
   }
-}
-__device__ __forceinline__ u32 wave_max_u32(u32 v) {
-  for (int off = 32; off > 0; off >>= 1) { u32 o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
-  return v;
 }
 __device__ __forceinline__ void bool_feed(ColWriter& w, bool& last, u64& cnt, bool v) {  // boolean.rs:35-50
   if (v == last) cnt++; else { cw_uleb(w, cnt); last = v; cnt = 1; }
@@ -118,11 +285,9 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
     ColWriter wa, wc; wa.out = col_out[0]; wa.pos = 0; wc.out = col_out[1]; wc.pos = 0;
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
-        u32 t = B.ops_sorted[S.base[l] + i];
-        u32 kr = op_key_row(B, t);
-        u32 oc = B.r_obj_ctr[kr];
-        S.t0[l * ENC_STRIDE + k] = oc ? B.chg_actor_map[S.mapb[l] + B.r_obj_actor[kr]] : AMH_NULL32;
-        S.t1[l * ENC_STRIDE + k] = oc;
+        u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
+        S.t0[o] = B.cv[0][j];
+        S.t1[o] = B.cv[1][j];
       });
       __syncthreads();
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
@@ -144,13 +309,11 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
     ColWriter wa, wc, ws; wa.out = col_out[2]; wa.pos = 0; wc.out = col_out[3]; wc.pos = 0; ws.out = col_out[4]; ws.pos = 0;
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
-        u32 t = B.ops_sorted[S.base[l] + i];
-        OpKey ky = op_key(B, t);
-        u32 o = l * ENC_STRIDE + k;
-        S.t0[o] = ky.kind == 2 ? B.chg_actor_map[S.mapb[l] + ky.actor] : AMH_NULL32;
-        S.t1[o] = ky.kind == 0 ? AMH_NULL32 : (ky.kind == 1 ? 0 : ky.ctr);
-        S.t2[o] = ky.str_off;
-        S.t3[o] = ky.kind == 0 ? ky.str_len : AMH_NULL32;
+        u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
+        S.t0[o] = B.cv[2][j];
+        S.t1[o] = B.cv[3][j];
+        S.t2[o] = B.cv[4][j];
+        S.t3[o] = B.cv[5][j];
       });
       __syncthreads();
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
@@ -175,13 +338,9 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
     wpn.out = col_out[9]; wpn.pos = 0; wex.out = col_out[12]; wex.pos = 0;
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
-        u32 t = B.ops_sorted[S.base[l] + i];
-        bool del = op_is_del(B, t);
-        u32 action = del ? 3 : B.r_action[t];
-        u32 ins = del ? 0 : (B.r_insert[t] != 0);
-        u32 ex = (!del && action == 7 && B.r_expand[t]) ? 1 : 0;
-        S.t0[l * ENC_STRIDE + k] = ins | (ex << 1) | (action << 8);
-        S.t1[l * ENC_STRIDE + k] = B.t_pred_cnt[t];
+        u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
+        S.t0[o] = B.cv[6][j];
+        S.t1[o] = B.cv[7][j];
       });
       __syncthreads();
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
@@ -207,13 +366,11 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
     ColWriter wm, wr; wm.out = col_out[7]; wm.pos = 0; wr.out = col_out[8]; wr.pos = 0;
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
-        u32 t = B.ops_sorted[S.base[l] + i];
-        OpVal v = op_val(B, t);
-        u32 o = l * ENC_STRIDE + k;
-        S.t0[o] = (u32)v.meta;
-        S.t1[o] = (u32)(v.meta >> 32) | ((u32)v.kind << 8);
-        if (v.kind == 2) { S.t2[o] = (u32)(u64)v.i; S.t3[o] = (u32)((u64)v.i >> 32); }
-        else { S.t2[o] = v.kind == 1 && v.raw_len ? B.desc[B.r_doc[t]].ocol[OC_VAL_RAW].off + B.r_vraw_off[t] : 0; S.t3[o] = v.raw_len; }
+        u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
+        S.t0[o] = B.cv[8][j];
+        S.t1[o] = B.cv[9][j];
+        S.t2[o] = B.cv[10][j];
+        S.t3[o] = B.cv[11][j];
       });
       __syncthreads();
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
@@ -288,6 +445,14 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
 void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
   if (n == 0) return;
   hipStream_t s = (hipStream_t)stream;
+  if (k == AK_DECODE_OPS) {
+    dim3 g((B.n_docs + 63) / 64), b64(64);
+#define DC(col) hipLaunchKernelGGL((g_decode_col<col>), g, b64, 0, s, B);
+    DC(OC_OBJ_ACTOR) DC(OC_OBJ_CTR) DC(OC_KEY_ACTOR) DC(OC_KEY_CTR) DC(OC_KEY_STR) DC(OC_ID_ACTOR) DC(OC_ID_CTR) DC(OC_INSERT)
+    DC(OC_ACTION) DC(OC_VAL_META) DC(OC_SUCC_NUM) DC(OC_SUCC_ACTOR) DC(OC_SUCC_CTR) DC(OC_EXPAND) DC(OC_MARK_NAME)
+#undef DC
+    return;
+  }
   if (k == AK_ENCODE_SIZE) { hipLaunchKernelGGL((g_encode_lds<false>), dim3((B.tot_chg + 63) / 64), dim3(64), 0, s, B); return; }
   if (k == AK_ENCODE_STORE) { hipLaunchKernelGGL((g_encode_lds<true>), dim3((B.tot_chg + 63) / 64), dim3(64), 0, s, B); return; }
   dim3 grid((n + AMH_BLOCK - 1) / AMH_BLOCK), block(AMH_BLOCK);
@@ -297,7 +462,7 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
     L(AK_ACTORS, k_actors) L(AK_CHG_INIT, k_chg_init) L(AK_DECODE_CHG, k_decode_chg)
     L(AK_DECODE_OPS, k_decode_ops) L(AK_ROWS, k_rows) L(AK_OBJ_ORDER, k_obj_order) L(AK_SUCC, k_succ)
     L(AK_BUCKET, k_bucket) L(AK_CHG_FINISH, k_chg_finish) L(AK_PLACE, k_place) L(AK_PRED_SLOT_CNT, k_pred_slot_cnt) L(AK_PRED_SLOT_BASE, k_pred_slot_base) L(AK_PRED_FILL, k_pred_fill)
-    L(AK_PRED_SORT, k_pred_sort) L(AK_ACTOR_MARK, k_actor_mark) L(AK_ACTOR_RANK, k_actor_rank)
+    L(AK_PRED_SORT, k_pred_sort) L(AK_ACTOR_MARK, k_actor_mark) L(AK_ACTOR_RANK, k_actor_rank) L(AK_CHANGE_VIEW, k_change_view)
     L(AK_ENCODE_SIZE, k_encode_size) L(AK_CHG_LAYOUT, k_chg_layout) L(AK_ENCODE_STORE, k_encode_store)
     L(AK_ASSEMBLE_HASH, k_assemble_hash) L(AK_VISIBLE, k_visible)
     default: break;

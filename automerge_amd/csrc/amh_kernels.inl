@@ -607,8 +607,7 @@ AMH_DEV void decode_ops_stream(const BatchDev& B, u32 d, u32 col, const u8* p, u
         int rc = rle_next<0>(r, v, aux, isnull);
         if (rc != 0 || isnull) { amh_fail(B, d, AMH_E_READ_OP); return; }
         B.r_succ_cnt[rb + i] = (u32)v;
-        B.r_succ_base[rb + i] = sb + run;
-        for (u32 k = 0; k < (u32)v; k++) B.s_row[sb + run + k] = rb + i;
+        B.r_succ_base[rb + i] = sb + run;   // the owning row of each entry (s_row) is filled in by k_rows
         run += (u32)v;
       }
       break;
@@ -687,6 +686,10 @@ AMH_DEV void k_rows(const BatchDev& B, u32 r) {
   B.r_inc_sum[r] = 0;
   if (d == AMH_NULL32) { B.r_doc[r] = find_doc(B.row_base, B.n_docs, r); return; }
   if (B.status[d]) return;
+  {  // owning row of each succ entry
+    u32 sc = B.r_succ_cnt[r], sb = B.r_succ_base[r];
+    for (u32 k = 0; k < sc; k++) B.s_row[sb + k] = r;
+  }
   const DocDesc& D = B.desc[d];
   u32 na = D.n_actors;
   u32 ia = B.r_id_actor[r], ic = B.r_id_ctr[r];
@@ -1215,6 +1218,39 @@ AMH_DEV u32 encode_change_col(const BatchDev& B, u32 c, u32 col, u8* out) {
     }
   }
   return w.pos;
+}
+
+// K14b  change view: the fields the column encoders need, gathered once per op into slot order so
+//       that the encoders stream them (op_as_changeop.rs:15-146).  Thread per slot j.
+AMH_DEV void k_change_view(const BatchDev& B, u32 j) {
+  u32 t = B.ops_sorted[j];
+  if (t == AMH_EMPTY32) return;
+  u32 c = B.t_chg[t];
+  if (c == AMH_EMPTY32 || B.status[B.c_doc[c]]) return;
+  const u32* amap = B.chg_actor_map + B.c_map_base[c];
+  u32 kr = op_key_row(B, t);
+  u32 oc = B.r_obj_ctr[kr];
+  B.cv[0][j] = oc ? amap[B.r_obj_actor[kr]] : AMH_NULL32;
+  B.cv[1][j] = oc;
+  OpKey ky = op_key(B, t);
+  B.cv[2][j] = ky.kind == 2 ? amap[ky.actor] : AMH_NULL32;
+  B.cv[3][j] = ky.kind == 0 ? AMH_NULL32 : (ky.kind == 1 ? 0 : ky.ctr);
+  B.cv[4][j] = ky.str_off;
+  B.cv[5][j] = ky.kind == 0 ? ky.str_len : AMH_NULL32;
+  bool del = op_is_del(B, t);
+  u32 action = del ? 3 : B.r_action[t];
+  u32 ins = del ? 0 : (B.r_insert[t] != 0);
+  u32 ex = (!del && action == 7 && B.r_expand[t]) ? 1 : 0;
+  B.cv[6][j] = ins | (ex << 1) | (action << 8);
+  B.cv[7][j] = B.t_pred_cnt[t];
+  OpVal v = op_val(B, t);
+  B.cv[8][j] = (u32)v.meta;
+  B.cv[9][j] = (u32)(v.meta >> 32) | ((u32)v.kind << 8);
+  if (v.kind == 2) { B.cv[10][j] = (u32)(u64)v.i; B.cv[11][j] = (u32)((u64)v.i >> 32); }
+  else {
+    B.cv[10][j] = (v.kind == 1 && v.raw_len) ? B.desc[B.r_doc[t]].ocol[OC_VAL_RAW].off + B.r_vraw_off[t] : 0;
+    B.cv[11][j] = v.raw_len;
+  }
 }
 
 AMH_DEV u32 chg_spec(u32 col) {

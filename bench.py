@@ -50,6 +50,7 @@ def algorithmic_bytes(st, cols):
         "pred_sort": 16 * S,
         "actor_mark": 12 * T,
         "actor_rank": 8 * C + 4 * st["actor_map"],
+        "change_view": 44 * T + 48 * T,
         "encode_size": 44 * T + 56 * C,                      # SURVEY 8d re-encode: 44 + E' (size pass: no E')
         "chg_layout": 100 * C,
         "encode_store": 44 * T + Eout,
