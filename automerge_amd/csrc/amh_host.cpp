@@ -316,7 +316,7 @@ extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, cons
   B.c_nops = balloc<u32>(b, NC, &ok); B.c_start_op = balloc<u64>(b, NC, &ok); B.c_op_base = balloc<u32>(b, NC, &ok);
   B.c_next_same_actor = balloc<u32>(b, NC, &ok); B.c_hash = balloc<u8>(b, NC * 32, &ok);
   B.c_out_off = balloc<u32>(b, NC, &ok); B.c_out_len = balloc<u32>(b, NC, &ok); B.c_body_len = balloc<u32>(b, NC, &ok);
-  B.c_cols_off = balloc<u32>(b, NC, &ok); B.c_col_len = balloc<u32>(b, NC * AMH_NCOLS, &ok);
+  B.c_cols_off = balloc<u32>(b, NC, &ok); B.c_col_len = balloc<u32>(b, NC * AMH_NCOLS, &ok); B.c_wide = balloc<u32>(b, NC, &ok);
   B.c_map_base = balloc<u32>(b, NC, &ok); B.c_n_other = balloc<u32>(b, NC, &ok);
   B.chg_actor_map = balloc<u32>(b, (size_t)b->tot_map + 1, &ok);
   u32** rcols[] = {&B.r_id_actor, &B.r_id_ctr, &B.r_obj_actor, &B.r_obj_ctr, &B.r_key_actor, &B.r_key_ctr, &B.r_key_off,
@@ -338,6 +338,12 @@ extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, cons
   rt_memset(B.d_first_pred_row, 0xFF, ((size_t)B.tot_dt + 1) * 4, ctx->stream);
   rt_memset(B.s_row, 0xFF, NS * 4, ctx->stream);
   rt_memset(B.r_doc, 0xFF, NR * 4, ctx->stream);
+  // "absent column" defaults of the nullable op columns (the staged decoders skip columns no document of a wave has)
+  rt_memset(B.r_obj_actor, 0xFF, NR * 4, ctx->stream); rt_memset(B.r_obj_ctr, 0xFF, NR * 4, ctx->stream);
+  rt_memset(B.r_key_actor, 0xFF, NR * 4, ctx->stream); rt_memset(B.r_key_ctr, 0xFF, NR * 4, ctx->stream);
+  rt_memset(B.r_key_off, 0, NR * 4, ctx->stream); rt_memset(B.r_key_len, 0xFF, NR * 4, ctx->stream);
+  rt_memset(B.r_mark_off, 0, NR * 4, ctx->stream); rt_memset(B.r_mark_len, 0xFF, NR * 4, ctx->stream);
+  rt_memset(B.r_expand, 0, NR, ctx->stream);
   rt_memset(B.t_pred_cnt, 0, ((size_t)T + 2) * 4, ctx->stream);
   rt_memset(B.t_pred_fill, 0, ((size_t)T + 2) * 4, ctx->stream);
   rt_memset(B.chg_actor_map, 0, ((size_t)b->tot_map + 1) * 4, ctx->stream);
@@ -376,6 +382,7 @@ extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, cons
   launch(ctx, AK_ACTOR_RANK, B, B.tot_chg);
   for (int k = 0; k < 12; k++) B.cv[k] = balloc<u32>(b, (size_t)tot_ops + 1, &ok);
   if (!ok) return fail("device out of memory");
+  rt_memset(B.c_wide, 0, NC * 4, ctx->stream);
   launch(ctx, AK_CHANGE_VIEW, B, tot_ops);
   launch(ctx, AK_ENCODE_SIZE, B, B.tot_chg * AMH_NCOLS);
   launch(ctx, AK_CHG_LAYOUT, B, B.tot_chg);

@@ -50,7 +50,7 @@ AMH_GLOBAL(k_visible)
 // ------------------------------------------------------------------------------------------
 #define DEC_W 64u          // window bytes per lane
 #define DEC_NEED 24u       // a decode step reads at most two LEB128 numbers past pos
-#define DEC_K 16u          // rows buffered per lane between write-backs
+#define DEC_K 8u           // rows buffered per lane between write-backs
 #define DEC_KS (DEC_K + 1)
 
 struct DecShared {
@@ -67,8 +67,7 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
 __device__ __forceinline__ u32 obase_succ(const BatchDev& B, u32 d) { return B.succ_base[d]; }
 
 template <u32 COL>
-__global__ void __launch_bounds__(64) g_decode_col(BatchDev B) {
-  __shared__ DecShared S;
+__device__ __forceinline__ void decode_col_body(const BatchDev& B, DecShared& S) {
   constexpr bool SUCC_ENTRY = COL == OC_SUCC_ACTOR || COL == OC_SUCC_CTR;
   constexpr bool IS_DELTA = COL == OC_KEY_CTR || COL == OC_ID_CTR || COL == OC_SUCC_CTR;
   constexpr bool IS_STR = COL == OC_KEY_STR || COL == OC_MARK_NAME;
@@ -86,10 +85,11 @@ __global__ void __launch_bounds__(64) g_decode_col(BatchDev B) {
   S.cnt[lane] = cnt;
   const u32 cnt_max = wave_max_u32(cnt);
   if (cnt_max == 0) return;
-  if (COL == OC_EXPAND && !__ballot(cnt != 0 && len != 0)) {   // no expand column anywhere in this wave: all false
-    for (u32 i = 0; i < cnt; i++) B.r_expand[obase + i] = 0;   // (rare; only mark-free documents take this path)
-    return;
-  }
+  // nullable columns that no document of this wave has: the host pre-filled the arrays with the
+  // "null" pattern (amh_load_staged), nothing to decode
+  constexpr bool NULLABLE = COL == OC_OBJ_ACTOR || COL == OC_OBJ_CTR || COL == OC_KEY_ACTOR || COL == OC_KEY_CTR ||
+                            COL == OC_KEY_STR || COL == OC_EXPAND || COL == OC_MARK_NAME;
+  if (NULLABLE && !__ballot(cnt != 0 && len != 0)) return;
   // decoder state
   RleDec r; DeltaDec dl; BoolDec bd;
   u32 wbase = off & ~3u;
@@ -206,6 +206,17 @@ __global__ void __launch_bounds__(64) g_decode_col(BatchDev B) {
   }
   if ((COL == OC_ID_CTR || COL == OC_SUCC_CTR) && live && !failed && cnt) amh_atomic_max(&B.doc_max_op[dd], mx);
 }
+// all 15 column streams in one launch: blockIdx.y = column (uniform per wave), blockIdx.x = 64 documents
+__global__ void __launch_bounds__(64) g_decode_cols(BatchDev B) {
+  __shared__ DecShared S;
+  switch (blockIdx.y) {
+#define DC(col) case col: decode_col_body<col>(B, S); break;
+    DC(OC_OBJ_ACTOR) DC(OC_OBJ_CTR) DC(OC_KEY_ACTOR) DC(OC_KEY_CTR) DC(OC_KEY_STR) DC(OC_ID_ACTOR) DC(OC_ID_CTR) DC(OC_INSERT)
+    DC(OC_ACTION) DC(OC_VAL_META) DC(OC_SUCC_NUM) DC(OC_SUCC_ACTOR) DC(OC_SUCC_CTR) DC(OC_EXPAND) DC(OC_MARK_NAME)
+#undef DC
+    default: break;
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // Change re-encode, LDS-staged (replaces the thread-per-(change, column) kernels k_encode_size /
@@ -238,12 +249,21 @@ __device__ __forceinline__ void enc_load_tile(const u32* cnt, u32 t0, F f) {
     if (t0 + k < cnt[l]) f(l, k, t0 + k);
   }
 }
-__device__ __forceinline__ void bool_feed(ColWriter& w, bool& last, u64& cnt, bool v) {  // boolean.rs:35-50
+template <class W>
+__device__ __forceinline__ void bool_feed(W& w, bool& last, u64& cnt, bool v) {  // boolean.rs:35-50
   if (v == last) cnt++; else { cw_uleb(w, cnt); last = v; cnt = 1; }
 }
 
+template <bool STORE> struct EncW { typedef SizeWriter T; };
+template <> struct EncW<true> { typedef FastWriter T; };
+__device__ __forceinline__ void w_init(SizeWriter& w, u8*) { sw_init(w); }
+__device__ __forceinline__ void w_init(FastWriter& w, u8* o) { fw_init(w, o); }
+__device__ __forceinline__ u32 w_done(SizeWriter& w) { return w.wide; }
+__device__ __forceinline__ u32 w_done(FastWriter& w) { fw_finish(w); return 0; }
+
 template <bool STORE>
 __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
+  typedef typename EncW<STORE>::T W;
   __shared__ EncShared S;
   const u32 lane = threadIdx.x;
   const u32 c = blockIdx.x * 64 + lane;
@@ -263,13 +283,16 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
   S.pn[lane] = pn;
   __syncthreads();
   const u32 n_max = wave_max_u32(n);
-  // output cursors of the store pass: columns back to back at c_cols_off (storage/change.rs:486-488)
+  // output cursors of the store pass: columns back to back at c_cols_off (storage/change.rs:486-488).
+  // Columns the size pass flagged as "wide literal" are left to k_encode_store (in-place header widening).
+  const u32 wide_in = (STORE && live) ? B.c_wide[c] : 0;
+  u32 wide = 0;
   u8* col_out[AMH_NCOLS];
   {
     u64 off = live ? (u64)B.c_out_off[c] + B.c_cols_off[c] : 0;
 #pragma unroll
     for (int k = 0; k < AMH_NCOLS; k++) {
-      col_out[k] = (STORE && live && cl[k]) ? B.out_arena + off : (u8*)0;
+      col_out[k] = (STORE && live && cl[k] && !((wide_in >> k) & 1)) ? B.out_arena + off : (u8*)0;
       if (STORE && live) off += cl[k];
     }
   }
@@ -282,7 +305,7 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
   // ---- group 1: object id (columns 0, 1; obj_id.rs:158-172) -----------------------------------
   {
     RleEnc<0> ea, ec; re_init(ea); re_init(ec);
-    ColWriter wa, wc; wa.out = col_out[0]; wa.pos = 0; wc.out = col_out[1]; wc.pos = 0;
+    W wa, wc; w_init(wa, col_out[0]); w_init(wc, col_out[1]);
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
         u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
@@ -299,6 +322,7 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
       __syncthreads();
     }
     re_finish(wa, ea); re_finish(wc, ec);
+    wide |= w_done(wa) << 0 | w_done(wc) << 1;
     len_out[0] = wa.pos; len_out[1] = wc.pos;
   }
   // ---- group 2: key (columns 2, 3, 4; key.rs:236-257) -----------------------------------------
@@ -306,7 +330,7 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
     RleEnc<0> ea; re_init(ea);
     DeltaEnc ec; re_init(ec.r); ec.abs = 0;
     RleEnc<2> es; re_init(es);
-    ColWriter wa, wc, ws; wa.out = col_out[2]; wa.pos = 0; wc.out = col_out[3]; wc.pos = 0; ws.out = col_out[4]; ws.pos = 0;
+    W wa, wc, ws; w_init(wa, col_out[2]); w_init(wc, col_out[3]); w_init(ws, col_out[4]);
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
         u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
@@ -327,6 +351,7 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
       __syncthreads();
     }
     re_finish(wa, ea); re_finish(wc, ec.r); re_finish(ws, es);
+    wide |= w_done(wa) << 2 | w_done(wc) << 3 | w_done(ws) << 4;
     len_out[2] = wa.pos; len_out[3] = wc.pos; len_out[4] = ws.pos;
   }
   // ---- group 3: insert, action, predNum, expand (columns 5, 6, 9, 12) -------------------------
@@ -334,8 +359,7 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
     bool ins_last = false, exp_last = false, exp_any = false;
     u64 ins_cnt = 0, exp_cnt = 0;
     RleEnc<0> eact, epn; re_init(eact); re_init(epn);
-    ColWriter wi, wact, wpn, wex; wi.out = col_out[5]; wi.pos = 0; wact.out = col_out[6]; wact.pos = 0;
-    wpn.out = col_out[9]; wpn.pos = 0; wex.out = col_out[12]; wex.pos = 0;
+    W wi, wact, wpn, wex; w_init(wi, col_out[5]); w_init(wact, col_out[6]); w_init(wpn, col_out[9]); w_init(wex, col_out[12]);
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
         u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
@@ -358,12 +382,13 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
     if (ins_cnt > 0) cw_uleb(wi, ins_cnt);
     re_finish(wact, eact); re_finish(wpn, epn);
     if (exp_any && exp_cnt > 0) cw_uleb(wex, exp_cnt);   // MaybeBoolean: nothing unless a true was appended (boolean.rs:131-137)
+    wide |= w_done(wi) << 5 | w_done(wact) << 6 | w_done(wpn) << 9 | w_done(wex) << 12;
     len_out[5] = wi.pos; len_out[6] = wact.pos; len_out[9] = wpn.pos; len_out[12] = exp_any ? wex.pos : 0;
   }
   // ---- group 4: value (columns 7, 8; value.rs:320-369, op_as_changeop.rs:94-103) --------------
   {
     RleEnc<0> em; re_init(em);
-    ColWriter wm, wr; wm.out = col_out[7]; wm.pos = 0; wr.out = col_out[8]; wr.pos = 0;
+    W wm, wr; w_init(wm, col_out[7]); w_init(wr, col_out[8]);
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
         u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
@@ -384,13 +409,14 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
       __syncthreads();
     }
     re_finish(wm, em);
+    wide |= w_done(wm) << 7 | w_done(wr) << 8;
     len_out[7] = wm.pos; len_out[8] = wr.pos;
   }
   // ---- group 5: flattened pred lists (columns 10, 11; opid_list.rs:52-78) ---------------------
   {
     RleEnc<0> ea; re_init(ea);
     DeltaEnc ec; re_init(ec.r); ec.abs = 0;
-    ColWriter wa, wc; wa.out = col_out[10]; wa.pos = 0; wc.out = col_out[11]; wc.pos = 0;
+    W wa, wc; w_init(wa, col_out[10]); w_init(wc, col_out[11]);
     const u32 p_max = wave_max_u32(pn);
     for (u32 t0 = 0; t0 < p_max; t0 += ENC_K) {
       enc_load_tile(S.pn, t0, [&](u32 l, u32 k, u32 i) {
@@ -407,6 +433,7 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
       __syncthreads();
     }
     re_finish(wa, ea); re_finish(wc, ec.r);
+    wide |= w_done(wa) << 10 | w_done(wc) << 11;
     len_out[10] = wa.pos; len_out[11] = wc.pos;
   }
   // ---- group 6: mark names (column 13) — only when a document of this wave has a mark column ---
@@ -414,7 +441,7 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
     bool has_marks = live && B.desc[d].ocol[OC_MARK_NAME].len != 0;
     if (__ballot(has_marks)) {
       RleEnc<2> es; re_init(es);
-      ColWriter ws; ws.out = col_out[13]; ws.pos = 0;
+      W ws; w_init(ws, col_out[13]);
       for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
         enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
           u32 t = B.ops_sorted[S.base[l] + i];
@@ -432,12 +459,14 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
         __syncthreads();
       }
       re_finish(ws, es);
+      wide |= w_done(ws) << 13;
       len_out[13] = ws.pos;
     }
   }
   if (!STORE && c < B.tot_chg) {
 #pragma unroll
     for (int k = 0; k < AMH_NCOLS; k++) cl[k] = live ? len_out[k] : 0;
+    B.c_wide[c] = live ? wide : 0;
   }
   (void)raw_col;
 }
@@ -446,15 +475,16 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
   if (n == 0) return;
   hipStream_t s = (hipStream_t)stream;
   if (k == AK_DECODE_OPS) {
-    dim3 g((B.n_docs + 63) / 64), b64(64);
-#define DC(col) hipLaunchKernelGGL((g_decode_col<col>), g, b64, 0, s, B);
-    DC(OC_OBJ_ACTOR) DC(OC_OBJ_CTR) DC(OC_KEY_ACTOR) DC(OC_KEY_CTR) DC(OC_KEY_STR) DC(OC_ID_ACTOR) DC(OC_ID_CTR) DC(OC_INSERT)
-    DC(OC_ACTION) DC(OC_VAL_META) DC(OC_SUCC_NUM) DC(OC_SUCC_ACTOR) DC(OC_SUCC_CTR) DC(OC_EXPAND) DC(OC_MARK_NAME)
-#undef DC
+    hipLaunchKernelGGL(g_decode_cols, dim3((B.n_docs + 63) / 64, OC_COUNT), dim3(64), 0, s, B);
     return;
   }
   if (k == AK_ENCODE_SIZE) { hipLaunchKernelGGL((g_encode_lds<false>), dim3((B.tot_chg + 63) / 64), dim3(64), 0, s, B); return; }
-  if (k == AK_ENCODE_STORE) { hipLaunchKernelGGL((g_encode_lds<true>), dim3((B.tot_chg + 63) / 64), dim3(64), 0, s, B); return; }
+  if (k == AK_ENCODE_STORE) {
+    hipLaunchKernelGGL((g_encode_lds<true>), dim3((B.tot_chg + 63) / 64), dim3(64), 0, s, B);
+    // columns with a literal run of more than 64 values (flagged in c_wide): byte-wise writer that can widen the header
+    hipLaunchKernelGGL(g_k_encode_store, dim3((n + AMH_BLOCK - 1) / AMH_BLOCK), dim3(AMH_BLOCK), 0, s, B, n);
+    return;
+  }
   dim3 grid((n + AMH_BLOCK - 1) / AMH_BLOCK), block(AMH_BLOCK);
 #define L(id, name) case id: hipLaunchKernelGGL(g_##name, grid, block, 0, s, B, n); break;
   switch (k) {

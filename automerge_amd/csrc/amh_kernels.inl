@@ -971,15 +971,138 @@ AMH_DEV void k_actor_rank(const BatchDev& B, u32 c) {
 //      opid_list.rs:244-254, value.rs:320-369,412-432; op views per op_as_changeop.rs:86-145.
 //      Thread per (change, column).  Runs twice: size pass (out == null) and store pass.
 // ------------------------------------------------------------------------------------------
+// Writers.  ColWriter: bytes straight to memory (or size only when out == null), may widen a literal
+// header in place.  SizeWriter: counts, and notes columns with a literal run of more than 64 values
+// (their header is wider than the one byte reserved).  FastWriter: collects bytes in two registers
+// and stores 16 at a time; it cannot widen a header, so columns SizeWriter flagged go through
+// ColWriter instead (k_encode_store, restricted to those columns).
 struct ColWriter {
   u8* out;   // null = size only
   u32 pos;
 };
+struct SizeWriter {
+  u32 pos;
+  u32 wide;
+};
+struct FastWriter {
+  u8* out;   // null = this column is not written by this writer
+  u32 pos, na;
+  u64 a0, a1;
+};
+AMH_DEV void fw_init(FastWriter& w, u8* out) { w.out = out; w.pos = 0; w.na = 0; w.a0 = 0; w.a1 = 0; }
+AMH_DEV void sw_init(SizeWriter& w) { w.pos = 0; w.wide = 0; }
+AMH_DEV void amh_store16(u8* p, u64 lo, u64 hi) {
+  struct __attribute__((packed)) P { u64 lo, hi; };
+  P v; v.lo = lo; v.hi = hi;
+  *(P*)p = v;
+}
+// x holds n (1..8) bytes, low byte first, upper bytes zero
+AMH_DEV void fw_put(FastWriter& w, u64 x, u32 n) {
+  if (!w.out) { w.pos += n; return; }
+  u32 na = w.na;
+  u64 carry = 0;
+  if (na < 8) {
+    w.a0 |= x << (8 * na);
+    if (na + n > 8) w.a1 |= x >> (8 * (8 - na));
+  } else {
+    u32 k = na - 8;
+    w.a1 |= x << (8 * k);
+    if (k + n > 8) carry = x >> (8 * (8 - k));
+  }
+  na += n;
+  w.pos += n;
+  if (na >= 16) {
+    amh_store16(w.out + (w.pos - na), w.a0, w.a1);
+    w.a0 = carry; w.a1 = 0; na -= 16;
+  }
+  w.na = na;
+}
+AMH_DEV void fw_finish(FastWriter& w) {
+  if (!w.out) return;
+  u8* o = w.out + (w.pos - w.na);
+  for (u32 i = 0; i < w.na; i++) o[i] = (u8)((i < 8 ? w.a0 >> (8 * i) : w.a1 >> (8 * (i - 8))) & 0xFF);
+  w.na = 0; w.a0 = 0; w.a1 = 0;
+}
+// spread the low 56 bits of v into eight 7-bit groups, one per byte
+AMH_DEV u64 amh_leb_spread(u64 x) {
+  x = (x & 0x000000000fffffffull) | ((x & 0x00fffffff0000000ull) << 4);
+  x = (x & 0x00003fff00003fffull) | ((x & 0x0fffc0000fffc000ull) << 2);
+  x = (x & 0x007f007f007f007full) | ((x & 0x3f803f803f803f80ull) << 1);
+  return x;
+}
+AMH_DEV u32 amh_clz64(u64 v) { return v ? (u32)__builtin_clzll(v) : 64; }
+AMH_DEV u32 uleb_size_fast(u64 v) { u32 bits = 64 - amh_clz64(v | 1); return (bits + 6) / 7; }
+AMH_DEV u32 sleb_size_fast(i64 v) { u64 m = v < 0 ? ~(u64)v : (u64)v; u32 bits = 65 - amh_clz64(m); return (bits + 6) / 7; }
+AMH_DEV u64 amh_cont_bits(u32 nb) { return nb >= 8 ? 0x0080808080808080ull : (0x8080808080808080ull & (((u64)1 << (8 * (nb - 1))) - 1)); }
+AMH_DEV void cw_uleb(FastWriter& w, u64 v) {
+  u32 nb = uleb_size_fast(v);
+  if (nb <= 8) { fw_put(w, amh_leb_spread(v) | amh_cont_bits(nb), nb); return; }
+  fw_put(w, amh_leb_spread(v) | 0x8080808080808080ull, 8);
+  u64 rest = v >> 56;
+  u32 rb = nb - 8;
+  fw_put(w, amh_leb_spread(rest) | amh_cont_bits(rb), rb);
+}
+AMH_DEV void cw_sleb(FastWriter& w, i64 v) {
+  u32 nb = sleb_size_fast(v);
+  if (nb <= 8) {
+    u64 m = nb == 8 ? (u64)v & 0x00ffffffffffffffull : (u64)v & (((u64)1 << (7 * nb)) - 1);
+    fw_put(w, amh_leb_spread(m) | amh_cont_bits(nb), nb);
+    return;
+  }
+  fw_put(w, amh_leb_spread((u64)v & 0x00ffffffffffffffull) | 0x8080808080808080ull, 8);
+  u64 g8 = (u64)(v >> 56) & 0x7f, g9 = (u64)(v >> 63) & 0x7f;
+  if (nb == 9) fw_put(w, g8, 1); else fw_put(w, (g8 | 0x80) | (g9 << 8), 2);
+}
+AMH_DEV u64 amh_peek8_any(const u8* p) {   // 8 bytes at any address; reads at most 11 bytes past p (the arena is padded)
+  u64 a = (u64)p;
+  const u32* w = (const u32*)(a & ~(u64)3);
+  u32 w0 = w[0], w1 = w[1], w2 = w[2];
+  u32 sh = (u32)(a & 3) * 8;
+  u64 lo = (u64)w0 | ((u64)w1 << 32);
+  return sh ? (lo >> sh) | ((u64)w2 << (64 - sh)) : lo;
+}
+AMH_DEV void cw_bytes(FastWriter& w, const u8* p, u32 n) {
+  if (!w.out) { w.pos += n; return; }
+  u32 i = 0;
+  for (; i + 8 <= n; i += 8) fw_put(w, amh_peek8_any(p + i), 8);
+  if (i < n) { u32 r = n - i; fw_put(w, amh_peek8_any(p + i) & (((u64)1 << (8 * r)) - 1), r); }
+}
+AMH_DEV void cw_uleb(SizeWriter& w, u64 v) { w.pos += uleb_size_fast(v); }
+AMH_DEV void cw_sleb(SizeWriter& w, i64 v) { w.pos += sleb_size_fast(v); }
+AMH_DEV void cw_bytes(SizeWriter& w, const u8*, u32 n) { w.pos += n; }
 AMH_DEV void cw_uleb(ColWriter& w, u64 v) { w.pos += wr_uleb(w.out ? w.out + w.pos : (u8*)0, v); }
 AMH_DEV void cw_sleb(ColWriter& w, i64 v) { w.pos += wr_sleb(w.out ? w.out + w.pos : (u8*)0, v); }
 AMH_DEV void cw_bytes(ColWriter& w, const u8* p, u32 n) {
   if (w.out) for (u32 i = 0; i < n; i++) w.out[w.pos + i] = p[i];
   w.pos += n;
+}
+// literal-run header: one byte reserved at open, written at close (rle.rs:112-119, 128-133)
+AMH_DEV u32 cw_lit_open(ColWriter& w) { u32 at = w.pos; w.pos += 1; return at; }
+AMH_DEV u32 cw_lit_open(SizeWriter& w) { u32 at = w.pos; w.pos += 1; return at; }
+AMH_DEV u32 cw_lit_open(FastWriter& w) { u32 at = w.pos; fw_put(w, 0, 1); return at; }
+AMH_DEV void cw_lit_close(ColWriter& w, u32 at, u64 cnt) {
+  i64 hdr = -(i64)cnt;
+  u32 h = sleb_size(hdr);
+  if (h > 1) {
+    if (w.out) for (u32 i = w.pos; i > at + 1; i--) w.out[i - 1 + (h - 1)] = w.out[i - 1];
+    w.pos += h - 1;
+  }
+  if (w.out) wr_sleb(w.out + at, hdr);
+}
+AMH_DEV void cw_lit_close(SizeWriter& w, u32, u64 cnt) {
+  u32 h = sleb_size_fast(-(i64)cnt);
+  if (h > 1) { w.pos += h - 1; w.wide = 1; }
+}
+AMH_DEV void cw_lit_close(FastWriter& w, u32 at, u64 cnt) {   // cnt <= 64 here: wide columns never reach a FastWriter with out != null
+  if (!w.out) { u32 h = sleb_size_fast(-(i64)cnt); if (h > 1) w.pos += h - 1; return; }
+  u64 hdr = (u64)(-(i64)cnt) & 0x7f;
+  u32 first = w.pos - w.na;   // oldest byte still in the registers
+  if (at >= first) {
+    u32 k = at - first;
+    if (k < 8) w.a0 |= hdr << (8 * k); else w.a1 |= hdr << (8 * (k - 8));
+  } else {
+    w.out[at] = (u8)hdr;
+  }
 }
 
 // RLE state machine restated with O(1) state: a literal run's values are streamed behind a
@@ -989,13 +1112,19 @@ struct RleVal { u64 v; const u8* s; u32 n; };
 template <int KIND> AMH_DEV bool rv_eq(const RleVal& a, const RleVal& b) {
   if (KIND != 2) return a.v == b.v;
   if (a.n != b.n) return false;
-  for (u32 i = 0; i < a.n; i++) if (a.s[i] != b.s[i]) return false;
+  if (a.s == b.s) return true;
+  for (u32 i = 0; i < a.n; i += 8) {
+    u64 d = amh_peek8_any(a.s + i) ^ amh_peek8_any(b.s + i);
+    u32 r = a.n - i;
+    if (r < 8) d &= ((u64)1 << (8 * r)) - 1;
+    if (d) return false;
+  }
   return true;
 }
-template <int KIND> AMH_DEV void rv_write(ColWriter& w, const RleVal& x) {
+template <int KIND, class W> AMH_DEV void rv_write(W& w, const RleVal& x) {
   if (KIND == 0) cw_uleb(w, x.v);
   else if (KIND == 1) cw_sleb(w, (i64)x.v);
-  else { cw_uleb(w, x.n); cw_bytes(w, x.s, x.n); }
+  else { cw_uleb(w, (u64)x.n); cw_bytes(w, x.s, x.n); }
 }
 template <int KIND> struct RleEnc {
   int st;        // 0 Empty 1 InitialNullRun 2 NullRun 3 LiteralRun 4 LoneVal 5 Run
@@ -1005,20 +1134,12 @@ template <int KIND> struct RleEnc {
   u64 lit_cnt;   // values already streamed into it
 };
 template <int KIND> AMH_DEV void re_init(RleEnc<KIND>& e) { e.st = 0; e.n = 0; e.lit_pos = 0; e.lit_cnt = 0; e.val.v = 0; e.val.s = 0; e.val.n = 0; }
-template <int KIND> AMH_DEV void re_lit_open(ColWriter& w, RleEnc<KIND>& e) { e.lit_pos = w.pos; w.pos += 1; e.lit_cnt = 0; }
-template <int KIND> AMH_DEV void re_lit_push(ColWriter& w, RleEnc<KIND>& e, const RleVal& x) { rv_write<KIND>(w, x); e.lit_cnt++; }
-template <int KIND> AMH_DEV void re_lit_close(ColWriter& w, RleEnc<KIND>& e) {
-  i64 hdr = -(i64)e.lit_cnt;
-  u32 h = sleb_size(hdr);
-  if (h > 1) {
-    if (w.out) for (u32 i = w.pos; i > e.lit_pos + 1; i--) w.out[i - 1 + (h - 1)] = w.out[i - 1];
-    w.pos += h - 1;
-  }
-  if (w.out) wr_sleb(w.out + e.lit_pos, hdr);
-}
-template <int KIND> AMH_DEV void re_flush_run(ColWriter& w, const RleVal& v, u64 n) { cw_sleb(w, (i64)n); rv_write<KIND>(w, v); }
-AMH_DEV void re_flush_nulls(ColWriter& w, u64 n) { cw_sleb(w, 0); cw_uleb(w, n); }
-template <int KIND> AMH_DEV void re_null(ColWriter& w, RleEnc<KIND>& e) {  // rle.rs:71-90
+template <int KIND, class W> AMH_DEV void re_lit_open(W& w, RleEnc<KIND>& e) { e.lit_pos = cw_lit_open(w); e.lit_cnt = 0; }
+template <int KIND, class W> AMH_DEV void re_lit_push(W& w, RleEnc<KIND>& e, const RleVal& x) { rv_write<KIND>(w, x); e.lit_cnt++; }
+template <int KIND, class W> AMH_DEV void re_lit_close(W& w, RleEnc<KIND>& e) { cw_lit_close(w, e.lit_pos, e.lit_cnt); }
+template <int KIND, class W> AMH_DEV void re_flush_run(W& w, const RleVal& v, u64 n) { cw_sleb(w, (i64)n); rv_write<KIND>(w, v); }
+template <class W> AMH_DEV void re_flush_nulls(W& w, u64 n) { cw_sleb(w, (i64)0); cw_uleb(w, n); }
+template <int KIND, class W> AMH_DEV void re_null(W& w, RleEnc<KIND>& e) {  // rle.rs:71-90
   switch (e.st) {
     case 0: e.st = 1; e.n = 1; break;
     case 1: case 2: e.n++; break;
@@ -1027,7 +1148,7 @@ template <int KIND> AMH_DEV void re_null(ColWriter& w, RleEnc<KIND>& e) {  // rl
     case 3: re_lit_push(w, e, e.val); re_lit_close(w, e); e.st = 2; e.n = 1; break;
   }
 }
-template <int KIND> AMH_DEV void re_value(ColWriter& w, RleEnc<KIND>& e, const RleVal& x) {  // rle.rs:92-126
+template <int KIND, class W> AMH_DEV void re_value(W& w, RleEnc<KIND>& e, const RleVal& x) {  // rle.rs:92-126
   switch (e.st) {
     case 0: e.st = 4; e.val = x; break;
     case 4:
@@ -1045,7 +1166,7 @@ template <int KIND> AMH_DEV void re_value(ColWriter& w, RleEnc<KIND>& e, const R
     case 1: case 2: re_flush_nulls(w, e.n); e.st = 4; e.val = x; break;
   }
 }
-template <int KIND> AMH_DEV void re_finish(ColWriter& w, RleEnc<KIND>& e) {  // rle.rs:31-46
+template <int KIND, class W> AMH_DEV void re_finish(W& w, RleEnc<KIND>& e) {  // rle.rs:31-46
   switch (e.st) {
     case 2: re_flush_nulls(w, e.n); break;
     case 4: re_lit_open(w, e); re_lit_push(w, e, e.val); re_lit_close(w, e); break;
@@ -1055,7 +1176,7 @@ template <int KIND> AMH_DEV void re_finish(ColWriter& w, RleEnc<KIND>& e) {  // 
   }
 }
 struct DeltaEnc { RleEnc<1> r; i64 abs; };
-AMH_DEV void de_value(ColWriter& w, DeltaEnc& e, i64 v) {  // delta.rs:23-27
+template <class W> AMH_DEV void de_value(W& w, DeltaEnc& e, i64 v) {  // delta.rs:23-27
   i64 dlt;
   if (__builtin_sub_overflow(v, e.abs, &dlt)) dlt = v > e.abs ? INT64_MAX : INT64_MIN;
   RleVal x; x.v = (u64)dlt; x.s = 0; x.n = 0;
@@ -1308,6 +1429,9 @@ AMH_DEV void k_encode_store(const BatchDev& B, u32 gid) {
   if (B.status[B.c_doc[c]]) return;
   const u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
   if (cl[col] == 0) return;
+#ifndef AMH_EMU
+  if (!((B.c_wide[c] >> col) & 1)) return;   // written by g_encode_lds
+#endif
   u64 off = B.c_out_off[c] + B.c_cols_off[c];
   for (u32 k = 0; k < col; k++) off += cl[k];
   encode_change_col(B, c, col, B.out_arena + off);

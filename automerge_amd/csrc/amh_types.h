@@ -114,6 +114,7 @@ struct BatchDev {
   u32* c_out_off;                // [tot_chg + 1] offset of the re-derived change chunk in out_arena
   u32 *c_out_len, *c_body_len, *c_cols_off;
   u32* c_col_len;                // [tot_chg * 14] encoded column lengths
+  u32* c_wide;                   // [tot_chg] bit k: column k holds a literal run of more than 64 values
   u32* c_map_base;               // base into chg_actor_map
   u32* c_n_other;
   u32* chg_actor_map;            // [sum over changes of n_actors(doc)]: index in the change's actor table

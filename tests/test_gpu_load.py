@@ -57,6 +57,15 @@ def test_generated_text_documents_bit_exact(engine):
         _compare(batch, i, d)
 
 
+def test_large_changes_with_long_literal_runs(engine):
+    """changes of 700 ops: literal runs of more than 64 values (multi-byte literal headers), many tiles per change"""
+    blob, offs = engine.gen_text_docs(0xC070, 3, 3, 300, 2100, 700, 4)
+    docs = [blob[offs[i]:offs[i + 1]] for i in range(9)]
+    batch = engine.load_batch(docs)
+    for i, d in enumerate(docs):
+        _compare(batch, i, d)
+
+
 def test_bad_documents_do_not_poison_the_batch(engine, golden_dir):
     import oracle_lib as o
     files = sorted(glob.glob(os.path.join(golden_dir, "ref_fuzz_crashers", "*"))) + sorted(glob.glob(os.path.join(golden_dir, "ref_fixtures", "*")))
