@@ -431,3 +431,92 @@ AMH_DEV void sha_finish(Sha256Dev& s, u8* out32) {
     out32[4 * i + 3] = (u8)s.h[i];
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// SHA-256 of one contiguous byte range, block at a time out of registers: sixteen message words per
+// block come from aligned 32-bit loads funnel-shifted to the range's byte phase (no byte loads, no
+// indexed scratch buffer).  Reads at most 67 bytes past the range (the arenas are padded).
+// ---------------------------------------------------------------------------------------------
+AMH_DEV u32 amh_bswap32(u32 x) { return __builtin_bswap32(x); }
+struct ShaState { u32 h[8]; };
+AMH_DEV void sha_compress16(ShaState& s, u32 (&w)[16]) {
+  u32 a = s.h[0], b = s.h[1], c = s.h[2], d = s.h[3], e = s.h[4], f = s.h[5], g = s.h[6], h = s.h[7];
+#pragma unroll
+  for (int i = 0; i < 64; i++) {
+    u32 wi;
+    if (i < 16) {
+      wi = w[i];
+    } else {
+      u32 w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+      u32 s0 = sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3);
+      u32 s1 = sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10);
+      wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+      w[i & 15] = wi;
+    }
+    u32 S1 = sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25);
+    u32 ch = (e & f) ^ (~e & g);
+    u32 t1 = h + S1 + ch + AMH_SHA_K[i] + wi;
+    u32 S0 = sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22);
+    u32 mj = (a & b) ^ (a & c) ^ (b & c);
+    u32 t2 = S0 + mj;
+    h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  s.h[0] += a; s.h[1] += b; s.h[2] += c; s.h[3] += d; s.h[4] += e; s.h[5] += f; s.h[6] += g; s.h[7] += h;
+}
+AMH_DEV void sha256_contig(const u8* p, u64 n, u8* out32) {
+  ShaState s;
+  s.h[0] = 0x6a09e667; s.h[1] = 0xbb67ae85; s.h[2] = 0x3c6ef372; s.h[3] = 0xa54ff53a;
+  s.h[4] = 0x510e527f; s.h[5] = 0x9b05688c; s.h[6] = 0x1f83d9ab; s.h[7] = 0x5be0cd19;
+  u64 addr = (u64)p;
+  const u32* base = (const u32*)(addr & ~(u64)3);
+  u32 sh = (u32)(addr & 3) * 8;
+  u64 full = n / 64;
+  u32 w[16];
+  for (u64 k = 0; k < full; k++) {
+    const u32* m = base + 16 * k;
+    u32 prev = m[0];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      u32 next = m[i + 1];
+      u32 le = sh ? (prev >> sh) | (next << (32 - sh)) : prev;
+      w[i] = amh_bswap32(le);
+      prev = next;
+    }
+    sha_compress16(s, w);
+  }
+  // tail: the remaining r < 64 bytes, 0x80, zeros, 64-bit big-endian bit count (one or two blocks)
+  u32 r = (u32)(n & 63);
+  const u32* m = base + 16 * full;
+  u64 bits = n * 8;
+  int nblk = r >= 56 ? 2 : 1;
+  for (int blk = 0; blk < nblk; blk++) {
+    u32 prev = m[16 * blk];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      u32 next = m[16 * blk + i + 1];
+      u32 le = sh ? (prev >> sh) | (next << (32 - sh)) : prev;
+      prev = next;
+      u32 o = (u32)(64 * blk + 4 * i);   // byte offset of this word inside the tail region
+      u32 be = amh_bswap32(le);
+      u32 word;
+      if (o + 4 <= r) word = be;
+      else if (o >= r + 1) word = 0;
+      else {  // the word holding the 0x80 terminator (and possibly the last message bytes)
+        u32 keep = r - o;   // message bytes in this word: 0..3
+        u32 mask = keep ? 0xFFFFFFFFu << (32 - 8 * keep) : 0;
+        word = (be & mask) | (0x80u << (24 - 8 * keep));
+      }
+      if (blk == nblk - 1 && i == 14) word = (u32)(bits >> 32);
+      if (blk == nblk - 1 && i == 15) word = (u32)bits;
+      w[i] = word;
+    }
+    sha_compress16(s, w);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    out32[4 * i] = (u8)(s.h[i] >> 24);
+    out32[4 * i + 1] = (u8)(s.h[i] >> 16);
+    out32[4 * i + 2] = (u8)(s.h[i] >> 8);
+    out32[4 * i + 3] = (u8)s.h[i];
+  }
+}

@@ -21,6 +21,7 @@
 
 #define AMH_EMPTY32 0xFFFFFFFFu
 #define AMH_NCOLS 14
+#define AMH_LEVEL_CAP_HOST 48u   // = AMH_LEVEL_CAP of amh_kernels.inl
 
 static thread_local std::string g_last_error;
 
@@ -288,9 +289,12 @@ extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, cons
   B.doc_hash = balloc<u8>(b, (size_t)n * 32 + 32, &ok);
   B.doc_max_op = balloc<u32>(b, n + 1, &ok);
   B.heads_ok = balloc<u32>(b, n + 1, &ok);
+  B.doc_level = balloc<u32>(b, n + 1, &ok);
+  B.max_level = balloc<u32>(b, 4, &ok);
   if (!ok) return fail("device out of memory");
   rt_memset(B.status, 0, (n + 1) * sizeof(i32), ctx->stream);
   rt_memset(B.fail_line, 0, (n + 1) * sizeof(u32), ctx->stream);
+  rt_memset(B.max_level, 0, 16, ctx->stream);
   launch(ctx, AK_PARSE, B, n);
   launch(ctx, AK_SHA_DOC, B, n);
   launch(ctx, AK_COUNT, B, n);
@@ -314,7 +318,7 @@ extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, cons
   B.c_extra_off = balloc<u32>(b, NC, &ok); B.c_extra_len = balloc<u32>(b, NC, &ok); B.c_doc = balloc<u32>(b, NC, &ok);
   B.dep_idx = balloc<u32>(b, B.tot_deps + 1, &ok);
   B.c_nops = balloc<u32>(b, NC, &ok); B.c_start_op = balloc<u64>(b, NC, &ok); B.c_op_base = balloc<u32>(b, NC, &ok);
-  B.c_next_same_actor = balloc<u32>(b, NC, &ok); B.c_hash = balloc<u8>(b, NC * 32, &ok);
+  B.c_next_same_actor = balloc<u32>(b, NC, &ok); B.c_level = balloc<u32>(b, NC, &ok); B.c_is_dep = balloc<u8>(b, NC, &ok); B.c_hash = balloc<u8>(b, NC * 32, &ok);
   B.c_out_off = balloc<u32>(b, NC, &ok); B.c_out_len = balloc<u32>(b, NC, &ok); B.c_body_len = balloc<u32>(b, NC, &ok);
   B.c_cols_off = balloc<u32>(b, NC, &ok); B.c_col_len = balloc<u32>(b, NC * AMH_NCOLS, &ok); B.c_wide = balloc<u32>(b, NC, &ok);
   B.c_map_base = balloc<u32>(b, NC, &ok); B.c_n_other = balloc<u32>(b, NC, &ok);
@@ -398,7 +402,22 @@ extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, cons
   B.out_arena = balloc<u8>(b, (size_t)tot_out + 64, &ok);
   if (!ok) return fail("device out of memory");
   launch(ctx, AK_ENCODE_STORE, B, B.tot_chg * AMH_NCOLS);
-  launch(ctx, AK_ASSEMBLE_HASH, B, n);
+  launch(ctx, AK_CHG_HEADER, B, B.tot_chg);
+  // hash the changes level by level: every change of a level only needs hashes of earlier levels
+  B.lvl_order = balloc<u32>(b, (size_t)B.tot_chg + 1, &ok);
+  B.lvl_start = balloc<u32>(b, AMH_LEVEL_CAP_HOST + 4, &ok);
+  u32* lvl_tmp = balloc<u32>(b, amh_level_sort_tmp_words(B.tot_chg), &ok);
+  if (!ok) return fail("device out of memory");
+  amh_level_sort(B, lvl_tmp, (void*)ctx->stream);
+  u32 lvl_start[AMH_LEVEL_CAP_HOST + 2] = {0};
+  if (!rt_d2h(lvl_start, B.lvl_start, sizeof(lvl_start), ctx->stream)) return fail("device pipeline failed");
+  for (u32 lvl = 0; lvl < AMH_LEVEL_CAP_HOST; lvl++) {
+    if (lvl_start[lvl + 1] == lvl_start[lvl]) continue;
+    B.cur_level = lvl_start[lvl];
+    launch(ctx, AK_CHG_HASH, B, lvl_start[lvl + 1] - lvl_start[lvl]);
+  }
+  if (lvl_start[AMH_LEVEL_CAP_HOST + 1] > lvl_start[AMH_LEVEL_CAP_HOST]) launch(ctx, AK_CHG_HASH_SEQ, B, n);
+  launch(ctx, AK_HEADS, B, n);
   launch(ctx, AK_VISIBLE, B, B.tot_rows);
   b->status.resize(n);
   b->fail_line.resize(n);
@@ -773,7 +792,7 @@ extern "C" int amh_debug_array(const amh_batch* b, const char* name, void* out, 
     {"c_msg_off", B.c_msg_off, NC * 4}, {"c_msg_len", B.c_msg_len, NC * 4}, {"c_ndeps", B.c_ndeps, NC * 4},
     {"c_dep_base", B.c_dep_base, NC * 4}, {"c_extra_off", B.c_extra_off, NC * 4}, {"c_extra_len", B.c_extra_len, NC * 4},
     {"c_doc", B.c_doc, NC * 4}, {"dep_idx", B.dep_idx, (size_t)B.tot_deps * 4}, {"c_nops", B.c_nops, NC * 4},
-    {"c_start_op", B.c_start_op, NC * 8}, {"c_op_base", B.c_op_base, (NC + 1) * 4}, {"c_next_same_actor", B.c_next_same_actor, NC * 4},
+    {"c_start_op", B.c_start_op, NC * 8}, {"c_op_base", B.c_op_base, (NC + 1) * 4}, {"c_next_same_actor", B.c_next_same_actor, NC * 4}, {"c_level", B.c_level, NC * 4},
     {"c_hash", B.c_hash, NC * 32}, {"c_out_off", B.c_out_off, (NC + 1) * 4}, {"c_out_len", B.c_out_len, NC * 4},
     {"c_body_len", B.c_body_len, NC * 4}, {"c_cols_off", B.c_cols_off, NC * 4}, {"c_col_len", B.c_col_len, NC * AMH_NCOLS * 4},
     {"c_map_base", B.c_map_base, NC * 4}, {"c_n_other", B.c_n_other, NC * 4}, {"chg_actor_map", B.chg_actor_map, (size_t)b->tot_map * 4},

@@ -37,7 +37,10 @@ AMH_GLOBAL(k_change_view)
 AMH_GLOBAL(k_encode_size)
 AMH_GLOBAL(k_chg_layout)
 AMH_GLOBAL(k_encode_store)
-AMH_GLOBAL(k_assemble_hash)
+AMH_GLOBAL(k_chg_header)
+AMH_GLOBAL(k_chg_hash)
+AMH_GLOBAL(k_chg_hash_seq)
+AMH_GLOBAL(k_heads)
 AMH_GLOBAL(k_visible)
 
 // ------------------------------------------------------------------------------------------
@@ -494,7 +497,7 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
     L(AK_BUCKET, k_bucket) L(AK_CHG_FINISH, k_chg_finish) L(AK_PLACE, k_place) L(AK_PRED_SLOT_CNT, k_pred_slot_cnt) L(AK_PRED_SLOT_BASE, k_pred_slot_base) L(AK_PRED_FILL, k_pred_fill)
     L(AK_PRED_SORT, k_pred_sort) L(AK_ACTOR_MARK, k_actor_mark) L(AK_ACTOR_RANK, k_actor_rank) L(AK_CHANGE_VIEW, k_change_view)
     L(AK_ENCODE_SIZE, k_encode_size) L(AK_CHG_LAYOUT, k_chg_layout) L(AK_ENCODE_STORE, k_encode_store)
-    L(AK_ASSEMBLE_HASH, k_assemble_hash) L(AK_VISIBLE, k_visible)
+    L(AK_CHG_HEADER, k_chg_header) L(AK_CHG_HASH, k_chg_hash) L(AK_CHG_HASH_SEQ, k_chg_hash_seq) L(AK_HEADS, k_heads) L(AK_VISIBLE, k_visible)
     default: break;
   }
 #undef L
@@ -583,4 +586,44 @@ void amh_scan_inplace(u32* data, u32 n, u32* tmp, void* stream) {
   hipLaunchKernelGGL(g_scan_reduce, dim3(tiles), dim3(AMH_BLOCK), 0, s, (const u32*)data, n, tmp);
   amh_scan_inplace(tmp, tiles, tmp + tiles + 1, s);  // tmp[tiles] receives the total of the tile sums
   hipLaunchKernelGGL(g_scan_apply, dim3(tiles), dim3(AMH_BLOCK), 0, s, data, n, (const u32*)tmp, data + n);
+}
+
+// ------------------------------------------------------------------------------------------
+// changes grouped by dependency level: one radix split on the level (49 buckets).
+//   g_level_hist     per block of 256 changes, a histogram in LDS -> hist[bucket * nblocks + block]
+//   (exclusive scan of hist)
+//   g_level_scatter  each change to base[bucket][block] + its rank inside the block
+// ------------------------------------------------------------------------------------------
+#define LVL_BUCKETS (AMH_LEVEL_CAP + 1)
+__global__ void __launch_bounds__(AMH_BLOCK) g_level_hist(BatchDev B, u32* hist, u32 nblocks) {
+  __shared__ u32 h[LVL_BUCKETS];
+  for (u32 i = threadIdx.x; i < LVL_BUCKETS; i += AMH_BLOCK) h[i] = 0;
+  __syncthreads();
+  u32 c = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  if (c < B.tot_chg) atomicAdd(&h[chg_level_bucket(B, c)], 1u);
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < LVL_BUCKETS; i += AMH_BLOCK) hist[(u64)i * nblocks + blockIdx.x] = h[i];
+}
+__global__ void __launch_bounds__(AMH_BLOCK) g_level_scatter(BatchDev B, const u32* hist, u32 nblocks) {
+  __shared__ u32 h[LVL_BUCKETS];
+  for (u32 i = threadIdx.x; i < LVL_BUCKETS; i += AMH_BLOCK) h[i] = hist[(u64)i * nblocks + blockIdx.x];
+  __syncthreads();
+  u32 c = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  if (c < B.tot_chg) B.lvl_order[atomicAdd(&h[chg_level_bucket(B, c)], 1u)] = c;
+  if (blockIdx.x == 0)
+    for (u32 i = threadIdx.x; i <= LVL_BUCKETS; i += AMH_BLOCK) B.lvl_start[i] = i < LVL_BUCKETS ? hist[(u64)i * nblocks] : B.tot_chg;
+}
+u32 amh_level_sort_tmp_words(u32 tot_chg) {
+  u32 nblocks = (tot_chg + AMH_BLOCK - 1) / AMH_BLOCK;
+  u32 n = LVL_BUCKETS * nblocks;
+  return n + 2 + amh_scan_tmp_words(n);
+}
+void amh_level_sort(const BatchDev& B, u32* tmp, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  u32 nblocks = (B.tot_chg + AMH_BLOCK - 1) / AMH_BLOCK;
+  if (nblocks == 0) { (void)hipMemsetAsync(B.lvl_start, 0, (LVL_BUCKETS + 1) * sizeof(u32), s); return; }
+  u32 n = LVL_BUCKETS * nblocks;
+  hipLaunchKernelGGL(g_level_hist, dim3(nblocks), dim3(AMH_BLOCK), 0, s, B, tmp, nblocks);
+  amh_scan_inplace(tmp, n, tmp + n + 2, s);
+  hipLaunchKernelGGL(g_level_scatter, dim3(nblocks), dim3(AMH_BLOCK), 0, s, B, (const u32*)tmp, nblocks);
 }

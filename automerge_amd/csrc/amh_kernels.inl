@@ -274,13 +274,9 @@ AMH_DEV void k_sha_doc(const BatchDev& B, u32 d) {
   const DocDesc& D = B.desc[d];
   if (D.chunk_len == 0) return;
   const u8* p = B.arena + D.chunk_off;
-  Sha256Dev s;
-  sha_init(s);
-  sha_update(s, p + 8, D.data_off - 8);  // type byte + uleb(len) exactly as stored (strict parse => canonical)
-  sha_update(s, p + D.data_off, D.data_len);
-  u8 h[32];
-  sha_finish(s, h);
-  for (int i = 0; i < 32; i++) B.doc_hash[(u64)d * 32 + i] = h[i];
+  // type byte + uleb(len) exactly as stored (strict parse => canonical) and the data: one contiguous range
+  u8* h = B.doc_hash + (u64)d * 32;
+  sha256_contig(p + 8, (u64)(D.data_off - 8) + D.data_len, h);
   if (h[0] != p[4] || h[1] != p[5] || h[2] != p[6] || h[3] != p[7]) amh_fail(B, d, AMH_E_BAD_CHECKSUM);
 }
 
@@ -406,7 +402,7 @@ AMH_DEV void k_decode_chg(const BatchDev& B, u32 d) {
   delta_init(didx, p, D.ccol[CC_DEPS_IDX].off, D.ccol[CC_DEPS_IDX].len);
   bool has_msg = D.ccol[CC_MESSAGE].len != 0;
   u32 cb = B.chg_base[d], db = B.dep_base[d];
-  u32 ndep = 0;
+  u32 ndep = 0, max_lvl = 0;
   u64 extra_off = 0;
   u64 v; u32 aux; bool isnull; i64 sv;
   for (u32 i = 0; i < C.n_chg; i++) {
@@ -430,13 +426,19 @@ AMH_DEV void k_decode_chg(const BatchDev& B, u32 d) {
     if (rle_next<0>(dnum, v, aux, isnull) != 0 || isnull) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
     B.c_ndeps[c] = (u32)v;
     B.c_dep_base[c] = db + ndep;
+    u32 lvl = 0;
     for (u64 k = 0; k < v; k++) {
       if (ndep >= C.n_deps) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
       if (delta_next(didx, sv, isnull) != 0 || isnull || sv < 0) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
       if ((u64)sv >= i) { amh_fail(B, d, AMH_E_MISSING_CHANGE); return; }  // change_collector.rs:163-177
       B.dep_idx[db + ndep] = (u32)sv;
+      B.c_is_dep[cb + (u32)sv] = 1;
+      u32 dl = B.c_level[cb + (u32)sv] + 1;
+      if (dl > lvl) lvl = dl;
       ndep++;
     }
+    B.c_level[c] = lvl;
+    if (lvl > max_lvl) max_lvl = lvl;
     // extra bytes: must be a Bytes value when present (doc_change_columns.rs:256-270)
     B.c_extra_off[c] = 0;
     B.c_extra_len[c] = 0;
@@ -460,6 +462,8 @@ AMH_DEV void k_decode_chg(const BatchDev& B, u32 d) {
     bool d_none = rle_next<0>(dnum, v, aux, isnull) == 1;
     if (!(s_none || m_none || t_none || d_none)) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
   }
+  B.doc_level[d] = max_lvl;
+  amh_atomic_max(B.max_level, max_lvl);
   // per-actor chains in file order + ordering checks (change_collector.rs:56-62, 105-118)
   u32 ab = B.actor_base[d];
   for (u32 i = 0; i < C.n_chg; i++) {
@@ -1438,86 +1442,104 @@ AMH_DEV void k_encode_store(const BatchDev& B, u32 gid) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K17  assemble every change chunk of a document in file order (deps hashes come from earlier
-//      changes) and hash it — storage/change.rs:460-495, chunk.rs:181-193, 286-293;
-//      change_collector.rs:121-133.  Thread per document.
+// K17  change chunks: header, hash, heads — storage/change.rs:460-495, chunk.rs:181-193, 286-293;
+//      change_collector.rs:121-133, 163-178.
+//   k_chg_header  (thread per change)  everything of the chunk but the dep hashes and the checksum
+//   k_chg_hash    (thread per change of dependency level B.cur_level)  dep hashes (sorted), SHA-256
+//   k_chg_hash_seq(thread per document whose dependency chains are deeper than AMH_LEVEL_CAP) the same, in file order
+//   k_heads       (thread per document)  derived heads against the stored ones
+// A change's level is 1 + the deepest level among its deps (k_decode_chg), so all changes of one
+// level can be hashed at once: their deps were hashed by earlier launches.
 // ------------------------------------------------------------------------------------------
-AMH_DEV void k_assemble_hash(const BatchDev& B, u32 d) {
+#define AMH_LEVEL_CAP 48u
+AMH_DEV void k_chg_header(const BatchDev& B, u32 c) {
+  u32 d = B.c_doc[c];
   if (B.status[d]) return;
   const DocDesc& D = B.desc[d];
   const u8* chunk = B.arena + D.chunk_off;
-  u32 cb = B.chg_base[d], nchg = B.cnt[d].n_chg, ab = B.actor_base[d], na = D.n_actors;
-  for (u32 i = 0; i < nchg; i++) {
-    u32 c = cb + i;
-    u8* out = B.out_arena + B.c_out_off[c];
-    u32 body_len = B.c_body_len[c];
-    u32 hdr = B.c_out_len[c] - body_len;
-    u32 pos = hdr;
-    // deps: hashes of earlier changes, sorted (change_collector.rs:178; change.rs:335-341)
-    u32 nd = B.c_ndeps[c];
-    pos += wr_uleb(out + pos, nd);
-    u8* deps = out + pos;
-    for (u32 k = 0; k < nd; k++) {
-      const u8* h = B.c_hash + (u64)(cb + B.dep_idx[B.c_dep_base[c] + k]) * 32;
-      // insertion sort by bytes
-      u32 j = k;
-      while (j > 0 && amh_memcmp(deps + 32 * (j - 1), 32, h, 32) > 0) {
-        for (int b = 0; b < 32; b++) deps[32 * j + b] = deps[32 * (j - 1) + b];
-        j--;
-      }
-      for (int b = 0; b < 32; b++) deps[32 * j + b] = h[b];
-    }
-    pos += 32 * nd;
-    u32 a = ab + B.c_actor[c];
-    pos += wr_uleb(out + pos, B.actor_len[a]);
-    for (u32 b = 0; b < B.actor_len[a]; b++) out[pos++] = chunk[B.actor_off[a] + b];
-    pos += wr_uleb(out + pos, B.c_seq[c]);
-    pos += wr_uleb(out + pos, B.c_start_op[c]);
-    pos += wr_sleb(out + pos, B.c_time[c]);
-    u32 ml = B.c_msg_len[c] == AMH_NULL32 ? 0 : B.c_msg_len[c];
-    pos += wr_uleb(out + pos, ml);
-    for (u32 b = 0; b < ml; b++) out[pos++] = chunk[B.c_msg_off[c] + b];
-    pos += wr_uleb(out + pos, B.c_n_other[c]);
-    const u32* amap = B.chg_actor_map + B.c_map_base[c];
-    for (u32 k = 0; k < na; k++) {  // other actors in bytewise order
-      u32 oa = B.actor_by_rank[ab + k];
-      if (amap[oa] == AMH_EMPTY32 || amap[oa] == 0) continue;
-      pos += wr_uleb(out + pos, B.actor_len[ab + oa]);
-      for (u32 b = 0; b < B.actor_len[ab + oa]; b++) out[pos++] = chunk[B.actor_off[ab + oa] + b];
-    }
-    const u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
-    u32 ncols = 0, data = 0;
-    for (u32 k = 0; k < AMH_NCOLS; k++) if (cl[k]) ncols++;
-    pos += wr_uleb(out + pos, ncols);
-    for (u32 k = 0; k < AMH_NCOLS; k++)
-      if (cl[k]) { pos += wr_uleb(out + pos, chg_spec(k)); pos += wr_uleb(out + pos, cl[k]); data += cl[k]; }
-    // column data was written by the store pass at c_cols_off
-    pos += data;
-    for (u32 b = 0; b < B.c_extra_len[c]; b++) out[pos++] = chunk[B.c_extra_off[c] + b];
-    // header + hash
-    out[0] = 0x85; out[1] = 0x6f; out[2] = 0x4a; out[3] = 0x83;
-    out[8] = 1;
-    wr_uleb(out + 9, body_len);
-    Sha256Dev s;
-    sha_init(s);
-    sha_update(s, out + 8, hdr - 8);
-    sha_update(s, out + hdr, body_len);
-    u8* h = B.c_hash + (u64)c * 32;
-    sha_finish(s, h);
-    out[4] = h[0]; out[5] = h[1]; out[6] = h[2]; out[7] = h[3];
+  u32 ab = B.actor_base[d], na = D.n_actors;
+  u8* out = B.out_arena + B.c_out_off[c];
+  u32 body_len = B.c_body_len[c];
+  u32 hdr = B.c_out_len[c] - body_len;
+  u32 pos = hdr;
+  u32 nd = B.c_ndeps[c];
+  pos += wr_uleb(out + pos, nd);
+  pos += 32 * nd;   // filled in by k_chg_hash
+  u32 a = ab + B.c_actor[c];
+  pos += wr_uleb(out + pos, B.actor_len[a]);
+  for (u32 b = 0; b < B.actor_len[a]; b++) out[pos++] = chunk[B.actor_off[a] + b];
+  pos += wr_uleb(out + pos, B.c_seq[c]);
+  pos += wr_uleb(out + pos, B.c_start_op[c]);
+  pos += wr_sleb(out + pos, B.c_time[c]);
+  u32 ml = B.c_msg_len[c] == AMH_NULL32 ? 0 : B.c_msg_len[c];
+  pos += wr_uleb(out + pos, ml);
+  for (u32 b = 0; b < ml; b++) out[pos++] = chunk[B.c_msg_off[c] + b];
+  pos += wr_uleb(out + pos, B.c_n_other[c]);
+  const u32* amap = B.chg_actor_map + B.c_map_base[c];
+  for (u32 k = 0; k < na; k++) {  // other actors in bytewise order
+    u32 oa = B.actor_by_rank[ab + k];
+    if (amap[oa] == AMH_EMPTY32 || amap[oa] == 0) continue;
+    pos += wr_uleb(out + pos, B.actor_len[ab + oa]);
+    for (u32 b = 0; b < B.actor_len[ab + oa]; b++) out[pos++] = chunk[B.actor_off[ab + oa] + b];
   }
+  const u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
+  u32 ncols = 0, data = 0;
+  for (u32 k = 0; k < AMH_NCOLS; k++) if (cl[k]) ncols++;
+  pos += wr_uleb(out + pos, ncols);
+  for (u32 k = 0; k < AMH_NCOLS; k++)
+    if (cl[k]) { pos += wr_uleb(out + pos, chg_spec(k)); pos += wr_uleb(out + pos, cl[k]); data += cl[k]; }
+  pos += data;  // column data was written by the store pass at c_cols_off
+  for (u32 b = 0; b < B.c_extra_len[c]; b++) out[pos++] = chunk[B.c_extra_off[c] + b];
+  out[0] = 0x85; out[1] = 0x6f; out[2] = 0x4a; out[3] = 0x83;
+  out[8] = 1;
+  wr_uleb(out + 9, body_len);
+}
+AMH_DEV void chg_hash_one(const BatchDev& B, u32 c, u32 cb) {
+  u8* out = B.out_arena + B.c_out_off[c];
+  u32 body_len = B.c_body_len[c];
+  u32 hdr = B.c_out_len[c] - body_len;
+  u32 nd = B.c_ndeps[c];
+  u8* deps = out + hdr + uleb_size(nd);
+  // deps: hashes of earlier changes, sorted (change_collector.rs:178; change.rs:335-341)
+  for (u32 k = 0; k < nd; k++) {
+    const u8* h = B.c_hash + (u64)(cb + B.dep_idx[B.c_dep_base[c] + k]) * 32;
+    u32 j = k;
+    while (j > 0 && amh_memcmp(deps + 32 * (j - 1), 32, h, 32) > 0) {
+      for (int b = 0; b < 32; b++) deps[32 * j + b] = deps[32 * (j - 1) + b];
+      j--;
+    }
+    for (int b = 0; b < 32; b++) deps[32 * j + b] = h[b];
+  }
+  u8* h = B.c_hash + (u64)c * 32;
+  sha256_contig(out + 8, (u64)(hdr - 8) + body_len, h);
+  out[4] = h[0]; out[5] = h[1]; out[6] = h[2]; out[7] = h[3];
+}
+// bucket of a change in the level sort: its level, or AMH_LEVEL_CAP = "not hashed by k_chg_hash"
+AMH_DEV u32 chg_level_bucket(const BatchDev& B, u32 c) {
+  u32 d = B.c_doc[c];
+  if (B.status[d] || B.doc_level[d] >= AMH_LEVEL_CAP) return AMH_LEVEL_CAP;
+  return B.c_level[c];
+}
+AMH_DEV void k_chg_hash(const BatchDev& B, u32 i) {   // i-th change of the current level (lvl_order is grouped by level)
+  u32 c = B.lvl_order[B.cur_level + i];
+  chg_hash_one(B, c, B.chg_base[B.c_doc[c]]);
+}
+AMH_DEV void k_chg_hash_seq(const BatchDev& B, u32 d) {
+  if (B.status[d] || B.doc_level[d] < AMH_LEVEL_CAP) return;
+  u32 cb = B.chg_base[d], nchg = B.cnt[d].n_chg;
+  for (u32 i = 0; i < nchg; i++) chg_hash_one(B, cb + i, cb);
+}
+AMH_DEV void k_heads(const BatchDev& B, u32 d) {
+  if (B.status[d]) return;
+  const DocDesc& D = B.desc[d];
+  const u8* chunk = B.arena + D.chunk_off;
+  u32 cb = B.chg_base[d], nchg = B.cnt[d].n_chg;
   // heads: hashes nobody depends on, compared as a set with the stored heads
   // (change_collector.rs:121-133; reconstruct_document.rs:211-221)
   u32 derived = 0;
   bool ok = true;
   for (u32 i = 0; i < nchg && ok; i++) {
-    bool is_dep = false;
-    for (u32 j = i + 1; j < nchg && !is_dep; j++) {
-      u32 c2 = cb + j;
-      for (u32 k = 0; k < B.c_ndeps[c2]; k++) if (B.dep_idx[B.c_dep_base[c2] + k] == i) { is_dep = true; break; }
-    }
-    if (is_dep) continue;
-    // distinct hashes only (BTreeSet): skip if an earlier head has the same hash
+    if (B.c_is_dep[cb + i]) continue;
     const u8* h = B.c_hash + (u64)(cb + i) * 32;
     derived++;
     bool found = false;
@@ -1596,6 +1618,7 @@ AMH_DEV void k_extract(const BatchDev& B, u32 d) {
   B.map_base[d] = m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)m;
   B.doc_max_op[d] = 0;
   B.heads_ok[d] = 0;
+  B.doc_level[d] = 0;
 }
 AMH_DEV void k_chg_init(const BatchDev& B, u32 c) {
   u32 d = find_doc(B.chg_base, B.n_docs, c);
@@ -1606,4 +1629,6 @@ AMH_DEV void k_chg_init(const BatchDev& B, u32 c) {
   B.c_ndeps[c] = 0;
   B.c_extra_len[c] = 0;
   B.c_msg_len[c] = AMH_NULL32;
+  B.c_level[c] = 0;
+  B.c_is_dep[c] = 0;
 }

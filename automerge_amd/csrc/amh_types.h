@@ -81,6 +81,11 @@ struct BatchDev {
   u32 n_docs;
   u32 tot_rows, tot_succ, tot_chg, tot_deps, tot_actors, tot_dt, tot_ops;
   u32 check_heads;         // VerificationMode::Check (reconstruct_document.rs:86-90)
+  u32 cur_level;           // start, in lvl_order, of the dependency level hashed by the current k_chg_hash launch
+  u32* lvl_order;          // [tot_chg] changes grouped by dependency level
+  u32* lvl_start;          // [AMH_LEVEL_CAP + 2] start of each level in lvl_order
+  u32* max_level;          // [1] deepest dependency level in the batch
+  u32* doc_level;          // [n_docs] deepest level per document
   const u8* arena;
   const u64* doc_off;      // [2 * n_docs] (start, end) byte range of each input in the arena
   i32* status;             // [n_docs]
@@ -110,6 +115,8 @@ struct BatchDev {
   u64* c_start_op;
   u32* c_op_base;                // [tot_chg + 1] slot base in ops_sorted
   u32* c_next_same_actor;
+  u32* c_level;                  // dependency depth of the change inside its document
+  u8* c_is_dep;                  // some later change lists it as a dep (not a head)
   u8* c_hash;                    // [tot_chg * 32]
   u32* c_out_off;                // [tot_chg + 1] offset of the re-derived change chunk in out_arena
   u32 *c_out_len, *c_body_len, *c_cols_off;

@@ -54,7 +54,10 @@ def algorithmic_bytes(st, cols):
         "encode_size": 44 * T + 56 * C,                      # SURVEY 8d re-encode: 44 + E' (size pass: no E')
         "chg_layout": 100 * C,
         "encode_store": 44 * T + Eout,
-        "assemble_hash": 2 * Eout + 32 * C,
+        "chg_header": 100 * C,
+        "chg_hash": Eout + 32 * C + 4 * C * 5,
+        "chg_hash_seq": Eout,
+        "heads": 64 * C + 40 * D,
         "visible": 12 * R + 2 * R,
         "scan": 8 * (9 * D + 2 * C + T),
     }

@@ -15,7 +15,7 @@ void amh_launch(int k, const BatchDev& B, u32 n, void*) {
     L(AK_BUCKET, k_bucket) L(AK_CHG_FINISH, k_chg_finish) L(AK_PLACE, k_place) L(AK_PRED_SLOT_CNT, k_pred_slot_cnt) L(AK_PRED_SLOT_BASE, k_pred_slot_base) L(AK_PRED_FILL, k_pred_fill)
     L(AK_PRED_SORT, k_pred_sort) L(AK_ACTOR_MARK, k_actor_mark) L(AK_ACTOR_RANK, k_actor_rank) L(AK_CHANGE_VIEW, k_change_view)
     L(AK_ENCODE_SIZE, k_encode_size) L(AK_CHG_LAYOUT, k_chg_layout) L(AK_ENCODE_STORE, k_encode_store)
-    L(AK_ASSEMBLE_HASH, k_assemble_hash) L(AK_VISIBLE, k_visible)
+    L(AK_CHG_HEADER, k_chg_header) L(AK_CHG_HASH, k_chg_hash) L(AK_CHG_HASH_SEQ, k_chg_hash_seq) L(AK_HEADS, k_heads) L(AK_VISIBLE, k_visible)
     default: break;
   }
 #undef L
@@ -29,4 +29,12 @@ void amh_scan_inplace(u32* data, u32 n, u32*, void*) {
     run += v;
   }
   data[n] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)run;
+}
+u32 amh_level_sort_tmp_words(u32) { return 2; }
+void amh_level_sort(const BatchDev& B, u32*, void*) {
+  u32 cnt[AMH_LEVEL_CAP + 2] = {0};
+  for (u32 c = 0; c < B.tot_chg; c++) cnt[chg_level_bucket(B, c) + 1]++;
+  for (u32 l = 0; l <= AMH_LEVEL_CAP; l++) cnt[l + 1] += cnt[l];
+  for (u32 l = 0; l <= AMH_LEVEL_CAP + 1; l++) B.lvl_start[l] = cnt[l];
+  for (u32 c = 0; c < B.tot_chg; c++) B.lvl_order[cnt[chg_level_bucket(B, c)]++] = c;
 }

@@ -90,3 +90,15 @@ def test_empty_and_ragged_batch(emu):
     assert batch.status(3)[0] != 0
     compare(batch, 4, docs[4])
     assert len(emu.load_batch([])) == 0
+
+
+def test_deep_dependency_chains(emu):
+    """more dependency levels than the level-parallel hashing handles (AMH_LEVEL_CAP): sequential per-document hashing"""
+    blob, offs = emu.gen_text_docs(0xD070, 2, 2, 20, 600, 10, 2)
+    docs = [blob[offs[i]:offs[i + 1]] for i in range(4)]
+    blob2, offs2 = emu.gen_map_docs(11, 3, 3, 4, 20, 16, 2)   # shallow documents in the same batch
+    docs += [blob2[offs2[i]:offs2[i + 1]] for i in range(3)]
+    batch = emu.load_batch(docs)
+    for i, d in enumerate(docs):
+        compare(batch, i, d)
+    assert len(batch.get_changes(0)) == 61

@@ -116,3 +116,15 @@ def test_device_arrays_match_host_emulation(engine, golden_dir):
     for name in sys_names:
         a, b = fetch(engine.lib, bg.h, name), fetch(emu.lib, be.h, name)
         assert a.shape == b.shape and np.array_equal(a, b), name
+
+
+def test_deep_dependency_chains(engine):
+    """more dependency levels than the level-parallel hashing handles (AMH_LEVEL_CAP): sequential per-document hashing"""
+    blob, offs = engine.gen_text_docs(0xD070, 2, 2, 20, 600, 10, 2)
+    docs = [blob[offs[i]:offs[i + 1]] for i in range(4)]
+    blob2, offs2 = engine.gen_map_docs(11, 3, 3, 4, 20, 16, 2)   # shallow documents in the same batch
+    docs += [blob2[offs2[i]:offs2[i + 1]] for i in range(3)]
+    batch = engine.load_batch(docs)
+    for i, d in enumerate(docs):
+        _compare(batch, i, d)
+    assert len(batch.get_changes(0)) == 61
