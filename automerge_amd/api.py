@@ -107,6 +107,21 @@ class EngineError(Exception):
     pass
 
 
+def parse_sync_summaries(raw):
+    import struct
+    out, pos = [], 0
+    while pos < len(raw):
+        doc, status, nh = struct.unpack_from("<III", raw, pos)
+        pos += 12
+        heads = [raw[pos + 32 * k:pos + 32 * k + 32] for k in range(nh)]
+        pos += 32 * nh
+        (bl,) = struct.unpack_from("<I", raw, pos)
+        pos += 4
+        out.append(dict(doc=doc, status=status, heads=heads, bloom=raw[pos:pos + bl]))
+        pos += bl
+    return out
+
+
 class Batch:
     """N loaded documents (amh_batch)."""
 
@@ -188,6 +203,20 @@ class Batch:
         if rc != 0:
             raise EngineError(f"amh_doc_max_op failed: {rc}")
         return v.value
+
+    def sync_summaries_raw(self):
+        """All sync summary records of the batch as one bytes object (amh_sync_summaries)."""
+        o = BytesOut()
+        rc = self.engine.lib.amh_sync_summaries(self.engine.ctx, self.h, C.byref(o))
+        if rc != 0:
+            raise EngineError(f"amh_sync_summaries failed: {rc} {self.engine._err()}")
+        raw = C.string_at(o.data, o.len) if o.len else b""
+        self.engine.lib.amh_bytes_free(C.byref(o))
+        return raw
+
+    def sync_summaries(self):
+        """Per document: dict(doc, status, heads=[32-byte hashes, sorted], bloom=bytes) — get_heads + make_bloom_filter(last_sync=[])."""
+        return parse_sync_summaries(self.sync_summaries_raw())
 
     def stats(self):
         s = BatchStats()

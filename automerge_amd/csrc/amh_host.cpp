@@ -836,9 +836,30 @@ extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch*, const amh_save_opt
   set_error(ctx, "amh_save_batch: not implemented in this round");
   return AMH_ERR_UNIMPLEMENTED;
 }
-extern "C" int amh_sync_summaries(amh_ctx* ctx, const amh_batch*, amh_bytes_out*) {
-  set_error(ctx, "amh_sync_summaries: not implemented in this round");
-  return AMH_ERR_UNIMPLEMENTED;
+extern "C" int amh_sync_summaries(amh_ctx* ctx, const amh_batch* bc, amh_bytes_out* out) {
+  if (!ctx || !bc || !out) { set_error(ctx, "invalid argument"); return AMH_ERR_INVALID_ARG; }
+  amh_batch* b = const_cast<amh_batch*>(bc);
+  BatchDev B = b->B;
+  u32 n = B.n_docs;
+  out->data = nullptr;
+  out->len = 0;
+  if (n == 0) return AMH_SUCCESS;
+  bool ok = true;
+  B.sync_off = balloc<u32>(b, n + 2, &ok);
+  if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  launch(ctx, AK_SYNC_SIZE, B, n);
+  u32 total = 0;
+  if (!scan_inplace(b, B.sync_off, n, &total)) { set_error(ctx, "scan failed"); return AMH_ERR_DEVICE; }
+  if (total == 0xFFFFFFFFu) { set_error(ctx, "sync summaries exceed 4 GiB"); return AMH_ERR_BATCH_TOO_LARGE; }
+  B.sync_out = balloc<u8>(b, (size_t)total + 64, &ok);
+  if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  launch(ctx, AK_SYNC_FILL, B, n);
+  out->data = (uint8_t*)malloc(total ? total : 1);
+  if (!out->data) return AMH_ERR_OOM;
+  if (!rt_d2h(out->data, B.sync_out, total, ctx->stream)) { free(out->data); out->data = nullptr; set_error(ctx, "D2H copy failed"); return AMH_ERR_DEVICE; }
+  out->len = total;
+  collect_profile(ctx);
+  return AMH_SUCCESS;
 }
 
 // ---------------------------------------------------------------------------------------------

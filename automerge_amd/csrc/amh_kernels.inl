@@ -1598,6 +1598,71 @@ AMH_DEV void k_visible(const BatchDev& B, u32 r) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K19  sync summaries: sorted heads (automerge.rs:1300-1304) and the Bloom filter over every change
+//      hash of the document (sync.rs:243-250 with last_sync = [], sync/bloom.rs:9-10, 38-47, 69-102,
+//      125-146).  Record: u32 doc, u32 status, u32 n_heads, heads[32 x n], u32 bloom_len, bloom bytes.
+//      Thread per document: k_sync_size -> record sizes (scanned into sync_off), k_sync_fill.
+// ------------------------------------------------------------------------------------------
+AMH_DEV u32 bloom_wire_len(u32 n) {  // uleb(n) uleb(10) uleb(7) + ceil(10 n / 8) bytes; nothing for an empty filter
+  return n ? uleb_size(n) + 2 + (u32)(((u64)n * 10 + 7) / 8) : 0;
+}
+AMH_DEV void k_sync_size(const BatchDev& B, u32 d) {
+  u32 nh = 0, nc = 0;
+  if (B.status[d] == 0) {
+    nc = B.cnt[d].n_chg;
+    u32 cb = B.chg_base[d];
+    for (u32 i = 0; i < nc; i++) if (!B.c_is_dep[cb + i]) nh++;
+  }
+  B.sync_off[d] = 12 + 32 * nh + 4 + bloom_wire_len(nc);
+}
+AMH_DEV void sync_put32(u8* o, u32 v) { o[0] = (u8)v; o[1] = (u8)(v >> 8); o[2] = (u8)(v >> 16); o[3] = (u8)(v >> 24); }
+AMH_DEV void k_sync_fill(const BatchDev& B, u32 d) {
+  u8* o = B.sync_out + B.sync_off[d];
+  u32 rec_len = B.sync_off[d + 1] - B.sync_off[d];
+  sync_put32(o, d);
+  sync_put32(o + 4, (u32)B.status[d]);
+  u32 nh = 0, nc = 0, cb = 0;
+  if (B.status[d] == 0) { nc = B.cnt[d].n_chg; cb = B.chg_base[d]; }
+  u8* hs = o + 12;
+  for (u32 i = 0; i < nc; i++) {   // heads in ascending hash order (BTreeSet<ChangeHash>)
+    if (B.c_is_dep[cb + i]) continue;
+    const u8* h = B.c_hash + (u64)(cb + i) * 32;
+    u32 j = nh;
+    while (j > 0 && amh_memcmp(hs + 32 * (j - 1), 32, h, 32) > 0) {
+      for (int b = 0; b < 32; b++) hs[32 * j + b] = hs[32 * (j - 1) + b];
+      j--;
+    }
+    for (int b = 0; b < 32; b++) hs[32 * j + b] = h[b];
+    nh++;
+  }
+  sync_put32(o + 8, nh);
+  u8* bl = hs + 32 * nh;
+  u32 blen = bloom_wire_len(nc);
+  sync_put32(bl, blen);
+  bl += 4;
+  if (blen && 12 + 32 * nh + 4 + blen == rec_len) {
+    u32 pos = wr_uleb(bl, nc);
+    bl[pos++] = 10;
+    bl[pos++] = 7;
+    u8* bits = bl + pos;
+    u32 nbytes = blen - pos, modulo = 8 * nbytes;
+    for (u32 i = 0; i < nbytes; i++) bits[i] = 0;
+    for (u32 i = 0; i < nc; i++) {
+      const u8* h = B.c_hash + (u64)(cb + i) * 32;
+      u32 x = ((u32)h[0] | ((u32)h[1] << 8) | ((u32)h[2] << 16) | ((u32)h[3] << 24)) % modulo;
+      u32 y = ((u32)h[4] | ((u32)h[5] << 8) | ((u32)h[6] << 16) | ((u32)h[7] << 24)) % modulo;
+      u32 z = ((u32)h[8] | ((u32)h[9] << 8) | ((u32)h[10] << 16) | ((u32)h[11] << 24)) % modulo;
+      bits[x >> 3] |= (u8)(1u << (x & 7));
+      for (u32 k = 1; k < 7; k++) {
+        x = (u32)(((u64)x + y) % modulo);
+        y = (u32)(((u64)y + z) % modulo);
+        bits[x >> 3] |= (u8)(1u << (x & 7));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // small glue kernels
 // ------------------------------------------------------------------------------------------
 AMH_DEV u32 amh_pow2_at_least(u32 v) { u32 p = 1; while (p < v) p <<= 1; return p; }

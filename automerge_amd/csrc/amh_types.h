@@ -158,4 +158,6 @@ struct BatchDev {
   // 8 value meta lo  9 value meta hi | kind << 8  10, 11 raw offset + length, or the i64 of a re-encoded increment
   u32* cv[12];
   u8* out_arena;                 // re-derived change chunks
+  u32* sync_off;                 // [n_docs + 1] record offsets of the sync summaries
+  u8* sync_out;
 };

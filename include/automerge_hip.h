@@ -150,7 +150,8 @@ int amh_save_batch(amh_ctx*, const amh_batch*, const amh_save_opts*, amh_bytes_o
 /* ---- sync summaries ---------------------------------------------------------------------------
  * per document: sorted heads (get_heads) + Bloom filter over all change hashes
  * (sync.rs:243-250 make_bloom_filter with last_sync = [], sync/bloom.rs:38-47,69-90,125-146).
- * Record layout per document: u32 doc, u32 n_heads, heads[32 x n], u32 bloom_len, bloom bytes.
+ * Record layout per document (little-endian): u32 doc, u32 status (0 = loaded), u32 n_heads,
+ * heads[32 x n], u32 bloom_len, bloom bytes (BloomFilter::to_bytes: uleb n, uleb 10, uleb 7, bits).
  * The all-gather across ranks is done by the caller's torch.distributed group. */
 int amh_sync_summaries(amh_ctx*, const amh_batch*, amh_bytes_out* out);
 

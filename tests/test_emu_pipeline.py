@@ -102,3 +102,24 @@ def test_deep_dependency_chains(emu):
     for i, d in enumerate(docs):
         compare(batch, i, d)
     assert len(batch.get_changes(0)) == 61
+
+
+def test_sync_summaries(emu, golden_dir):
+    """heads + Bloom filter per document == get_heads / make_bloom_filter(last_sync = []) of the oracle; a failed
+    document gets a record with its status and no heads"""
+    import oracle_lib as o
+    docs = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(golden_dir, "docs", "*.automerge")))[:20]]
+    blob, offs = emu.gen_map_docs(21, 6, 4, 5, 10, 16, 2)
+    docs += [blob[offs[i]:offs[i + 1]] for i in range(6)] + [b"", b"\x85\x6f\x4a\x83garbage"]
+    batch = emu.load_batch(docs)
+    recs = batch.sync_summaries()
+    assert len(recs) == len(docs)
+    for i, (d, rec) in enumerate(zip(docs, recs)):
+        assert rec["doc"] == i
+        if i == len(docs) - 1:
+            assert rec["status"] != 0 and rec["heads"] == [] and rec["bloom"] == b""
+            continue
+        ref = o.Doc.load(d)
+        assert rec["status"] == 0
+        assert rec["heads"] == ref.get_heads() == batch.get_heads(i)
+        assert rec["bloom"] == ref.bloom()
