@@ -22,6 +22,10 @@ class ChangeView(C.Structure):
                 ("num_deps", C.c_uint32)]
 
 
+class SaveOpts(C.Structure):
+    _fields_ = [("deflate", C.c_int), ("retain_orphans", C.c_int)]
+
+
 class LoadOpts(C.Structure):
     _fields_ = [("verify_heads", C.c_int), ("on_partial_load", C.c_int)]
 
@@ -83,6 +87,7 @@ def bind(lib):
                                       C.POINTER(BytesOut), C.POINTER(C.POINTER(C.c_uint64))]
     lib.amh_u64_free.argtypes = [C.POINTER(C.c_uint64)]
     lib.amh_sync_summaries.argtypes = [vp, vp, C.POINTER(BytesOut)]
+    lib.amh_save_batch.argtypes = [vp, vp, C.POINTER(SaveOpts), C.POINTER(BytesOut)]
     return lib
 
 
@@ -203,6 +208,19 @@ class Batch:
         if rc != 0:
             raise EngineError(f"amh_doc_max_op failed: {rc}")
         return v.value
+
+    def save_all(self, deflate=True):
+        """== Automerge::save_with_options per document (automerge.rs:943); None for documents without a saved form."""
+        opts = SaveOpts(1 if deflate else 0, 1)
+        outs = (BytesOut * max(1, self.n))()
+        rc = self.engine.lib.amh_save_batch(self.engine.ctx, self.h, C.byref(opts), outs)
+        if rc != 0:
+            raise EngineError(f"amh_save_batch failed: {rc} {self.engine._err()}")
+        res = []
+        for i in range(self.n):
+            res.append(C.string_at(outs[i].data, outs[i].len) if outs[i].data else None)
+            self.engine.lib.amh_bytes_free(C.byref(outs[i]))
+        return res
 
     def sync_summaries_raw(self):
         """All sync summary records of the batch as one bytes object (amh_sync_summaries)."""

@@ -832,9 +832,51 @@ extern "C" int amh_apply_changes(amh_ctx* ctx, amh_batch*, uint32_t, const uint8
   set_error(ctx, "amh_apply_changes: not implemented in this round");
   return AMH_ERR_UNIMPLEMENTED;
 }
-extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch*, const amh_save_opts*, amh_bytes_out*) {
-  set_error(ctx, "amh_save_batch: not implemented in this round");
-  return AMH_ERR_UNIMPLEMENTED;
+extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch* bc, const amh_save_opts* opts, amh_bytes_out* out) {
+  if (!ctx || !bc || !out) { set_error(ctx, "invalid argument"); return AMH_ERR_INVALID_ARG; }
+  amh_batch* b = const_cast<amh_batch*>(bc);
+  BatchDev B = b->B;
+  u32 n = B.n_docs;
+  for (u32 d = 0; d < n; d++) { out[d].data = nullptr; out[d].len = 0; }
+  if (n == 0) return AMH_SUCCESS;
+  bool ok = true;
+  B.sv_status = balloc<i32>(b, n + 1, &ok);
+  B.sv_col_len = balloc<u32>(b, (size_t)n * 25 + 1, &ok);
+  B.sv_body_len = balloc<u32>(b, n + 1, &ok);
+  B.sv_off = balloc<u32>(b, n + 2, &ok);
+  if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  launch(ctx, AK_SAVE_CHECK, B, n);
+  launch(ctx, AK_SAVE_SIZE, B, n * 25);
+  launch(ctx, AK_SAVE_LAYOUT, B, n);
+  u32 total = 0;
+  if (!scan_inplace(b, B.sv_off, n, &total)) { set_error(ctx, "scan failed"); return AMH_ERR_DEVICE; }
+  if (total == 0xFFFFFFFFu) { set_error(ctx, "saved documents exceed 4 GiB: save the batch in parts"); return AMH_ERR_BATCH_TOO_LARGE; }
+  B.sv_out = balloc<u8>(b, (size_t)total + 256, &ok);
+  if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  launch(ctx, AK_SAVE_STORE, B, n * 25);
+  launch(ctx, AK_SAVE_FINISH, B, n);
+  std::vector<u8> host((size_t)total);
+  std::vector<u32> off(n + 1);
+  std::vector<i32> st(n);
+  if (!rt_d2h(host.data(), B.sv_out, total, ctx->stream) || !rt_d2h(off.data(), B.sv_off, (n + 1) * sizeof(u32), ctx->stream) ||
+      !rt_d2h(st.data(), B.sv_status, n * sizeof(i32), ctx->stream)) {
+    set_error(ctx, "D2H copy failed");
+    return AMH_ERR_DEVICE;
+  }
+  collect_profile(ctx);
+  bool deflate = opts ? opts->deflate != 0 : true;
+  for (u32 d = 0; d < n; d++) {
+    if (st[d] != 0) continue;   // failed to load, or a shape save does not handle: no bytes (amh_doc_status / amh_save_status)
+    size_t len = off[d + 1] - off[d];
+    const u8* src = host.data() + off[d];
+    std::vector<u8> z;
+    if (deflate && amh_host_deflate_document(src, len, z)) { src = z.data(); len = z.size(); }
+    out[d].data = (uint8_t*)malloc(len ? len : 1);
+    if (!out[d].data) return AMH_ERR_OOM;
+    memcpy(out[d].data, src, len);
+    out[d].len = len;
+  }
+  return AMH_SUCCESS;
 }
 extern "C" int amh_sync_summaries(amh_ctx* ctx, const amh_batch* bc, amh_bytes_out* out) {
   if (!ctx || !bc || !out) { set_error(ctx, "invalid argument"); return AMH_ERR_INVALID_ARG; }

@@ -118,3 +118,85 @@ bool amh_ingest_normalise(const u8* p, size_t len, std::vector<u8>& out) {
   out.insert(out.end(), body.begin(), body.end());
   return true;
 }
+
+static bool deflate_raw(const u8* src, size_t n, std::vector<u8>& out) {
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+  zs.next_in = const_cast<Bytef*>(src);
+  zs.avail_in = (uInt)n;
+  u8 buf[16384];
+  int rc;
+  do {
+    zs.next_out = buf;
+    zs.avail_out = sizeof(buf);
+    rc = deflate(&zs, Z_FINISH);
+    out.insert(out.end(), buf, buf + (sizeof(buf) - zs.avail_out));
+  } while (rc == Z_OK || rc == Z_BUF_ERROR);
+  deflateEnd(&zs);
+  return rc == Z_STREAM_END;
+}
+
+// SaveOptions::deflate (automerge.rs:1816-1830): every column of at least 256 bytes is raw-DEFLATEd and
+// gets the deflate bit, then the chunk is re-hashed over the compressed body
+// (storage/document/compression.rs:29-49, 346-355; raw_column.rs:49-62).  Host side by design
+// (SURVEY.md 8a row a22); the compressed bytes are zlib's, not flate2's: parity unpinned.
+bool amh_host_deflate_document(const u8* p, size_t len, std::vector<u8>& out) {
+  if (len < 10 || p[8] != 0) return false;
+  u64 pos = 9, end = len, dlen;
+  if (rd_uleb_strict(p, pos, end, dlen) || dlen != end - pos) return false;
+  u64 data_off = pos, n;
+  if (rd_uleb_strict(p, pos, end, n)) return false;
+  for (u64 i = 0; i < n; i++) { u64 al; if (rd_uleb_strict(p, pos, end, al) || al > end - pos) return false; pos += al; }
+  if (rd_uleb_strict(p, pos, end, n) || n > (end - pos) / 32) return false;
+  pos += 32 * n;
+  u64 prefix_end = pos;
+  struct Col { u32 spec; u64 len; };
+  std::vector<Col> cols[2];
+  for (int w = 0; w < 2; w++) {
+    u64 nc;
+    if (rd_uleb_strict(p, pos, end, nc) || nc > end - pos) return false;
+    for (u64 i = 0; i < nc; i++) {
+      u64 spec, cl;
+      if (rd_uleb_strict(p, pos, end, spec) || rd_uleb_strict(p, pos, end, cl) || cl > end) return false;
+      cols[w].push_back(Col{(u32)spec, cl});
+    }
+  }
+  std::vector<u8> data[2];
+  bool any = false;
+  for (int w = 0; w < 2; w++)
+    for (auto& c : cols[w]) {
+      if (c.len > end - pos) return false;
+      if (c.len >= 256 && !(c.spec & 8)) {
+        size_t before = data[w].size();
+        if (!deflate_raw(p + pos, c.len, data[w])) return false;
+        pos += c.len;
+        c.spec |= 8;
+        c.len = data[w].size() - before;
+        any = true;
+      } else {
+        data[w].insert(data[w].end(), p + pos, p + pos + c.len);
+        pos += c.len;
+      }
+    }
+  if (!any) return false;
+  std::vector<u8> body(p + data_off, p + prefix_end);
+  for (int w = 0; w < 2; w++) {
+    push_uleb(body, cols[w].size());
+    for (auto& c : cols[w]) { push_uleb(body, c.spec); push_uleb(body, c.len); }
+  }
+  body.insert(body.end(), data[0].begin(), data[0].end());
+  body.insert(body.end(), data[1].begin(), data[1].end());
+  body.insert(body.end(), p + pos, p + end);
+  std::vector<u8> pre;
+  pre.push_back(0);
+  push_uleb(pre, body.size());
+  u8 h[32];
+  amh_host_sha256(pre.data(), pre.size(), body.data(), body.size(), h);
+  out.clear();
+  out.insert(out.end(), p, p + 4);
+  out.insert(out.end(), h, h + 4);
+  out.insert(out.end(), pre.begin(), pre.end());
+  out.insert(out.end(), body.begin(), body.end());
+  return true;
+}

@@ -1663,6 +1663,278 @@ AMH_DEV void k_sync_fill(const BatchDev& B, u32 d) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K20  save: the document chunk of every loaded document — automerge.rs:943-965,
+//      storage/save/document.rs:21-148, storage/document.rs:214-263, doc_op_columns.rs:104-311,
+//      doc_change_columns.rs:87-162, convert/op_as_docop.rs:23-162, indexed_cache.rs:72-107.
+//   k_save_size   (thread per (document, column))  column sizes -> sv_col_len
+//   k_save_layout (thread per document)            chunk size -> sv_off (scanned)
+//   k_save_store  (thread per (document, column))  column bytes
+//   k_save_finish (thread per document)            actors, heads, column metadata, head indices, header + SHA-256
+//   Columns 0..8 = change metadata, 9..24 = ops.  Actor numbers are ranks in the bytewise-sorted table.
+// ------------------------------------------------------------------------------------------
+#define AMH_SV_CHG_COLS 9
+#define AMH_SV_NCOLS 25
+AMH_DEV u32 sv_spec(u32 col) {
+  const u32 specs[AMH_SV_NCOLS] = {0x01, 0x03, 0x13, 0x23, 0x35, 0x40, 0x43, 0x56, 0x57,
+                                   0x01, 0x02, 0x11, 0x13, 0x15, 0x21, 0x23, 0x34, 0x42, 0x56, 0x57, 0x80, 0x81, 0x83, 0x94, 0xA5};
+  return specs[col];
+}
+// k-th dep of change c in the order of the deps' hashes (save/document.rs:141-146: deps() is sorted by hash)
+AMH_DEV u32 sv_dep_sorted(const BatchDev& B, u32 c, u32 cb, u32 k) {
+  u32 nd = B.c_ndeps[c];
+  const u32* di = B.dep_idx + B.c_dep_base[c];
+  for (u32 a = 0; a < nd; a++) {   // the dep with exactly k deps ordered before it
+    const u8* ha = B.c_hash + (u64)(cb + di[a]) * 32;
+    u32 before = 0;
+    for (u32 b = 0; b < nd; b++) {
+      if (b == a) continue;
+      int cmp = amh_memcmp(B.c_hash + (u64)(cb + di[b]) * 32, 32, ha, 32);
+      if (cmp < 0 || (cmp == 0 && b < a)) before++;
+    }
+    if (before == k) return di[a];
+  }
+  return 0;
+}
+AMH_DEV u32 save_encode_col(const BatchDev& B, u32 d, u32 col, u8* out) {
+  const DocDesc& D = B.desc[d];
+  const u8* chunk = B.arena + D.chunk_off;
+  const u32* rank = B.actor_rank + B.actor_base[d];
+  ColWriter w; w.out = out; w.pos = 0;
+  RleVal x; x.v = 0; x.s = 0; x.n = 0;
+  if (col < AMH_SV_CHG_COLS) {
+    u32 cb = B.chg_base[d], n = B.cnt[d].n_chg;
+    switch (col) {
+      case 0: { RleEnc<0> e; re_init(e); for (u32 i = 0; i < n; i++) { x.v = rank[B.c_actor[cb + i]]; re_value(w, e, x); } re_finish(w, e); break; }
+      case 1: { DeltaEnc e; re_init(e.r); e.abs = 0; for (u32 i = 0; i < n; i++) de_value(w, e, (i64)B.c_seq[cb + i]); re_finish(w, e.r); break; }
+      case 2: { DeltaEnc e; re_init(e.r); e.abs = 0; for (u32 i = 0; i < n; i++) de_value(w, e, (i64)B.c_max_op[cb + i]); re_finish(w, e.r); break; }
+      case 3: { DeltaEnc e; re_init(e.r); e.abs = 0; for (u32 i = 0; i < n; i++) de_value(w, e, B.c_time[cb + i]); re_finish(w, e.r); break; }
+      case 4: {
+        RleEnc<2> e; re_init(e);
+        for (u32 i = 0; i < n; i++) {
+          u32 ml = B.c_msg_len[cb + i];
+          if (ml == AMH_NULL32 || ml == 0) re_null(w, e);
+          else { RleVal sv; sv.v = 0; sv.s = chunk + B.c_msg_off[cb + i]; sv.n = ml; re_value(w, e, sv); }
+        }
+        re_finish(w, e);
+        break;
+      }
+      case 5: { RleEnc<0> e; re_init(e); for (u32 i = 0; i < n; i++) { x.v = B.c_ndeps[cb + i]; re_value(w, e, x); } re_finish(w, e); break; }
+      case 6: {
+        DeltaEnc e; re_init(e.r); e.abs = 0;
+        for (u32 i = 0; i < n; i++) { u32 nd = B.c_ndeps[cb + i]; for (u32 k = 0; k < nd; k++) de_value(w, e, (i64)sv_dep_sorted(B, cb + i, cb, k)); }
+        re_finish(w, e.r);
+        break;
+      }
+      case 7: { RleEnc<0> e; re_init(e); for (u32 i = 0; i < n; i++) { x.v = ((u64)B.c_extra_len[cb + i] << 4) | 7; re_value(w, e, x); } re_finish(w, e); break; }
+      case 8: { for (u32 i = 0; i < n; i++) cw_bytes(w, chunk + B.c_extra_off[cb + i], B.c_extra_len[cb + i]); break; }
+    }
+    return w.pos;
+  }
+  u32 rb = B.row_base[d], n = B.cnt[d].n_rows;
+  switch (col) {
+    case 9: case 10: {
+      RleEnc<0> e; re_init(e);
+      for (u32 i = 0; i < n; i++) {
+        u32 r = rb + i;
+        if (B.r_obj_ctr[r] == 0) re_null(w, e);
+        else { x.v = col == 9 ? rank[B.r_obj_actor[r]] : B.r_obj_ctr[r]; re_value(w, e, x); }
+      }
+      re_finish(w, e);
+      break;
+    }
+    case 11: {
+      RleEnc<0> e; re_init(e);
+      for (u32 i = 0; i < n; i++) { OpKey k = op_key(B, rb + i); if (k.kind == 2) { x.v = rank[k.actor]; re_value(w, e, x); } else re_null(w, e); }
+      re_finish(w, e);
+      break;
+    }
+    case 12: {
+      DeltaEnc e; re_init(e.r); e.abs = 0;
+      for (u32 i = 0; i < n; i++) { OpKey k = op_key(B, rb + i); if (k.kind == 0) re_null(w, e.r); else de_value(w, e, k.kind == 1 ? 0 : (i64)k.ctr); }
+      re_finish(w, e.r);
+      break;
+    }
+    case 13: {
+      RleEnc<2> e; re_init(e);
+      for (u32 i = 0; i < n; i++) {
+        OpKey k = op_key(B, rb + i);
+        if (k.kind == 0) { RleVal sv; sv.v = 0; sv.s = chunk + k.str_off; sv.n = k.str_len; re_value(w, e, sv); } else re_null(w, e);
+      }
+      re_finish(w, e);
+      break;
+    }
+    case 14: { RleEnc<0> e; re_init(e); for (u32 i = 0; i < n; i++) { x.v = rank[B.r_id_actor[rb + i]]; re_value(w, e, x); } re_finish(w, e); break; }
+    case 15: { DeltaEnc e; re_init(e.r); e.abs = 0; for (u32 i = 0; i < n; i++) de_value(w, e, (i64)B.r_id_ctr[rb + i]); re_finish(w, e.r); break; }
+    case 16: {
+      bool last = false; u64 cnt = 0;
+      for (u32 i = 0; i < n; i++) { bool v = B.r_insert[rb + i] != 0; if (v == last) cnt++; else { cw_uleb(w, cnt); last = v; cnt = 1; } }
+      if (cnt > 0) cw_uleb(w, cnt);
+      break;
+    }
+    case 17: { RleEnc<0> e; re_init(e); for (u32 i = 0; i < n; i++) { x.v = B.r_action[rb + i]; re_value(w, e, x); } re_finish(w, e); break; }
+    case 18: { RleEnc<0> e; re_init(e); for (u32 i = 0; i < n; i++) { OpVal v = op_val(B, rb + i); x.v = v.meta; re_value(w, e, x); } re_finish(w, e); break; }
+    case 19: {
+      for (u32 i = 0; i < n; i++) {
+        OpVal v = op_val(B, rb + i);
+        if (v.kind == 1) cw_bytes(w, v.raw, v.raw_len); else if (v.kind == 2) cw_sleb(w, v.i);
+      }
+      break;
+    }
+    case 20: { RleEnc<0> e; re_init(e); for (u32 i = 0; i < n; i++) { x.v = B.r_succ_cnt[rb + i]; re_value(w, e, x); } re_finish(w, e); break; }
+    case 21: {
+      RleEnc<0> e; re_init(e);
+      u32 sb = B.succ_base[d], ns = B.cnt[d].n_succ;
+      for (u32 i = 0; i < ns; i++) { x.v = rank[B.s_actor[sb + i]]; re_value(w, e, x); }
+      re_finish(w, e);
+      break;
+    }
+    case 22: {
+      DeltaEnc e; re_init(e.r); e.abs = 0;
+      u32 sb = B.succ_base[d], ns = B.cnt[d].n_succ;
+      for (u32 i = 0; i < ns; i++) de_value(w, e, (i64)B.s_ctr[sb + i]);
+      re_finish(w, e.r);
+      break;
+    }
+    case 23: {   // MaybeBoolean (boolean.rs:131-137)
+      bool any = false;
+      for (u32 i = 0; i < n && !any; i++) any = B.r_action[rb + i] == 7 && B.r_expand[rb + i];
+      if (!any) break;
+      bool last = false; u64 cnt = 0;
+      for (u32 i = 0; i < n; i++) { bool v = B.r_action[rb + i] == 7 && B.r_expand[rb + i]; if (v == last) cnt++; else { cw_uleb(w, cnt); last = v; cnt = 1; } }
+      if (cnt > 0) cw_uleb(w, cnt);
+      break;
+    }
+    case 24: {
+      RleEnc<2> e; re_init(e);
+      for (u32 i = 0; i < n; i++) {
+        u32 r = rb + i;
+        if (B.r_action[r] == 7 && B.r_mark_len[r] != AMH_NULL32) { RleVal sv; sv.v = 0; sv.s = chunk + B.r_mark_off[r]; sv.n = B.r_mark_len[r]; re_value(w, e, sv); }
+        else re_null(w, e);
+      }
+      re_finish(w, e);
+      break;
+    }
+  }
+  return w.pos;
+}
+AMH_DEV bool sv_doc_ok(const BatchDev& B, u32 d) { return B.status[d] == 0 && B.sv_status[d] == 0; }
+AMH_DEV void k_save_check(const BatchDev& B, u32 d) {
+  B.sv_status[d] = 0;
+  if (B.status[d]) { B.sv_status[d] = B.status[d]; return; }
+  u32 ab = B.actor_base[d], na = B.desc[d].n_actors;
+  // object runs are kept in file order, which is lamport order only if the stored actor table is sorted
+  for (u32 a = 0; a < na; a++) if (B.actor_rank[ab + a] != a) { B.sv_status[d] = AMH_E_UNSUPPORTED; return; }
+}
+AMH_DEV void k_save_size(const BatchDev& B, u32 gid) {
+  u32 col = gid / B.n_docs, d = gid % B.n_docs;
+  if (col >= AMH_SV_NCOLS) return;
+  B.sv_col_len[(u64)d * AMH_SV_NCOLS + col] = sv_doc_ok(B, d) ? save_encode_col(B, d, col, (u8*)0) : 0;
+}
+AMH_DEV u32 sv_heads(const BatchDev& B, u32 d) {
+  u32 nh = 0, cb = B.chg_base[d], nc = B.cnt[d].n_chg;
+  for (u32 i = 0; i < nc; i++) if (!B.c_is_dep[cb + i]) nh++;
+  return nh;
+}
+AMH_DEV void k_save_layout(const BatchDev& B, u32 d) {
+  B.sv_off[d] = 0;
+  if (!sv_doc_ok(B, d)) return;
+  u32* cl = B.sv_col_len + (u64)d * AMH_SV_NCOLS;
+  if (cl[9] == 0) cl[10] = 0;     // ObjIdRange::encode -> None (obj_id.rs:79-81)
+  if (cl[21] == 0) cl[22] = 0;    // succ actor / ctr only when there are entries (doc_op_columns.rs:286-297)
+  const DocDesc& D = B.desc[d];
+  u32 ab = B.actor_base[d], na = D.n_actors;
+  u64 len = uleb_size(na);
+  for (u32 a = 0; a < na; a++) len += uleb_size(B.actor_len[ab + a]) + B.actor_len[ab + a];
+  u32 nh = sv_heads(B, d), cb = B.chg_base[d], nc = B.cnt[d].n_chg;
+  len += uleb_size(nh) + 32ull * nh;
+  for (u32 i = 0; i < nc; i++) if (!B.c_is_dep[cb + i]) len += uleb_size(i);
+  u32 ncc = 0, noc = 0;
+  for (u32 k = 0; k < AMH_SV_NCOLS; k++) {
+    if (!cl[k]) continue;
+    if (k < AMH_SV_CHG_COLS) ncc++; else noc++;
+    len += uleb_size(sv_spec(k)) + uleb_size(cl[k]) + cl[k];
+  }
+  len += uleb_size(ncc) + uleb_size(noc);
+  if (len > 0x7FFFFFF0ull) { B.sv_status[d] = AMH_E_TOO_LARGE; return; }
+  B.sv_body_len[d] = (u32)len;
+  B.sv_off[d] = 4 + 4 + 1 + uleb_size(len) + (u32)len;
+}
+// where the column data starts inside the chunk (after header, actors, heads and both metadata blocks)
+AMH_DEV u32 sv_data_start(const BatchDev& B, u32 d) {
+  const u32* cl = B.sv_col_len + (u64)d * AMH_SV_NCOLS;
+  u32 tot = 0;
+  for (u32 k = 0; k < AMH_SV_NCOLS; k++) tot += cl[k];
+  u32 nh = sv_heads(B, d), cb = B.chg_base[d], nc = B.cnt[d].n_chg, suffix = 0;
+  for (u32 i = 0; i < nc; i++) if (!B.c_is_dep[cb + i]) suffix += uleb_size(i);
+  (void)nh;
+  return (B.sv_off[d + 1] - B.sv_off[d]) - suffix - tot;
+}
+AMH_DEV void k_save_store(const BatchDev& B, u32 gid) {
+  u32 col = gid / B.n_docs, d = gid % B.n_docs;
+  if (col >= AMH_SV_NCOLS || !sv_doc_ok(B, d)) return;
+  const u32* cl = B.sv_col_len + (u64)d * AMH_SV_NCOLS;
+  if (cl[col] == 0) return;
+  u64 off = (u64)B.sv_off[d] + sv_data_start(B, d);
+  for (u32 k = 0; k < col; k++) off += cl[k];
+  save_encode_col(B, d, col, B.sv_out + off);
+}
+AMH_DEV void k_save_finish(const BatchDev& B, u32 d) {
+  if (!sv_doc_ok(B, d)) return;
+  const DocDesc& D = B.desc[d];
+  const u8* chunk = B.arena + D.chunk_off;
+  const u32* cl = B.sv_col_len + (u64)d * AMH_SV_NCOLS;
+  u8* out = B.sv_out + B.sv_off[d];
+  u32 body_len = B.sv_body_len[d];
+  u32 hdr = 9 + uleb_size(body_len), pos = hdr;
+  u32 ab = B.actor_base[d], na = D.n_actors, cb = B.chg_base[d], nc = B.cnt[d].n_chg;
+  pos += wr_uleb(out + pos, na);
+  for (u32 k = 0; k < na; k++) {   // bytewise order (document.rs:233)
+    u32 a = ab + B.actor_by_rank[ab + k];
+    pos += wr_uleb(out + pos, B.actor_len[a]);
+    for (u32 b = 0; b < B.actor_len[a]; b++) out[pos++] = chunk[B.actor_off[a] + b];
+  }
+  u32 nh = sv_heads(B, d);
+  pos += wr_uleb(out + pos, nh);
+  u8* heads = out + pos;
+  u32 tail = B.sv_off[d + 1] - B.sv_off[d];   // head indices are written from the sorted order below
+  // heads sorted by hash; their change indices follow the column data in the same order
+  u32 placed = 0;
+  for (u32 i = 0; i < nc; i++) {
+    if (B.c_is_dep[cb + i]) continue;
+    const u8* h = B.c_hash + (u64)(cb + i) * 32;
+    u32 j = placed;
+    while (j > 0 && amh_memcmp(heads + 32 * (j - 1), 32, h, 32) > 0) {
+      for (int b = 0; b < 32; b++) heads[32 * j + b] = heads[32 * (j - 1) + b];
+      j--;
+    }
+    for (int b = 0; b < 32; b++) heads[32 * j + b] = h[b];
+    placed++;
+  }
+  pos += 32 * nh;
+  for (int blk = 0; blk < 2; blk++) {
+    u32 lo = blk ? AMH_SV_CHG_COLS : 0, hi = blk ? AMH_SV_NCOLS : AMH_SV_CHG_COLS, cnt = 0;
+    for (u32 k = lo; k < hi; k++) if (cl[k]) cnt++;
+    pos += wr_uleb(out + pos, cnt);
+    for (u32 k = lo; k < hi; k++) if (cl[k]) { pos += wr_uleb(out + pos, sv_spec(k)); pos += wr_uleb(out + pos, cl[k]); }
+  }
+  for (u32 k = 0; k < AMH_SV_NCOLS; k++) pos += cl[k];   // column data: written by k_save_store
+  // suffix: index of each head's change, in head order
+  for (u32 k = 0; k < nh; k++) {
+    for (u32 i = 0; i < nc; i++) {
+      if (B.c_is_dep[cb + i]) continue;
+      if (amh_memcmp(B.c_hash + (u64)(cb + i) * 32, 32, heads + 32 * k, 32) == 0) { pos += wr_uleb(out + pos, i); break; }
+    }
+  }
+  (void)tail;
+  out[0] = 0x85; out[1] = 0x6f; out[2] = 0x4a; out[3] = 0x83;
+  out[8] = 0;
+  wr_uleb(out + 9, body_len);
+  u8 h[32];
+  sha256_contig(out + 8, (u64)(hdr - 8) + body_len, h);
+  out[4] = h[0]; out[5] = h[1]; out[6] = h[2]; out[7] = h[3];
+}
+
+// ------------------------------------------------------------------------------------------
 // small glue kernels
 // ------------------------------------------------------------------------------------------
 AMH_DEV u32 amh_pow2_at_least(u32 v) { u32 p = 1; while (p < v) p <<= 1; return p; }

@@ -158,6 +158,11 @@ struct BatchDev {
   // 8 value meta lo  9 value meta hi | kind << 8  10, 11 raw offset + length, or the i64 of a re-encoded increment
   u32* cv[12];
   u8* out_arena;                 // re-derived change chunks
+  i32* sv_status;                // [n_docs] save: 0 ok, else why the document has no saved form
+  u32* sv_col_len;               // [n_docs * 25]
+  u32* sv_body_len;              // [n_docs]
+  u32* sv_off;                   // [n_docs + 1] chunk offsets in sv_out
+  u8* sv_out;
   u32* sync_off;                 // [n_docs + 1] record offsets of the sync summaries
   u8* sync_out;
 };

@@ -144,7 +144,10 @@ int amh_merge_batch(amh_ctx*, amh_batch* dst, const amh_batch* src, const uint32
 /* == Automerge::apply_changes (automerge.rs:785; AMapplyChanges, automerge-c/src/doc.rs:84) */
 int amh_apply_changes(amh_ctx*, amh_batch*, uint32_t doc, const uint8_t* const* changes, const size_t* lens, size_t n);
 /* == Automerge::save_with_options (automerge.rs:943-965; AMsave, automerge-c/src/doc.rs:751);
- * out = array of n_docs amh_bytes_out */
+ * out = array of n_docs amh_bytes_out, each freed with amh_bytes_free.  A document that failed to load (or whose
+ * stored actor table is not in bytewise order: not a shape writers produce) gets data = NULL.
+ * deflate = 0 is save_nocompress (bit-exact); deflate = 1 compresses columns >= 256 bytes on the host with zlib
+ * (same policy as the reference; compressed bytes are not flate2's: parity unpinned). */
 int amh_save_batch(amh_ctx*, const amh_batch*, const amh_save_opts*, amh_bytes_out* out);
 
 /* ---- sync summaries ---------------------------------------------------------------------------

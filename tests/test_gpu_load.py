@@ -149,3 +149,30 @@ def test_sync_summaries(engine, golden_dir):
         assert rec["status"] == 0
         assert rec["heads"] == ref.get_heads() == batch.get_heads(i)
         assert rec["bloom"] == ref.bloom()
+
+
+def test_save(engine, golden_dir):
+    """save_nocompress(load(x)) is byte-identical to the oracle's; save() = same chunk with columns >= 256 bytes
+    DEFLATEd (compressed bytes are zlib's: parity unpinned, so compare after loading them back)"""
+    import oracle_lib as o
+    docs = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(golden_dir, "docs", "*.automerge")))]
+    blob, offs = engine.gen_map_docs(31, 5, 4, 5, 50, 64, 2)
+    docs += [blob[offs[i]:offs[i + 1]] for i in range(5)]
+    blob, offs = engine.gen_text_docs(32, 2, 2, 100, 400, 80, 2)
+    docs += [blob[offs[i]:offs[i + 1]] for i in range(4)] + [b"\x85\x6f\x4a\x83garbage"]
+    batch = engine.load_batch(docs)
+    plain, packed = batch.save_all(deflate=False), batch.save_all(deflate=True)
+    assert plain[-1] is None and packed[-1] is None
+    smaller = 0
+    for i, d in enumerate(docs[:-1]):
+        ref = o.Doc.load(d)
+        assert plain[i] == ref.save(deflate=False), i
+        again = o.Doc.load(packed[i])
+        assert again.save(deflate=False) == plain[i]
+        assert len(packed[i]) <= len(plain[i])
+        smaller += len(packed[i]) < len(plain[i])
+    assert smaller > 0
+    # and the saved bytes load back through the engine to the same state
+    b2 = engine.load_batch([p for p in packed[:-1]])
+    for i in range(len(docs) - 1):
+        assert b2.hydrate_json(i) == batch.hydrate_json(i) and b2.get_heads(i) == batch.get_heads(i)
