@@ -88,6 +88,7 @@ def bind(lib):
     lib.amh_u64_free.argtypes = [C.POINTER(C.c_uint64)]
     lib.amh_sync_summaries.argtypes = [vp, vp, C.POINTER(BytesOut)]
     lib.amh_save_batch.argtypes = [vp, vp, C.POINTER(SaveOpts), C.POINTER(BytesOut)]
+    lib.amh_merge_batch.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]
     return lib
 
 
@@ -208,6 +209,17 @@ class Batch:
         if rc != 0:
             raise EngineError(f"amh_doc_max_op failed: {rc}")
         return v.value
+
+    def merge(self, other, pairs):
+        """== self[a].merge(other[b]) for every (a, b) in pairs (automerge.rs:917).  Returns the call status: 0, or
+        -7 when some pairs were left unmerged (failed documents, duplicate seq numbers)."""
+        n = len(pairs)
+        a = (C.c_uint32 * max(1, n))(*[p[0] for p in pairs])
+        b = (C.c_uint32 * max(1, n))(*[p[1] for p in pairs])
+        rc = self.engine.lib.amh_merge_batch(self.engine.ctx, self.h, other.h, a, b, n)
+        if rc not in (0, -7):
+            raise EngineError(f"amh_merge_batch failed: {rc} {self.engine._err()}")
+        return rc
 
     def save_all(self, deflate=True):
         """== Automerge::save_with_options per document (automerge.rs:943); None for documents without a saved form."""

@@ -11,6 +11,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/automerge_hip.h"
@@ -824,9 +825,320 @@ extern "C" int amh_debug_array(const amh_batch* b, const char* name, void* out, 
 // ---------------------------------------------------------------------------------------------
 // boundary entry points declared for the path but not built in this round: they fail loudly
 // ---------------------------------------------------------------------------------------------
-extern "C" int amh_merge_batch(amh_ctx* ctx, amh_batch*, const amh_batch*, const uint32_t*, const uint32_t*, size_t) {
-  set_error(ctx, "amh_merge_batch: not implemented in this round");
-  return AMH_ERR_UNIMPLEMENTED;
+// ---------------------------------------------------------------------------------------------
+// merge — automerge.rs:917-940.  Host: which changes are new and in which order they apply
+// (get_changes_added :1311-1334 + the causal queue of apply_changes :797-858), actor-table union.
+// Device: everything per op (amh_merge.inl), then the save kernels over the merged rows; the merged
+// documents are loaded again through the normal pipeline, which re-derives every change hash and
+// checks the heads, so a wrong merge cannot go unnoticed.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+static T* upload(amh_batch* b, const std::vector<T>& v, bool* ok) {
+  T* p = balloc<T>(b, v.size() + 1, ok);
+  if (p && !v.empty() && !rt_h2d(p, v.data(), v.size() * sizeof(T), b->ctx->stream)) *ok = false;
+  return p;
+}
+struct Hash32 {
+  u8 b[32];
+  bool operator==(const Hash32& o) const { return memcmp(b, o.b, 32) == 0; }
+};
+struct Hash32Hasher { size_t operator()(const Hash32& h) const { size_t v; memcpy(&v, h.b, sizeof v); return v; } };
+
+extern "C" int amh_merge_batch(amh_ctx* ctx, amh_batch* dst, const amh_batch* src, const uint32_t* dst_idx, const uint32_t* src_idx, size_t n_pairs) {
+  if (!ctx || !dst || !src || dst == src || (n_pairs && (!dst_idx || !src_idx)) || n_pairs >= 0x7FFFFFFFull) { set_error(ctx, "amh_merge_batch: invalid argument"); return AMH_ERR_INVALID_ARG; }
+  if (n_pairs == 0) return AMH_SUCCESS;
+  if (!ensure_chg(dst) || !ensure_chg(src)) { set_error(ctx, "amh_merge_batch: D2H copy failed"); return AMH_ERR_DEVICE; }
+  const HostView &ha = dst->hv, &hb = src->hv;
+  const BatchDev &DB = dst->B, &SB = src->B;
+  u32 P = (u32)n_pairs;
+  std::vector<u32> d_pair(DB.n_docs, AMH_NULL32), s_pair(SB.n_docs, AMH_NULL32), p_a(P), p_b(P), a_len_pad(P, 0);
+  std::vector<i32> p_status(P, 0);
+  for (u32 p = 0; p < P; p++) {
+    u32 a = dst_idx[p], b = src_idx[p];
+    if (a >= DB.n_docs || b >= SB.n_docs || d_pair[a] != AMH_NULL32 || s_pair[b] != AMH_NULL32) { set_error(ctx, "amh_merge_batch: document index out of range or used twice"); return AMH_ERR_INVALID_ARG; }
+    d_pair[a] = p; s_pair[b] = p; p_a[p] = a; p_b[p] = b;
+  }
+  // ---- host: actors and changes -----------------------------------------------------------------
+  std::vector<u32> mapa_base(P + 1, 0), mapb_base(P + 1, 0), map_a, map_b, map_b2a;
+  std::vector<u8> s_added(SB.tot_chg + 1, 0);
+  std::vector<u32> m_actor_base(P + 1, 0), m_actor_off, m_actor_len, m_actor_rank;
+  std::vector<u32> m_chg_base(P + 1, 0), mc_from, mc_ndeps, mc_dep_base, m_dep_idx, mc_doc;
+  std::vector<u8> mc_is_dep;
+  std::vector<DocDesc> m_desc(P);
+  std::vector<DocCounts> m_cnt(P);
+  u64 arena_len = 0;
+  int n_failed = 0;
+  for (u32 p = 0; p < P; p++) {
+    u32 a = p_a[p], b = p_b[p];
+    mapa_base[p] = (u32)map_a.size(); mapb_base[p] = (u32)map_b.size();
+    m_actor_base[p] = (u32)m_actor_off.size(); m_chg_base[p] = (u32)mc_from.size();
+    memset(&m_desc[p], 0, sizeof(DocDesc)); memset(&m_cnt[p], 0, sizeof(DocCounts));
+    if (dst->status[a] || src->status[b]) { p_status[p] = dst->status[a] ? dst->status[a] : src->status[b]; n_failed++; continue; }
+    const u8* ca = dst->staged->h_arena.data() + dst->staged->h_doc_off[2 * (size_t)a];
+    const u8* cb = src->staged->h_arena.data() + src->staged->h_doc_off[2 * (size_t)b];
+    u32 na = ha.desc[a].n_actors, nb = hb.desc[b].n_actors, aba = ha.actor_base[a], abb = hb.actor_base[b];
+    auto abytes = [&](u32 i) { return std::make_pair(ca + ha.actor_off[aba + i], ha.actor_len[aba + i]); };
+    auto bbytes = [&](u32 i) { return std::make_pair(cb + hb.actor_off[abb + i], hb.actor_len[abb + i]); };
+    auto cmp = [](std::pair<const u8*, u32> x, std::pair<const u8*, u32> y) { int c = memcmp(x.first, y.first, std::min(x.second, y.second)); return c ? c : (x.second < y.second ? -1 : (x.second > y.second ? 1 : 0)); };
+    bool sorted = true;
+    for (u32 i = 1; i < na && sorted; i++) sorted = cmp(abytes(i - 1), abytes(i)) < 0;
+    for (u32 i = 1; i < nb && sorted; i++) sorted = cmp(bbytes(i - 1), bbytes(i)) < 0;
+    if (!sorted) { p_status[p] = AMH_E_UNSUPPORTED; n_failed++; continue; }
+    u32 lenA = ha.desc[a].chunk_len, lenApad = (lenA + 15u) & ~15u, lenB = hb.desc[b].chunk_len;
+    a_len_pad[p] = lenApad;
+    // union of the two sorted tables
+    std::vector<u32> la(na), lb(nb), lb2a(nb, AMH_NULL32);
+    {
+      u32 i = 0, j = 0, k = 0;
+      while (i < na || j < nb) {
+        int c = i >= na ? 1 : (j >= nb ? -1 : cmp(abytes(i), bbytes(j)));
+        if (c <= 0) { m_actor_off.push_back(ha.actor_off[aba + i]); m_actor_len.push_back(ha.actor_len[aba + i]); }
+        else { m_actor_off.push_back(lenApad + hb.actor_off[abb + j]); m_actor_len.push_back(hb.actor_len[abb + j]); }
+        m_actor_rank.push_back(k);
+        if (c == 0) lb2a[j] = i;
+        if (c <= 0) la[i++] = k;
+        if (c >= 0) lb[j++] = k;
+        k++;
+      }
+    }
+    map_a.insert(map_a.end(), la.begin(), la.end());
+    map_b.insert(map_b.end(), lb.begin(), lb.end());
+    map_b2a.insert(map_b2a.end(), lb2a.begin(), lb2a.end());
+    // changes: which of src's are new, and in which order they are applied
+    u32 nca = ha.cnt[a].n_chg, ncb = hb.cnt[b].n_chg, cba = ha.chg_base[a], cbb = hb.chg_base[b];
+    std::unordered_map<Hash32, u32, Hash32Hasher> in_a;
+    in_a.reserve(nca * 2 + 1);
+    for (u32 i = 0; i < nca; i++) { Hash32 h; memcpy(h.b, ha.c_hash.data() + (size_t)(cba + i) * 32, 32); in_a.emplace(h, i); }
+    std::vector<u32> b2a(ncb, AMH_NULL32);
+    for (u32 j = 0; j < ncb; j++) { Hash32 h; memcpy(h.b, hb.c_hash.data() + (size_t)(cbb + j) * 32, 32); auto it = in_a.find(h); if (it != in_a.end()) b2a[j] = it->second; }
+    auto bhash = [&](u32 j) { return hb.c_hash.data() + (size_t)(cbb + j) * 32; };
+    auto bdeps_sorted = [&](u32 j) {   // deps in the order of their hashes (Change::deps is sorted)
+      std::vector<u32> d;
+      for (u32 k = 0; k < hb.c_ndeps[cbb + j]; k++) d.push_back(hb.dep_idx[hb.c_dep_base[cbb + j] + k]);
+      std::sort(d.begin(), d.end(), [&](u32 x, u32 y) { return memcmp(bhash(x), bhash(y), 32) < 0; });
+      return d;
+    };
+    // get_changes_added: DFS from src's heads (sorted), popping from the end; result reversed
+    std::vector<u8> is_dep_b(ncb, 0);
+    for (u32 j = 0; j < ncb; j++) for (u32 k = 0; k < hb.c_ndeps[cbb + j]; k++) is_dep_b[hb.dep_idx[hb.c_dep_base[cbb + j] + k]] = 1;
+    std::vector<u32> stack;
+    for (u32 j = 0; j < ncb; j++) if (!is_dep_b[j]) stack.push_back(j);
+    std::sort(stack.begin(), stack.end(), [&](u32 x, u32 y) { return memcmp(bhash(x), bhash(y), 32) < 0; });
+    std::vector<u8> seen(ncb, 0);
+    std::vector<u32> added;
+    while (!stack.empty()) {
+      u32 j = stack.back(); stack.pop_back();
+      if (seen[j] || b2a[j] != AMH_NULL32) continue;
+      seen[j] = 1; added.push_back(j);
+      for (u32 dj : bdeps_sorted(j)) stack.push_back(dj);
+    }
+    std::reverse(added.begin(), added.end());
+    if (added.empty()) { p_status[p] = -1; continue; }   // nothing to do: dst stays as it is
+    // apply_changes: duplicate-seq check, causal gate, queue drained with swap_remove
+    std::vector<u32> per_actor(m_actor_off.size() - m_actor_base[p], 0);
+    for (u32 i = 0; i < nca; i++) per_actor[la[ha.c_actor[cba + i]]]++;
+    std::vector<u8> applied(ncb, 0);
+    std::vector<u32> order, queue;
+    auto ready = [&](u32 j) { for (u32 k = 0; k < hb.c_ndeps[cbb + j]; k++) { u32 dj = hb.dep_idx[hb.c_dep_base[cbb + j] + k]; if (b2a[dj] == AMH_NULL32 && !applied[dj]) return false; } return true; };
+    auto apply = [&](u32 j) { applied[j] = 1; order.push_back(j); per_actor[lb[hb.c_actor[cbb + j]]]++; };
+    bool dup = false;
+    for (u32 j : added) {
+      if (applied[j]) continue;
+      if (per_actor[lb[hb.c_actor[cbb + j]]] >= hb.c_seq[cbb + j]) { dup = true; break; }
+      if (ready(j)) apply(j); else queue.push_back(j);
+    }
+    while (!dup) {
+      bool got = false;
+      for (size_t q = 0; q < queue.size(); q++)
+        if (ready(queue[q])) { u32 j = queue[q]; queue[q] = queue.back(); queue.pop_back(); if (!applied[j]) apply(j); got = true; break; }
+      if (!got) break;
+    }
+    if (dup) { p_status[p] = AMH_E_DUPLICATE_SEQ; n_failed++; continue; }
+    if (!queue.empty()) { p_status[p] = AMH_E_MISSING_DEPS; n_failed++; continue; }
+    // merged history = dst's history, then the applied changes
+    std::vector<u32> b2m(ncb, AMH_NULL32);
+    for (u32 j = 0; j < ncb; j++) b2m[j] = b2a[j];
+    for (size_t k = 0; k < order.size(); k++) { b2m[order[k]] = nca + (u32)k; s_added[cbb + order[k]] = 1; }
+    size_t first_c = mc_from.size();
+    for (u32 i = 0; i < nca; i++) {
+      mc_from.push_back(cba + i); mc_doc.push_back(p); mc_is_dep.push_back(0);
+      mc_ndeps.push_back(ha.c_ndeps[cba + i]); mc_dep_base.push_back((u32)m_dep_idx.size());
+      for (u32 k = 0; k < ha.c_ndeps[cba + i]; k++) m_dep_idx.push_back(ha.dep_idx[ha.c_dep_base[cba + i] + k]);
+    }
+    for (u32 j : order) {
+      mc_from.push_back(0x80000000u | (cbb + j)); mc_doc.push_back(p); mc_is_dep.push_back(0);
+      mc_ndeps.push_back(hb.c_ndeps[cbb + j]); mc_dep_base.push_back((u32)m_dep_idx.size());
+      for (u32 k = 0; k < hb.c_ndeps[cbb + j]; k++) m_dep_idx.push_back(b2m[hb.dep_idx[hb.c_dep_base[cbb + j] + k]]);
+    }
+    for (size_t c = first_c; c < mc_from.size(); c++)
+      for (u32 k = 0; k < mc_ndeps[c]; k++) mc_is_dep[first_c + m_dep_idx[mc_dep_base[c] + k]] = 1;
+    m_cnt[p].n_chg = nca + (u32)order.size();
+    m_desc[p].chunk_off = arena_len;
+    m_desc[p].chunk_len = lenApad + lenB;
+    m_desc[p].n_actors = (u32)(m_actor_off.size() - m_actor_base[p]);
+    m_desc[p].ocol[OC_MARK_NAME].len = ha.desc[a].ocol[OC_MARK_NAME].len | hb.desc[b].ocol[OC_MARK_NAME].len;
+    arena_len += (lenApad + lenB + 15u) & ~15ull;
+  }
+  mapa_base[P] = (u32)map_a.size(); mapb_base[P] = (u32)map_b.size();
+  m_actor_base[P] = (u32)m_actor_off.size(); m_chg_base[P] = (u32)mc_from.size();
+  bool any_work = false;
+  for (u32 p = 0; p < P; p++) any_work = any_work || p_status[p] == 0;
+  if (!any_work) {
+    if (n_failed) { set_error(ctx, "amh_merge_batch: no pair could be merged (failed documents / duplicate seq numbers)"); return AMH_ERR_DOC_FAILED; }
+    return AMH_SUCCESS;
+  }
+  if (arena_len >= 0xFFFFFFF0ull || mc_from.size() >= 0x7FFFFFFFull) { set_error(ctx, "amh_merge_batch: batch too large"); return AMH_ERR_BATCH_TOO_LARGE; }
+  // ---- device ---------------------------------------------------------------------------------
+  std::unique_ptr<amh_batch, void (*)(amh_batch*)> mbh(new amh_batch(), amh_batch_free);
+  amh_batch* mb = mbh.get();
+  mb->ctx = ctx;
+  MergeDev G;
+  memset(&G, 0, sizeof G);
+  G.D = DB; G.S = SB;
+  BatchDev& M = G.M;
+  bool ok = true;
+  auto failm = [&](const char* m) { set_error(ctx, std::string("amh_merge_batch: ") + m); collect_profile(ctx); return AMH_ERR_DEVICE; };
+  G.n_pairs = P;
+  G.p_a = upload(mb, p_a, &ok); G.p_b = upload(mb, p_b, &ok); G.p_status = upload(mb, p_status, &ok);
+  G.d_pair = upload(mb, d_pair, &ok); G.s_pair = upload(mb, s_pair, &ok);
+  G.mapa_base = upload(mb, mapa_base, &ok); G.mapb_base = upload(mb, mapb_base, &ok);
+  G.map_a = upload(mb, map_a, &ok); G.map_b = upload(mb, map_b, &ok); G.map_b2a = upload(mb, map_b2a, &ok);
+  G.s_added = upload(mb, s_added, &ok); G.a_len_pad = upload(mb, a_len_pad, &ok); G.mc_from = upload(mb, mc_from, &ok);
+  M.n_docs = P;
+  M.tot_chg = (u32)mc_from.size(); M.tot_actors = (u32)m_actor_off.size(); M.tot_deps = (u32)m_dep_idx.size();
+  M.status = balloc<i32>(mb, P + 1, &ok); M.fail_line = balloc<u32>(mb, P + 1, &ok);
+  M.desc = upload(mb, m_desc, &ok); M.cnt = upload(mb, m_cnt, &ok);
+  M.row_base = balloc<u32>(mb, P + 2, &ok); M.succ_base = balloc<u32>(mb, P + 2, &ok);
+  M.chg_base = upload(mb, m_chg_base, &ok); M.actor_base = upload(mb, m_actor_base, &ok);
+  M.actor_off = upload(mb, m_actor_off, &ok); M.actor_len = upload(mb, m_actor_len, &ok);
+  M.actor_rank = upload(mb, m_actor_rank, &ok); M.actor_by_rank = upload(mb, m_actor_rank, &ok);
+  size_t NC = M.tot_chg + 2;
+  M.c_actor = balloc<u32>(mb, NC, &ok); M.c_seq = balloc<u64>(mb, NC, &ok); M.c_max_op = balloc<u64>(mb, NC, &ok); M.c_time = balloc<i64>(mb, NC, &ok);
+  M.c_msg_off = balloc<u32>(mb, NC, &ok); M.c_msg_len = balloc<u32>(mb, NC, &ok); M.c_extra_off = balloc<u32>(mb, NC, &ok); M.c_extra_len = balloc<u32>(mb, NC, &ok);
+  M.c_hash = balloc<u8>(mb, NC * 32, &ok);
+  M.c_ndeps = upload(mb, mc_ndeps, &ok); M.c_dep_base = upload(mb, mc_dep_base, &ok); M.dep_idx = upload(mb, m_dep_idx, &ok);
+  M.c_doc = upload(mb, mc_doc, &ok); M.c_is_dep = upload(mb, mc_is_dep, &ok);
+  u8* m_arena = balloc<u8>(mb, (size_t)arena_len + 256, &ok);
+  M.arena = m_arena;
+  size_t NRD = DB.tot_rows + 2, NRS = SB.tot_rows + 2;
+  G.new_idx = balloc<u32>(mb, NRS, &ok); G.gap_base = balloc<u32>(mb, P + 2, &ok);
+  G.sub_end = balloc<u32>(mb, NRD, &ok); G.upd_end = balloc<u32>(mb, NRD, &ok); G.stack = balloc<u32>(mb, NRD, &ok);
+  G.x_cnt = balloc<u32>(mb, NRD, &ok); G.x_fill = balloc<u32>(mb, NRD, &ok); G.d_to_m = balloc<u32>(mb, NRD, &ok);
+  MergeDev* Gdev = (MergeDev*)balloc<u8>(mb, sizeof(MergeDev), &ok);
+  if (!ok) { set_error(ctx, "amh_merge_batch: device out of memory"); return AMH_ERR_OOM; }
+  {
+    std::vector<i32> mst(P);
+    for (u32 p = 0; p < P; p++) mst[p] = p_status[p];   // documents of pairs that are not merged are skipped by the save kernels
+    if (!rt_h2d(M.status, mst.data(), P * sizeof(i32), ctx->stream)) return failm("H2D copy failed");
+  }
+  rt_memset(M.fail_line, 0, (P + 1) * 4, ctx->stream);
+  rt_memset(G.x_cnt, 0, NRD * 4, ctx->stream); rt_memset(G.x_fill, 0, NRD * 4, ctx->stream);
+  auto mg = [&](int k, u32 n) {
+    if (n == 0) return true;
+    if (!rt_h2d(Gdev, &G, sizeof(MergeDev), ctx->stream)) return false;
+#ifdef AMH_EMU
+    amh_launch_mg(k, &G, n, (void*)ctx->stream);
+#else
+    amh_launch_mg(k, Gdev, n, (void*)ctx->stream);
+#endif
+    return true;
+  };
+  mg(MK_NEW_FLAG, SB.tot_rows);
+  u32 tot_new = 0;
+  if (!scan_inplace(mb, G.new_idx, SB.tot_rows, &tot_new)) return failm("scan failed");
+  G.tot_new = tot_new;
+  mg(MK_PAIR_COUNTS, P);
+  u32 m_rows = 0, gap_tot = 0;
+  if (!scan_inplace(mb, M.row_base, P, &m_rows) || !scan_inplace(mb, G.gap_base, P, &gap_tot)) return failm("scan failed");
+  if (m_rows >= 0x7FFFFFF0u) { set_error(ctx, "amh_merge_batch: batch too large"); return AMH_ERR_BATCH_TOO_LARGE; }
+  M.tot_rows = m_rows;
+  G.new_src = balloc<u32>(mb, (size_t)tot_new + 1, &ok); G.new_gap = balloc<u32>(mb, (size_t)tot_new + 1, &ok);
+  G.gap_cnt = balloc<u32>(mb, (size_t)gap_tot + 2, &ok);
+  size_t NR = (size_t)m_rows + 2;
+  u32** rcols[] = {&M.r_id_actor, &M.r_id_ctr, &M.r_obj_actor, &M.r_obj_ctr, &M.r_key_actor, &M.r_key_ctr, &M.r_key_off, &M.r_key_len,
+                   &M.r_vraw_off, &M.r_mark_off, &M.r_mark_len, &M.r_succ_cnt, &M.r_succ_base, &M.r_doc};
+  for (auto pc : rcols) *pc = balloc<u32>(mb, NR, &ok);
+  M.r_insert = balloc<u8>(mb, NR, &ok); M.r_action = balloc<u8>(mb, NR, &ok); M.r_expand = balloc<u8>(mb, NR, &ok);
+  M.r_vmeta = balloc<u64>(mb, NR, &ok);
+  if (!ok) { set_error(ctx, "amh_merge_batch: device out of memory"); return AMH_ERR_OOM; }
+  rt_memset(G.gap_cnt, 0, ((size_t)gap_tot + 2) * 4, ctx->stream);
+  rt_memset(M.r_succ_cnt, 0, NR * 4, ctx->stream);
+  mg(MK_SUBTREE, P);
+  mg(MK_GAP, SB.tot_rows);
+  mg(MK_INHERIT, P);
+  if (!scan_inplace(mb, G.gap_cnt, gap_tot, nullptr)) return failm("scan failed");
+  mg(MK_EXTRA_CNT, SB.tot_succ);
+  mg(MK_ROWS_DST, DB.tot_rows);
+  mg(MK_ROWS_NEW, tot_new);
+#ifdef AMH_EMU
+  memcpy(M.r_succ_base, M.r_succ_cnt, (size_t)m_rows * 4);
+#else
+  (void)hipMemcpyAsync(M.r_succ_base, M.r_succ_cnt, (size_t)m_rows * 4, hipMemcpyDeviceToDevice, ctx->stream);
+#endif
+  u32 m_succ = 0;
+  if (!scan_inplace(mb, M.r_succ_base, m_rows, &m_succ)) return failm("scan failed");
+  M.tot_succ = m_succ;
+  M.s_actor = balloc<u32>(mb, (size_t)m_succ + 1, &ok); M.s_ctr = balloc<u32>(mb, (size_t)m_succ + 1, &ok);
+  if (!ok) { set_error(ctx, "amh_merge_batch: device out of memory"); return AMH_ERR_OOM; }
+  mg(MK_SUCC_DST, DB.tot_rows);
+  mg(MK_SUCC_NEW, tot_new);
+  mg(MK_SUCC_EXTRA, SB.tot_succ);
+  mg(MK_SUCC_SORT, DB.tot_rows);
+  mg(MK_DOC_SUCC, P);
+  mg(MK_CHANGES, M.tot_chg);
+  mg(MK_COPY_CHUNKS, P);
+  // pairs the kernels rejected
+  if (!rt_d2h(p_status.data(), G.p_status, P * sizeof(i32), ctx->stream)) return failm("D2H copy failed");
+  if (!rt_h2d(M.status, p_status.data(), P * sizeof(i32), ctx->stream)) return failm("H2D copy failed");
+  // ---- merged rows -> document chunks (the save kernels over M) ---------------------------------
+  M.sv_status = balloc<i32>(mb, P + 1, &ok); M.sv_col_len = balloc<u32>(mb, (size_t)P * 25 + 1, &ok);
+  M.sv_body_len = balloc<u32>(mb, P + 1, &ok); M.sv_off = balloc<u32>(mb, P + 2, &ok);
+  if (!ok) { set_error(ctx, "amh_merge_batch: device out of memory"); return AMH_ERR_OOM; }
+  launch(ctx, AK_SAVE_CHECK, M, P);
+  launch(ctx, AK_SAVE_SIZE, M, P * 25);
+  launch(ctx, AK_SAVE_LAYOUT, M, P);
+  u32 sv_total = 0;
+  if (!scan_inplace(mb, M.sv_off, P, &sv_total)) return failm("scan failed");
+  if (sv_total == 0xFFFFFFFFu) { set_error(ctx, "amh_merge_batch: merged documents exceed 4 GiB"); return AMH_ERR_BATCH_TOO_LARGE; }
+  M.sv_out = balloc<u8>(mb, (size_t)sv_total + 256, &ok);
+  if (!ok) { set_error(ctx, "amh_merge_batch: device out of memory"); return AMH_ERR_OOM; }
+  launch(ctx, AK_SAVE_STORE, M, P * 25);
+  launch(ctx, AK_SAVE_FINISH, M, P);
+  std::vector<u8> merged((size_t)sv_total);
+  std::vector<u32> sv_off(P + 1), sv_body(P);
+  std::vector<i32> sv_st(P);
+  if (!rt_d2h(merged.data(), M.sv_out, sv_total, ctx->stream) || !rt_d2h(sv_off.data(), M.sv_off, (P + 1) * 4, ctx->stream) ||
+      !rt_d2h(sv_body.data(), M.sv_body_len, P * 4, ctx->stream) || !rt_d2h(sv_st.data(), M.sv_status, P * 4, ctx->stream))
+    return failm("D2H copy failed");
+  collect_profile(ctx);
+  // ---- reload: every document of dst, merged ones from their new bytes ---------------------------
+  u32 nd = DB.n_docs;
+  std::vector<const uint8_t*> ptrs(nd);
+  std::vector<size_t> lens(nd);
+  for (u32 d = 0; d < nd; d++) {
+    ptrs[d] = dst->staged->h_arena.data() + dst->staged->h_doc_off[2 * (size_t)d];
+    lens[d] = dst->staged->h_doc_off[2 * (size_t)d + 1] - dst->staged->h_doc_off[2 * (size_t)d];
+    u32 p = d_pair[d];
+    if (p == AMH_NULL32 || p_status[p] != 0) continue;
+    if (sv_st[p] != 0) { p_status[p] = sv_st[p]; continue; }
+    u32 bl = sv_body[p];
+    ptrs[d] = merged.data() + sv_off[p];
+    lens[d] = 9 + bl + (bl < 0x80 ? 1 : bl < 0x4000 ? 2 : bl < 0x200000 ? 3 : bl < 0x10000000 ? 4 : 5);
+  }
+  amh_load_opts lo;
+  lo.verify_heads = 1; lo.on_partial_load = 0;
+  amh_batch* nb = amh_load_batch(ctx, ptrs.data(), lens.data(), nd, &lo);
+  if (!nb) return AMH_ERR_DEVICE;
+  int rc = AMH_SUCCESS;
+  for (u32 p = 0; p < P; p++) {
+    if (p_status[p] > 0) { rc = AMH_ERR_DOC_FAILED; continue; }
+    if (p_status[p] == 0 && nb->status[p_a[p]] != 0) rc = AMH_ERR_DEVICE;   // a merged document that does not verify is an engine bug, never a silent result
+  }
+  if (rc == AMH_ERR_DEVICE) { set_error(ctx, "amh_merge_batch: a merged document failed verification on reload"); amh_batch_free(nb); return rc; }
+  std::swap(*dst, *nb);
+  amh_batch_free(nb);
+  if (rc == AMH_ERR_DOC_FAILED) set_error(ctx, "amh_merge_batch: some pairs were not merged (failed documents, duplicate seq numbers or unsupported shapes); their dst documents are unchanged");
+  return rc;
 }
 extern "C" int amh_apply_changes(amh_ctx* ctx, amh_batch*, uint32_t, const uint8_t* const*, const size_t*, size_t) {
   set_error(ctx, "amh_apply_changes: not implemented in this round");
@@ -856,9 +1168,10 @@ extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch* bc, const amh_save_
   launch(ctx, AK_SAVE_STORE, B, n * 25);
   launch(ctx, AK_SAVE_FINISH, B, n);
   std::vector<u8> host((size_t)total);
-  std::vector<u32> off(n + 1);
+  std::vector<u32> off(n + 1), body(n);
   std::vector<i32> st(n);
   if (!rt_d2h(host.data(), B.sv_out, total, ctx->stream) || !rt_d2h(off.data(), B.sv_off, (n + 1) * sizeof(u32), ctx->stream) ||
+      !rt_d2h(body.data(), B.sv_body_len, n * sizeof(u32), ctx->stream) ||
       !rt_d2h(st.data(), B.sv_status, n * sizeof(i32), ctx->stream)) {
     set_error(ctx, "D2H copy failed");
     return AMH_ERR_DEVICE;
@@ -867,7 +1180,7 @@ extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch* bc, const amh_save_
   bool deflate = opts ? opts->deflate != 0 : true;
   for (u32 d = 0; d < n; d++) {
     if (st[d] != 0) continue;   // failed to load, or a shape save does not handle: no bytes (amh_doc_status / amh_save_status)
-    size_t len = off[d + 1] - off[d];
+    size_t len = 9 + body[d] + (body[d] < 0x80 ? 1 : body[d] < 0x4000 ? 2 : body[d] < 0x200000 ? 3 : body[d] < 0x10000000 ? 4 : 5);
     const u8* src = host.data() + off[d];
     std::vector<u8> z;
     if (deflate && amh_host_deflate_document(src, len, z)) { src = z.data(); len = z.size(); }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "amh_kernels.inl"
+#include "amh_merge.inl"
 #include "amh_launch.h"
 
 #define AMH_BLOCK 256
@@ -633,4 +634,31 @@ void amh_level_sort(const BatchDev& B, u32* tmp, void* stream) {
   hipLaunchKernelGGL(g_level_hist, dim3(nblocks), dim3(AMH_BLOCK), 0, s, B, tmp, nblocks);
   amh_scan_inplace(tmp, n, tmp + n + 2, s);
   hipLaunchKernelGGL(g_level_scatter, dim3(nblocks), dim3(AMH_BLOCK), 0, s, B, (const u32*)tmp, nblocks);
+}
+
+// ------------------------------------------------------------------------------------------
+// merge kernels: one thread per unit, the MergeDev block lives in device memory
+// ------------------------------------------------------------------------------------------
+#define AMH_GLOBAL_MG(name)                                                     \
+  __global__ void __launch_bounds__(AMH_BLOCK) g_##name(const MergeDev* G, u32 n) { \
+    u32 i = blockIdx.x * AMH_BLOCK + threadIdx.x;                              \
+    if (i < n) name(*G, i);                                                    \
+  }
+AMH_GLOBAL_MG(k_mg_new_flag) AMH_GLOBAL_MG(k_mg_pair_counts) AMH_GLOBAL_MG(k_mg_subtree) AMH_GLOBAL_MG(k_mg_gap)
+AMH_GLOBAL_MG(k_mg_inherit) AMH_GLOBAL_MG(k_mg_extra_cnt) AMH_GLOBAL_MG(k_mg_rows_dst) AMH_GLOBAL_MG(k_mg_rows_new)
+AMH_GLOBAL_MG(k_mg_succ_dst) AMH_GLOBAL_MG(k_mg_succ_new) AMH_GLOBAL_MG(k_mg_succ_extra) AMH_GLOBAL_MG(k_mg_succ_sort)
+AMH_GLOBAL_MG(k_mg_doc_succ) AMH_GLOBAL_MG(k_mg_changes) AMH_GLOBAL_MG(k_mg_copy_chunks)
+void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream) {
+  if (n == 0) return;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((n + AMH_BLOCK - 1) / AMH_BLOCK), block(AMH_BLOCK);
+#define M(id, name) case id: hipLaunchKernelGGL(g_##name, grid, block, 0, s, G, n); break;
+  switch (k) {
+    M(MK_NEW_FLAG, k_mg_new_flag) M(MK_PAIR_COUNTS, k_mg_pair_counts) M(MK_SUBTREE, k_mg_subtree) M(MK_GAP, k_mg_gap)
+    M(MK_INHERIT, k_mg_inherit) M(MK_EXTRA_CNT, k_mg_extra_cnt) M(MK_ROWS_DST, k_mg_rows_dst) M(MK_ROWS_NEW, k_mg_rows_new)
+    M(MK_SUCC_DST, k_mg_succ_dst) M(MK_SUCC_NEW, k_mg_succ_new) M(MK_SUCC_EXTRA, k_mg_succ_extra) M(MK_SUCC_SORT, k_mg_succ_sort)
+    M(MK_DOC_SUCC, k_mg_doc_succ) M(MK_CHANGES, k_mg_changes) M(MK_COPY_CHUNKS, k_mg_copy_chunks)
+    default: break;
+  }
+#undef M
 }

@@ -1837,6 +1837,7 @@ AMH_DEV u32 sv_heads(const BatchDev& B, u32 d) {
 }
 AMH_DEV void k_save_layout(const BatchDev& B, u32 d) {
   B.sv_off[d] = 0;
+  B.sv_body_len[d] = 0;
   if (!sv_doc_ok(B, d)) return;
   u32* cl = B.sv_col_len + (u64)d * AMH_SV_NCOLS;
   if (cl[9] == 0) cl[10] = 0;     // ObjIdRange::encode -> None (obj_id.rs:79-81)
@@ -1857,8 +1858,9 @@ AMH_DEV void k_save_layout(const BatchDev& B, u32 d) {
   len += uleb_size(ncc) + uleb_size(noc);
   if (len > 0x7FFFFFF0ull) { B.sv_status[d] = AMH_E_TOO_LARGE; return; }
   B.sv_body_len[d] = (u32)len;
-  B.sv_off[d] = 4 + 4 + 1 + uleb_size(len) + (u32)len;
+  B.sv_off[d] = (4 + 4 + 1 + uleb_size(len) + (u32)len + 15u) & ~15u;   // chunks start 16-byte aligned in sv_out
 }
+AMH_DEV u32 sv_chunk_len(const BatchDev& B, u32 d) { return 9 + uleb_size(B.sv_body_len[d]) + B.sv_body_len[d]; }
 // where the column data starts inside the chunk (after header, actors, heads and both metadata blocks)
 AMH_DEV u32 sv_data_start(const BatchDev& B, u32 d) {
   const u32* cl = B.sv_col_len + (u64)d * AMH_SV_NCOLS;
@@ -1867,7 +1869,7 @@ AMH_DEV u32 sv_data_start(const BatchDev& B, u32 d) {
   u32 nh = sv_heads(B, d), cb = B.chg_base[d], nc = B.cnt[d].n_chg, suffix = 0;
   for (u32 i = 0; i < nc; i++) if (!B.c_is_dep[cb + i]) suffix += uleb_size(i);
   (void)nh;
-  return (B.sv_off[d + 1] - B.sv_off[d]) - suffix - tot;
+  return sv_chunk_len(B, d) - suffix - tot;
 }
 AMH_DEV void k_save_store(const BatchDev& B, u32 gid) {
   u32 col = gid / B.n_docs, d = gid % B.n_docs;
@@ -1896,7 +1898,6 @@ AMH_DEV void k_save_finish(const BatchDev& B, u32 d) {
   u32 nh = sv_heads(B, d);
   pos += wr_uleb(out + pos, nh);
   u8* heads = out + pos;
-  u32 tail = B.sv_off[d + 1] - B.sv_off[d];   // head indices are written from the sorted order below
   // heads sorted by hash; their change indices follow the column data in the same order
   u32 placed = 0;
   for (u32 i = 0; i < nc; i++) {
@@ -1925,7 +1926,6 @@ AMH_DEV void k_save_finish(const BatchDev& B, u32 d) {
       if (amh_memcmp(B.c_hash + (u64)(cb + i) * 32, 32, heads + 32 * k, 32) == 0) { pos += wr_uleb(out + pos, i); break; }
     }
   }
-  (void)tail;
   out[0] = 0x85; out[1] = 0x6f; out[2] = 0x4a; out[3] = 0x83;
   out[8] = 0;
   wr_uleb(out + 9, body_len);

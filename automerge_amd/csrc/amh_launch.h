@@ -23,3 +23,10 @@ u32 amh_scan_tmp_words(u32 n);
 // tmp must hold amh_level_sort_tmp_words(B.tot_chg) u32 words.
 void amh_level_sort(const BatchDev& B, u32* tmp, void* stream);
 u32 amh_level_sort_tmp_words(u32 tot_chg);
+
+// merge kernels (amh_merge.inl): G is the MergeDev in device memory (host memory in the emulation)
+enum MgKernel {
+  MK_NEW_FLAG = 0, MK_PAIR_COUNTS, MK_SUBTREE, MK_GAP, MK_INHERIT, MK_EXTRA_CNT, MK_ROWS_DST, MK_ROWS_NEW, MK_SUCC_DST,
+  MK_SUCC_NEW, MK_SUCC_EXTRA, MK_SUCC_SORT, MK_DOC_SUCC, MK_CHANGES, MK_COPY_CHUNKS, MK_NUM
+};
+void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream);

@@ -166,3 +166,37 @@ struct BatchDev {
   u32* sync_off;                 // [n_docs + 1] record offsets of the sync summaries
   u8* sync_out;
 };
+
+// ---------------------------------------------------------------------------------------------
+// merge: dst[p_a[p]].merge(src[p_b[p]]) for P pairs (automerge.rs:917-940).  D, S = the two loaded
+// batches, M = a scratch batch of P merged documents in "loaded" form (rows in document order, succ
+// lists, change metadata) over a virtual chunk = [dst chunk | src chunk]; the save kernels turn M into
+// document chunks, which are loaded again (so every merged document is re-verified end to end).
+// The host decides which changes are new and in which order they apply (O(changes) replay of
+// automerge.rs:797-858, 1311-1334) and unions the actor tables; everything per op is on the device.
+// ---------------------------------------------------------------------------------------------
+struct MergeDev {
+  BatchDev D, S, M;
+  u32 n_pairs;
+  const u32 *p_a, *p_b;            // [P] document index in D / S
+  i32* p_status;                   // [P] 0 = ok (host pre-sets failures; kernels may add AMH_E_UNSUPPORTED)
+  const u32 *d_pair, *s_pair;      // [D.n_docs] / [S.n_docs] pair of the document, or AMH_NULL32
+  const u32 *mapa_base, *mapb_base;// [P + 1] bases into map_a / map_b (+ map_b2a)
+  const u32 *map_a, *map_b;        // document-local actor index -> index in the merged (sorted) table
+  const u32* map_b2a;              // src actor index -> dst actor index, or AMH_NULL32
+  const u8* s_added;               // [S.tot_chg] the change is applied by this merge
+  const u32* a_len_pad;            // [P] dst chunk length rounded up to 16 = offset of the src chunk in the virtual chunk
+  const u32* mc_from;              // [M.tot_chg] source of each merged change: bit 31 = from S, low bits = global change index
+  // new rows (rows of S whose change is added), compacted in S order
+  u32* new_idx;                    // [S.tot_rows + 1] flag, then exclusive scan
+  u32 tot_new;
+  u32 *new_src, *new_gap;          // [tot_new] S row; dst-local row index the row is inserted before (AMH_NULL32 = inherit)
+  u32* gap_base;                   // [P + 1] per pair region of rows(dst) + 1 counters
+  u32* gap_cnt;                    // counters, then exclusive scan
+  // dst sequence structure
+  u32 *sub_end, *upd_end;          // [D.tot_rows] (document-local indices) end of an element's subtree / of its own update rows
+  u32* stack;                      // [D.tot_rows] scratch of k_mg_subtree
+  u32* x_cnt;                      // [D.tot_rows] succ entries a dst row gains
+  u32* x_fill;                     // [D.tot_rows]
+  u32* d_to_m;                     // [D.tot_rows] merged row of a dst row
+};

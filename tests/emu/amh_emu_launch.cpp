@@ -4,6 +4,7 @@
 // never part of libautomerge_hip.so and never loaded by the automerge_amd package.
 #define AMH_EMU
 #include "../../automerge_amd/csrc/amh_kernels.inl"
+#include "../../automerge_amd/csrc/amh_merge.inl"
 #include "../../automerge_amd/csrc/amh_launch.h"
 
 void amh_launch(int k, const BatchDev& B, u32 n, void*) {
@@ -37,4 +38,15 @@ void amh_level_sort(const BatchDev& B, u32*, void*) {
   for (u32 l = 0; l <= AMH_LEVEL_CAP; l++) cnt[l + 1] += cnt[l];
   for (u32 l = 0; l <= AMH_LEVEL_CAP + 1; l++) B.lvl_start[l] = cnt[l];
   for (u32 c = 0; c < B.tot_chg; c++) B.lvl_order[cnt[chg_level_bucket(B, c)]++] = c;
+}
+void amh_launch_mg(int k, const MergeDev* G, u32 n, void*) {
+#define M(id, name) case id: for (u32 i = 0; i < n; i++) name(*G, i); break;
+  switch (k) {
+    M(MK_NEW_FLAG, k_mg_new_flag) M(MK_PAIR_COUNTS, k_mg_pair_counts) M(MK_SUBTREE, k_mg_subtree) M(MK_GAP, k_mg_gap)
+    M(MK_INHERIT, k_mg_inherit) M(MK_EXTRA_CNT, k_mg_extra_cnt) M(MK_ROWS_DST, k_mg_rows_dst) M(MK_ROWS_NEW, k_mg_rows_new)
+    M(MK_SUCC_DST, k_mg_succ_dst) M(MK_SUCC_NEW, k_mg_succ_new) M(MK_SUCC_EXTRA, k_mg_succ_extra) M(MK_SUCC_SORT, k_mg_succ_sort)
+    M(MK_DOC_SUCC, k_mg_doc_succ) M(MK_CHANGES, k_mg_changes) M(MK_COPY_CHUNKS, k_mg_copy_chunks)
+    default: break;
+  }
+#undef M
 }

@@ -1,0 +1,44 @@
+"""Merge scenarios shared by the CPU-tier (emulation) and GPU tests: divergent documents built with
+the oracle from generated histories, merged by the engine and by the oracle, compared bit for bit."""
+import oracle_lib as o
+
+
+def split_map_doc(doc_bytes, n_actors=4, rounds=5, common_rounds=3):
+    """Two causally closed, divergent documents out of one generated map document: both share the first
+    `common_rounds` rounds; A continues with the later changes of the first half of the actors, B with the others."""
+    chunks = [c["raw"] for c in o.Doc.load(doc_bytes).changes()]
+    common = chunks[:common_rounds * n_actors]
+    a, b = list(common), list(common)
+    for r in range(common_rounds, rounds):
+        for k in range(n_actors):
+            c = chunks[r * n_actors + k]
+            if r == common_rounds:
+                (a if k < n_actors // 2 else b).append(c)
+    da, db = o.Doc(), o.Doc()
+    da.apply_changes(a)
+    db.apply_changes(b)
+    return da.save(deflate=False), db.save(deflate=False)
+
+
+def check_merge(engine, dst_docs, src_docs, pairs):
+    """engine: dst[a].merge(src[b]) for the pairs; oracle the same; everything observable must agree"""
+    bd, bs = engine.load_batch(dst_docs), engine.load_batch(src_docs)
+    rc = bd.merge(bs, pairs)
+    assert rc == 0
+    paired = dict(pairs)
+    for a, data in enumerate(dst_docs):
+        ref = o.Doc.load(data)
+        if a in paired:
+            ref.merge(o.Doc.load(src_docs[paired[a]]))
+        bd.check(a)
+        assert bd.hydrate_json(a) == ref.hydrate_json(), a
+        assert bd.get_heads(a) == ref.get_heads(), a
+        assert [c["hash"] for c in bd.get_changes(a)] == [c["hash"] for c in ref.changes()], a   # history order
+        assert bd.max_op(a) == ref.max_op()
+    saved = bd.save_all(deflate=False)
+    for a, data in enumerate(dst_docs):
+        ref = o.Doc.load(data)
+        if a in paired:
+            ref.merge(o.Doc.load(src_docs[paired[a]]))
+        assert saved[a] == ref.save(deflate=False), a
+    return bd

@@ -176,3 +176,45 @@ def test_save(engine, golden_dir):
     b2 = engine.load_batch([p for p in packed[:-1]])
     for i in range(len(docs) - 1):
         assert b2.hydrate_json(i) == batch.hydrate_json(i) and b2.get_heads(i) == batch.get_heads(i)
+
+
+def test_merge_map_documents(engine):
+    """concurrent map edits on both sides: conflicts, overwrites of common ops (new succ entries), counters, deletes,
+    new keys, actors only one side knows"""
+    from merge_cases import check_merge, split_map_doc
+    blob, offs = engine.gen_map_docs(41, 6, 4, 5, 30, 24, 2)
+    docs = [blob[offs[i]:offs[i + 1]] for i in range(6)]
+    pairs_docs = [split_map_doc(d) for d in docs]
+    dst = [a for a, _ in pairs_docs] + [docs[0]]          # the last document is not part of any pair
+    src = [b for _, b in pairs_docs]
+    check_merge(engine, dst, src, [(i, i) for i in range(6)])
+    # merging the other way round gives the same document state
+    check_merge(engine, src, [a for a, _ in pairs_docs], [(i, 5 - i) for i in range(6) if i == 5 - i] or [(0, 0)])
+
+
+def test_merge_text_replicas(engine):
+    """eight divergent replicas of text documents merged one after the other (RGA interleaving, deletes of
+    common elements, runs typed at the same position)"""
+    from merge_cases import check_merge
+    n_docs, n_rep = 3, 5
+    blob, offs = engine.gen_text_docs(0xE070, n_docs, n_rep, 60, 240, 40, 2)
+    reps = [[blob[offs[i * n_rep + r]:offs[i * n_rep + r + 1]] for i in range(n_docs)] for r in range(n_rep)]
+    cur = reps[0]
+    for r in range(1, n_rep):
+        bd = check_merge(engine, cur, reps[r], [(i, i) for i in range(n_docs)])
+        cur = bd.save_all(deflate=False)
+
+
+def test_merge_nothing_new_and_failures(engine):
+    from merge_cases import split_map_doc
+    blob, offs = engine.gen_map_docs(43, 2, 4, 5, 10, 8, 1)
+    docs = [blob[offs[i]:offs[i + 1]] for i in range(2)]
+    a, b = split_map_doc(docs[0])
+    bd, bs = engine.load_batch([docs[0], a, a]), engine.load_batch([a, b"\x85\x6f\x4a\x83garbage", b])
+    before = bd.save_all(deflate=False)
+    assert bd.merge(bs, [(0, 0), (1, 1)]) == -7          # (0,0): src is an ancestor, nothing to do; (1,1): src failed to load
+    assert bd.save_all(deflate=False) == before
+    assert bd.merge(bs, [(2, 2)]) == 0
+    import oracle_lib as o
+    ref = o.Doc.load(a); ref.merge(o.Doc.load(b))
+    assert bd.save_all(deflate=False)[2] == ref.save(deflate=False)
