@@ -648,9 +648,96 @@ AMH_GLOBAL_MG(k_mg_new_flag) AMH_GLOBAL_MG(k_mg_pair_counts) AMH_GLOBAL_MG(k_mg_
 AMH_GLOBAL_MG(k_mg_inherit) AMH_GLOBAL_MG(k_mg_extra_cnt) AMH_GLOBAL_MG(k_mg_rows_dst) AMH_GLOBAL_MG(k_mg_rows_new)
 AMH_GLOBAL_MG(k_mg_succ_dst) AMH_GLOBAL_MG(k_mg_succ_new) AMH_GLOBAL_MG(k_mg_succ_extra) AMH_GLOBAL_MG(k_mg_succ_sort)
 AMH_GLOBAL_MG(k_mg_doc_succ) AMH_GLOBAL_MG(k_mg_changes) AMH_GLOBAL_MG(k_mg_copy_chunks)
+// wave-per-pair forms of the two merge kernels that are serial per document: the wave streams the
+// rows through LDS with coalesced loads and one lane walks them (no memory round trip per step).
+#define MGS_STACK 2048u
+__global__ void __launch_bounds__(64) g_mg_subtree_wave(const MergeDev* Gp) {
+  const MergeDev& G = *Gp;
+  u32 p = blockIdx.x;
+  if (p >= G.n_pairs || G.p_status[p] != 0) return;
+  __shared__ u32 t_oc[64], t_oa[64], t_kc[64], t_ka[64], t_ic[64], t_ia[64], t_fl[64];
+  __shared__ u32 s_i[MGS_STACK], s_c[MGS_STACK], s_a[MGS_STACK];
+  const BatchDev& D = G.D;
+  const u32 lane = threadIdx.x;
+  u32 a = G.p_a[p], rb = D.row_base[a], n = D.cnt[a].n_rows;
+  u32 sp = 0, last_ins = AMH_NULL32, poc = 0, poa = 0;
+  bool bad = false;
+  auto pop_to = [&](u32 i) {   // end the subtree on top of the stack at row i
+    sp--;
+    u32 e = sp < MGS_STACK ? s_i[sp] : G.stack[rb + sp];
+    G.sub_end[rb + e] = i;
+  };
+  for (u32 t0 = 0; t0 < n; t0 += 64) {
+    u32 i = t0 + lane;
+    if (i < n) {
+      u32 r = rb + i;
+      t_oc[lane] = D.r_obj_ctr[r]; t_oa[lane] = D.r_obj_actor[r];
+      t_kc[lane] = D.r_key_ctr[r]; t_ka[lane] = D.r_key_actor[r];
+      t_ic[lane] = D.r_id_ctr[r]; t_ia[lane] = D.r_id_actor[r];
+      t_fl[lane] = (D.r_key_len[r] != AMH_NULL32 ? 1u : 0u) | (D.r_insert[r] ? 2u : 0u);
+      G.sub_end[r] = i + 1;
+      G.upd_end[r] = i + 1;
+    }
+    __syncthreads();
+    if (lane == 0 && !bad) {
+      u32 cnt = n - t0 < 64 ? n - t0 : 64;
+      for (u32 k = 0; k < cnt; k++) {
+        u32 ii = t0 + k;
+        if (ii == 0 || t_oc[k] != poc || t_oa[k] != poa) {   // object boundary
+          while (sp) pop_to(ii);
+          if (last_ins != AMH_NULL32) G.upd_end[rb + last_ins] = ii;
+          last_ins = AMH_NULL32;
+          poc = t_oc[k]; poa = t_oa[k];
+        }
+        u32 fl = t_fl[k];
+        if ((fl & 1) || !(fl & 2)) continue;   // map row, or an update of an element
+        if (last_ins != AMH_NULL32) G.upd_end[rb + last_ins] = ii;
+        last_ins = ii;
+        u32 kc = t_kc[k], ka = t_ka[k];
+        if (kc == 0) { while (sp) pop_to(ii); }
+        else {
+          for (;;) {
+            if (!sp) { bad = true; break; }
+            u32 tc, ta;
+            if (sp - 1 < MGS_STACK) { tc = s_c[sp - 1]; ta = s_a[sp - 1]; }
+            else { u32 e = G.stack[rb + sp - 1]; tc = D.r_id_ctr[rb + e]; ta = D.r_id_actor[rb + e]; }
+            if (tc == kc && ta == ka) break;
+            pop_to(ii);
+          }
+          if (bad) break;
+        }
+        if (sp < MGS_STACK) { s_i[sp] = ii; s_c[sp] = t_ic[k]; s_a[sp] = t_ia[k]; }
+        else G.stack[rb + sp] = ii;
+        sp++;
+      }
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    if (bad) { G.p_status[p] = AMH_E_UNSUPPORTED; return; }
+    while (sp) pop_to(n);
+    if (last_ins != AMH_NULL32) G.upd_end[rb + last_ins] = n;
+  }
+}
+// the virtual chunk [dst chunk | src chunk]: one block per pair, 16-byte copies (chunks are 16-byte aligned and padded)
+__global__ void __launch_bounds__(AMH_BLOCK) g_mg_copy_chunks_blk(const MergeDev* Gp) {
+  const MergeDev& G = *Gp;
+  u32 p = blockIdx.x;
+  if (p >= G.n_pairs || G.p_status[p] != 0) return;
+  u32 a = G.p_a[p], b = G.p_b[p];
+  uint4* dst = (uint4*)(const_cast<u8*>(G.M.arena) + G.M.desc[p].chunk_off);
+  const uint4* sa = (const uint4*)(G.D.arena + G.D.desc[a].chunk_off);
+  const uint4* sb = (const uint4*)(G.S.arena + G.S.desc[b].chunk_off);
+  u32 na = (G.D.desc[a].chunk_len + 15) / 16, nb = (G.S.desc[b].chunk_len + 15) / 16, shift = G.a_len_pad[p] / 16;
+  for (u32 i = threadIdx.x; i < na; i += AMH_BLOCK) dst[i] = sa[i];
+  for (u32 i = threadIdx.x; i < nb; i += AMH_BLOCK) dst[shift + i] = sb[i];
+}
+
 void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream) {
   if (n == 0) return;
   hipStream_t s = (hipStream_t)stream;
+  if (k == MK_SUBTREE) { hipLaunchKernelGGL(g_mg_subtree_wave, dim3(n), dim3(64), 0, s, G); return; }
+  if (k == MK_COPY_CHUNKS) { hipLaunchKernelGGL(g_mg_copy_chunks_blk, dim3(n), dim3(AMH_BLOCK), 0, s, G); return; }
   dim3 grid((n + AMH_BLOCK - 1) / AMH_BLOCK), block(AMH_BLOCK);
 #define M(id, name) case id: hipLaunchKernelGGL(g_##name, grid, block, 0, s, G, n); break;
   switch (k) {

@@ -88,6 +88,82 @@ def column_bytes(eng, batch, n_docs):
     }
 
 
+def bench_merge(args, eng, rank, world, dist, torch):
+    """configs[2]: `--docs` text documents per GPU (default there: 10k), each a 1,000-character base + `--replicas`
+    divergent replicas of 5,000 edits (70 % inserts in runs, 30 % deletes).  One step = load all replicas (one
+    batch per replica index) and merge replicas 1..R-1 into replica 0, document by document."""
+    import ctypes as C
+    R = args.replicas
+    threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), 32))
+    t0 = time.time()
+    blob, offs = eng.gen_text_docs(0xB070 + rank * args.docs, args.docs, R, 1000, 5000, 500, threads)
+    t_gen = time.time() - t0
+    reps = [[blob[offs[i * R + r]:offs[i * R + r + 1]] for i in range(args.docs)] for r in range(R)]
+    staged = [eng.stage(reps[r]) for r in range(R)]
+    pairs = [(i, i) for i in range(args.docs)]
+
+    def step():
+        batches = [eng.load_staged(s) for s in staged]
+        t_load = time.perf_counter()
+        for r in range(1, R):
+            rc = batches[0].merge(batches[r], pairs)
+            assert rc == 0, rc
+        return batches, t_load
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    load_s = 0.0
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        batches, tl = step()
+        load_s += tl - ts
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = batches[0].stats()
+    assert st["n_ok"] == args.docs
+    ops = st["ops_loaded"]
+    tot = torch.tensor([float(elapsed), float(ops)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed_max, ops_all = float(tmax[0]), float(tot[1])
+    else:
+        elapsed_max, ops_all = elapsed, float(ops)
+    if rank == 0:
+        out = {"metric": "ops loaded+merged/sec (node)", "value": ops_all * args.steps / elapsed_max, "unit": "ops/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64", "data": "synthetic",
+               "config": {"workload": f"configs[2]: text documents x {R} divergent replicas of 5k edits, load {R} + merge {R - 1}",
+                          "docs_per_gpu": args.docs, "ops_per_merged_doc": ops / args.docs, "gen_s": round(t_gen, 2),
+                          "load_ms_per_step": load_s / args.steps * 1e3, "merge_ms_per_step": (elapsed - load_s) / args.steps * 1e3,
+                          "note": "merge round-trips the merged documents through the host (save bytes -> reload); ops counted once per merged document"}}
+        if not args.no_cpu and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as o
+            ns = min(args.docs, 64)
+            t0 = time.perf_counter()
+            n_ops = 0
+            for i in range(ns):
+                d = o.Doc.load(reps[0][i])
+                for r in range(1, R):
+                    d.merge(o.Doc.load(reps[r][i]))
+                n_ops += d.num_ops()
+            secs = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": n_ops / secs, "unit": "ops/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {ns} documents, load {R} + merge {R - 1} on one thread (CPU restatement in oracle/, not the Rust reference)"}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +172,9 @@ def main():
     ap.add_argument("--docs", type=int, default=100000, help="documents per GPU (configs[1]: 100k)")
     ap.add_argument("--cpu-sample", type=int, default=4000, help="documents of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", default="load", choices=["load", "merge"],
+                    help="load = configs[1] (the headline line); merge = configs[2]: text documents x 8 divergent replicas, load 8 + merge 7")
+    ap.add_argument("--replicas", type=int, default=8)
     args = ap.parse_args()
 
     import torch
@@ -113,6 +192,8 @@ def main():
 
     from automerge_amd import Engine
     eng = Engine(gpu=local_rank)
+    if args.workload == "merge":
+        return bench_merge(args, eng, rank, world, dist, torch)
     threads = int(os.environ.get("OMP_NUM_THREADS", "16")) if world == 1 else max(2, int(os.environ.get("OMP_NUM_THREADS", "16")) // max(1, world))
     threads = max(1, min(threads, 32))
     seed = 0xA070 + rank * args.docs
