@@ -793,7 +793,7 @@ extern "C" int amh_debug_array(const amh_batch* b, const char* name, void* out, 
     {"c_msg_off", B.c_msg_off, NC * 4}, {"c_msg_len", B.c_msg_len, NC * 4}, {"c_ndeps", B.c_ndeps, NC * 4},
     {"c_dep_base", B.c_dep_base, NC * 4}, {"c_extra_off", B.c_extra_off, NC * 4}, {"c_extra_len", B.c_extra_len, NC * 4},
     {"c_doc", B.c_doc, NC * 4}, {"dep_idx", B.dep_idx, (size_t)B.tot_deps * 4}, {"c_nops", B.c_nops, NC * 4},
-    {"c_start_op", B.c_start_op, NC * 8}, {"c_op_base", B.c_op_base, (NC + 1) * 4}, {"c_next_same_actor", B.c_next_same_actor, NC * 4}, {"c_level", B.c_level, NC * 4},
+    {"c_start_op", B.c_start_op, NC * 8}, {"c_op_base", B.c_op_base, (NC + 1) * 4}, {"c_next_same_actor", B.c_next_same_actor, NC * 4}, {"c_level", B.c_level, NC * 4}, {"c_wide", B.c_wide, NC * 4},
     {"c_hash", B.c_hash, NC * 32}, {"c_out_off", B.c_out_off, (NC + 1) * 4}, {"c_out_len", B.c_out_len, NC * 4},
     {"c_body_len", B.c_body_len, NC * 4}, {"c_cols_off", B.c_cols_off, NC * 4}, {"c_col_len", B.c_col_len, NC * AMH_NCOLS * 4},
     {"c_map_base", B.c_map_base, NC * 4}, {"c_n_other", B.c_n_other, NC * 4}, {"chg_actor_map", B.chg_actor_map, (size_t)b->tot_map * 4},

@@ -1,6 +1,7 @@
 // HIP launch wrappers for the batched document-load kernels (gfx950).  The per-thread bodies live
 // in amh_kernels.inl; this file gives each of them a grid.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "amh_kernels.inl"
 #include "amh_merge.inl"
@@ -493,7 +494,7 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
   if (k == AK_ENCODE_STORE) {
     hipLaunchKernelGGL((g_encode_lds<true>), dim3((B.tot_chg + 63) / 64), dim3(64), 0, s, B);
     // columns with a literal run of more than 64 values (flagged in c_wide): byte-wise writer that can widen the header
-    hipLaunchKernelGGL(g_k_encode_store, dim3((n + AMH_BLOCK - 1) / AMH_BLOCK), dim3(AMH_BLOCK), 0, s, B, n);
+    if (!getenv("AMH_SKIP_WIDE")) hipLaunchKernelGGL(g_k_encode_store, dim3((n + AMH_BLOCK - 1) / AMH_BLOCK), dim3(AMH_BLOCK), 0, s, B, n);
     return;
   }
   dim3 grid((n + AMH_BLOCK - 1) / AMH_BLOCK), block(AMH_BLOCK);

@@ -88,7 +88,7 @@ def column_bytes(eng, batch, n_docs):
     }
 
 
-def bench_merge(args, eng, rank, world, dist, torch):
+def bench_merge(args, eng, rank, world, dist, torch, red_dev):
     """configs[2]: `--docs` text documents per GPU (default there: 10k), each a 1,000-character base + `--replicas`
     divergent replicas of 5,000 edits (70 % inserts in runs, 30 % deletes).  One step = load all replicas (one
     batch per replica index) and merge replicas 1..R-1 into replica 0, document by document."""
@@ -129,7 +129,7 @@ def bench_merge(args, eng, rank, world, dist, torch):
     st = batches[0].stats()
     assert st["n_ok"] == args.docs
     ops = st["ops_loaded"]
-    tot = torch.tensor([float(elapsed), float(ops)], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(elapsed), float(ops)], dtype=torch.float64, device=red_dev)
     if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -183,19 +183,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
+    # one process per GPU; AMH_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a 1-GPU box)
+    backend = os.environ.get("AMH_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     from automerge_amd import Engine
     eng = Engine(gpu=local_rank)
     if args.workload == "merge":
-        return bench_merge(args, eng, rank, world, dist, torch)
-    threads = int(os.environ.get("OMP_NUM_THREADS", "16")) if world == 1 else max(2, int(os.environ.get("OMP_NUM_THREADS", "16")) // max(1, world))
-    threads = max(1, min(threads, 32))
+        return bench_merge(args, eng, rank, world, dist, torch, red_dev)
+    omp = int(os.environ.get("OMP_NUM_THREADS", "16"))
+    threads = max(1, min(omp if world == 1 else max(4, omp // world), 32))   # host threads of the (untimed) generator
     seed = 0xA070 + rank * args.docs
     t0 = time.time()
     arena = eng.gen_map_arena(seed, args.docs, 4, 5, 50, 128, threads)
@@ -229,7 +236,7 @@ def main():
     if n_bad:
         raise SystemExit(f"{n_bad} documents failed to load: the benchmark input must load cleanly")
     ops = st["ops_loaded"]
-    tot = torch.tensor([float(elapsed), float(ops)], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(elapsed), float(ops)], dtype=torch.float64, device=red_dev)
     if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
