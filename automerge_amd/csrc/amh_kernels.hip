@@ -231,6 +231,102 @@ __global__ void __launch_bounds__(64) g_decode_cols(BatchDev B) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Row / succ / change / dep counts (device form of k_count), same staging as the column decode:
+// lane = document, each lane reads its column through an LDS window refilled cooperatively.
+// Four passes: id-counter run headers -> rows; succ-count values -> succ entries; change actor
+// values -> changes; dep-count values -> deps.
+// ------------------------------------------------------------------------------------------
+struct CountShared {
+  u32 win[64][DEC_W / 4 + 1];
+  u64 src[64];
+};
+__global__ void __launch_bounds__(64) g_count_lds(BatchDev B) {
+  __shared__ CountShared S;
+  const u32 lane = threadIdx.x;
+  const u32 d = blockIdx.x * 64 + lane;
+  const u32 dd = d < B.n_docs ? d : 0;
+  bool live = d < B.n_docs && B.status[dd] == 0 && B.desc[dd].chunk_len != 0;
+  const DocDesc& D = B.desc[dd];
+  const u8* wp = (const u8*)S.win[lane];
+  i32 fail_code = 0;
+  u64 rows = 0, succ = 0, chg = 0, deps = 0;
+  for (int pass = 0; pass < 4; pass++) {
+    const ColRef cr = pass == 0 ? D.ocol[OC_ID_CTR] : pass == 1 ? D.ocol[OC_SUCC_NUM] : pass == 2 ? D.ccol[CC_ACTOR] : D.ccol[CC_DEPS_NUM];
+    const u32 off = cr.off, len = cr.len;
+    const i32 err = pass < 2 ? AMH_E_READ_OP : AMH_E_READ_CHANGE;
+    RleDec r;
+    u32 wbase = off & ~3u;
+    rle_init(r, wp - wbase, off, len);
+    r.gp = B.arena + D.chunk_off;
+    u64 lit = 0;            // pass 0: literal values still to skip
+    u64 todo = pass == 1 ? rows : (pass == 3 ? chg : 0);   // passes 1, 3: values to read
+    bool active = live && fail_code == 0;
+    if (pass == 1 || pass == 3) active = active && todo > 0;
+    bool first = true;
+    while (__ballot(active)) {
+      bool need = first || (active && r.pos + DEC_NEED > (u64)wbase + DEC_W && (u64)wbase + DEC_W < (u64)off + len);
+      if (__ballot(need)) {
+        first = false;
+        u32 nb = (r.pos > (u64)off + len ? off + len : (u32)r.pos) & ~3u;
+        wbase = nb;
+        S.src[lane] = D.chunk_off + nb;
+        __syncthreads();
+#pragma unroll 4
+        for (u32 l0 = 0; l0 < 64; l0 += 64 / (DEC_W / 4)) {
+          u32 l = l0 + lane / (DEC_W / 4), k = lane % (DEC_W / 4);
+          S.win[l][k] = *(const u32*)(B.arena + S.src[l] + 4 * k);
+        }
+        __syncthreads();
+        r.p = wp - wbase;
+      }
+      if (!active) continue;
+      u64 v = 0; u32 aux = 0; bool isnull = false;
+      if (pass == 0) {
+        if (lit > 0) {
+          if (!rle_read_value<1>(r, v, aux)) { fail_code = err; active = false; }
+          lit--;
+        } else if (r.pos >= r.end) {
+          active = false;
+        } else {
+          i64 n;
+          if (!rd_sleb_lenient(r.p, r.pos, r.end, n)) { fail_code = err; active = false; }
+          else if (n > 0) {
+            if (!rle_read_value<1>(r, v, aux)) { fail_code = err; active = false; }
+            rows += (u64)n;
+          } else if (n < 0) {
+            u64 k = (n == INT64_MIN) ? (u64)INT64_MAX : (u64)(-n);
+            if (k > r.end - r.pos) { fail_code = err; active = false; }   // each literal takes >= 1 byte
+            else { lit = k; rows += k; }
+          } else {
+            u64 nulls;
+            if (!rd_uleb_lenient(r.p, r.pos, r.end, nulls) || nulls) { fail_code = err; active = false; }   // a null id is "unexpected null" (opid.rs:114-117)
+          }
+          if (active && rows > AMH_MAX_ROWS_PER_DOC) { fail_code = AMH_E_TOO_LARGE; active = false; }
+        }
+      } else if (pass == 2) {
+        int rc = rle_next<0>(r, v, aux, isnull);
+        if (rc < 0) { fail_code = err; active = false; }
+        else if (rc == 1 || isnull) active = false;
+        else { chg++; if (chg > AMH_MAX_ROWS_PER_DOC) { fail_code = AMH_E_TOO_LARGE; active = false; } }
+      } else {
+        int rc = rle_next<0>(r, v, aux, isnull);
+        if (rc != 0 || isnull) { fail_code = err; active = false; }
+        else {
+          u64& acc = pass == 1 ? succ : deps;
+          acc += v;
+          if (v > AMH_MAX_ROWS_PER_DOC || acc > AMH_MAX_ROWS_PER_DOC) { fail_code = AMH_E_TOO_LARGE; active = false; }
+          if (--todo == 0) active = false;
+        }
+      }
+    }
+  }
+  if (d < B.n_docs && live) {
+    if (fail_code) amh_fail(B, dd, fail_code);
+    else { DocCounts& C = B.cnt[dd]; C.n_rows = (u32)rows; C.n_succ = (u32)succ; C.n_chg = (u32)chg; C.n_deps = (u32)deps; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Change re-encode, LDS-staged (replaces the thread-per-(change, column) kernels k_encode_size /
 // k_encode_store on the device; those remain the host-emulation form of the same encoders).
 //
@@ -486,6 +582,7 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
 void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
   if (n == 0) return;
   hipStream_t s = (hipStream_t)stream;
+  if (k == AK_COUNT) { hipLaunchKernelGGL(g_count_lds, dim3((B.n_docs + 63) / 64), dim3(64), 0, s, B); return; }
   if (k == AK_DECODE_OPS) {
     hipLaunchKernelGGL(g_decode_cols, dim3((B.n_docs + 63) / 64, OC_COUNT), dim3(64), 0, s, B);
     return;
