@@ -259,6 +259,18 @@ def main():
     per_launch_bytes = model[dom] / dom_calls
     achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
     total_kernel_ms = sum(v[0] for v in kt.values())
+    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    # (profiles/traffic_latest.json, tools/pmc_traffic.py); null when the file is missing
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))["kernels"]
+        names = {"encode_store": ["void g_encode_lds<true>(BatchDev)", "g_k_encode_store(BatchDev, unsigned int)"],
+                 "encode_size": ["void g_encode_lds<false>(BatchDev)"], "decode_ops": ["g_decode_cols(BatchDev)", "g_k_decode_ops(BatchDev, unsigned int)"],
+                 "count": ["g_count_lds(BatchDev)"]}.get(dom, [f"g_k_{dom}(BatchDev, unsigned int)"])
+        vals = [tj[nm]["traffic"] for nm in names if nm in tj]
+        traffic = sum(vals) if vals else None
+    except Exception:
+        traffic = None
     kernels = {k: {"ms": round(v[0] / max(1, v[1]), 4), "launches": v[1],
                    "GBps": round(model[k] / v[1] / (v[0] / v[1] * 1e-3) / 1e9, 2) if v[0] > 0 and v[1] > 0 else None}
                for k, v in kt.items() if v[1] > 0}
@@ -271,7 +283,7 @@ def main():
                    "sharding": f"documents x{world}", "gen_s": round(t_gen, 2), "stage_s": round(t_stage, 2),
                    "pcie_inclusive_ops_per_s": ops / (elapsed / args.steps + t_stage)},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": per_launch_bytes,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": per_launch_bytes,
                      "launch_ms": per_launch_ms, "kernel_ms_total": total_kernel_ms},
         "kernels": kernels,
     }

@@ -138,10 +138,15 @@ int amh_hydrate_json(const amh_batch*, uint32_t doc, amh_bytes_out* out);
 /* max op counter of the document (Automerge::max_op, automerge.rs:181) */
 int amh_doc_max_op(const amh_batch*, uint32_t doc, uint64_t* max_op);
 
-/* ---- merge / apply / save (boundary declared; device path lands in a later round) ------------
- * == dst[i].merge(&mut src[j]) (automerge.rs:917-940; AMmerge, automerge-c/src/doc.rs:564) */
+/* ---- merge / apply / save ---------------------------------------------------------------------
+ * == dst[dst_idx[p]].merge(&mut src[src_idx[p]]) for every pair, in place (automerge.rs:917-940; AMmerge,
+ * automerge-c/src/doc.rs:564).  dst and src are different batches; a document appears in at most one pair
+ * per call.  Returns AMH_ERR_DOC_FAILED when some pairs were left unmerged (a document that failed to load,
+ * DuplicateSeqNumber); their dst documents are unchanged.  Every merged document is re-verified (change
+ * hashes, heads) before it replaces the old one. */
 int amh_merge_batch(amh_ctx*, amh_batch* dst, const amh_batch* src, const uint32_t* dst_idx, const uint32_t* src_idx, size_t n_pairs);
-/* == Automerge::apply_changes (automerge.rs:785; AMapplyChanges, automerge-c/src/doc.rs:84) */
+/* == Automerge::apply_changes (automerge.rs:785; AMapplyChanges, automerge-c/src/doc.rs:84).
+ * Not built yet: returns AMH_ERR_UNIMPLEMENTED. */
 int amh_apply_changes(amh_ctx*, amh_batch*, uint32_t doc, const uint8_t* const* changes, const size_t* lens, size_t n);
 /* == Automerge::save_with_options (automerge.rs:943-965; AMsave, automerge-c/src/doc.rs:751);
  * out = array of n_docs amh_bytes_out, each freed with amh_bytes_free.  A document that failed to load (or whose
