@@ -40,7 +40,7 @@ EXPORTS = [
     "amh_load_batch", "amh_batch_free", "amh_bytes_free", "amh_doc_status", "amh_batch_get_stats", "amh_heads",
     "amh_changes", "amh_hydrate_json", "amh_doc_max_op", "amh_merge_batch", "amh_apply_changes", "amh_save_batch",
     "amh_sync_summaries", "amh_ctx_set_profiling", "amh_ctx_num_kernels", "amh_ctx_kernel_name", "amh_ctx_kernel_time",
-    "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free",
+    "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free", "amh_apply_batch", "amh_doc_queue_len",
 ]
 
 DOC_ERRORS = {
@@ -89,6 +89,10 @@ def bind(lib):
     lib.amh_sync_summaries.argtypes = [vp, vp, C.POINTER(BytesOut)]
     lib.amh_save_batch.argtypes = [vp, vp, C.POINTER(SaveOpts), C.POINTER(BytesOut)]
     lib.amh_merge_batch.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]
+    lib.amh_apply_changes.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t]
+    lib.amh_apply_batch.argtypes = [vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int,
+                                    C.POINTER(C.c_int)]
+    lib.amh_doc_queue_len.argtypes = [vp, C.c_uint32, C.POINTER(C.c_size_t)]
     return lib
 
 
@@ -220,6 +224,36 @@ class Batch:
         if rc not in (0, -7):
             raise EngineError(f"amh_merge_batch failed: {rc} {self.engine._err()}")
         return rc
+
+    def apply_changes(self, i, changes):
+        """== self[i].apply_changes(changes) (automerge.rs:785): `changes` = change chunks (Change::raw_bytes).
+        Raises AutomergeError with the reference's kind when the call fails for the document."""
+        res = self.apply_batch([(i, c) for c in changes])
+        if res and res[0]:
+            raise AutomergeError(res[0], "apply_changes")
+
+    def apply_batch(self, items, incremental=False):
+        """items = [(document, bytes)]: every buffer holds one or more chunks for that document, applied in order.
+        incremental=False is apply_changes per document; True is load_incremental (automerge.rs:730-769: chunks in
+        front of the first unreadable one are applied).  Returns the per-item outcome (0 or the AutomergeError kind)."""
+        n = len(items)
+        if n == 0:
+            return []
+        idx = (C.c_uint32 * n)(*[it[0] for it in items])
+        bufs = (C.c_char_p * n)(*[bytes(it[1]) for it in items])
+        lens = (C.c_size_t * n)(*[len(it[1]) for it in items])
+        res = (C.c_int * n)()
+        rc = self.engine.lib.amh_apply_batch(self.engine.ctx, self.h, idx, bufs, lens, n, 1 if incremental else 0, res)
+        if rc not in (0, -7):
+            raise EngineError(f"amh_apply_batch failed: {rc} {self.engine._err()}")
+        return list(res)
+
+    def queue_len(self, i):
+        n = C.c_size_t()
+        rc = self.engine.lib.amh_doc_queue_len(self.h, i, C.byref(n))
+        if rc != 0:
+            raise EngineError(f"amh_doc_queue_len failed: {rc}")
+        return n.value
 
     def save_all(self, deflate=True):
         """== Automerge::save_with_options per document (automerge.rs:943); None for documents without a saved form."""
@@ -357,10 +391,11 @@ class Engine:
             raise EngineError("amh_load_staged failed: " + self._err())
         return Batch(self, h, staged.n)
 
-    def load_batch(self, docs, verify_heads=True):
-        """== Automerge::load_with_options per document (automerge.rs:601)."""
+    def load_batch(self, docs, verify_heads=True, on_partial_load="error"):
+        """== Automerge::load_with_options per document (automerge.rs:601).  An input may be a document chunk followed
+        by change chunks, or change chunks alone; on_partial_load = "error" | "ignore" (OnPartialLoad)."""
         ptrs, lens, n = self._pack(docs)
-        opts = LoadOpts(1 if verify_heads else 0, 0)
+        opts = LoadOpts(1 if verify_heads else 0, 1 if on_partial_load == "ignore" else 0)
         h = self.lib.amh_load_batch(self.ctx, ptrs, lens, n, C.byref(opts))
         if not h:
             raise EngineError("amh_load_batch failed: " + self._err())

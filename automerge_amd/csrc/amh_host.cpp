@@ -125,7 +125,11 @@ struct amh_batch {
   mutable std::string msg_buf;
   u32 tot_ht = 0, tot_map = 0, tot_out = 0;
   mutable HostView hv;
+  // changes waiting for their dependencies (Automerge::queue, automerge.rs:168): raw chunks per document
+  std::unordered_map<u32, std::vector<std::vector<u8>>> queue;
 };
+
+static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts, bool trailing);
 
 // ---------------------------------------------------------------------------------------------
 // launch helpers
@@ -260,7 +264,11 @@ extern "C" void amh_batch_free(amh_batch* b) {
   delete b;
 }
 
+static int load_trailing_chunks(amh_ctx* ctx, amh_batch* b, const amh_load_opts* opts);
 extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts) {
+  return load_staged_impl(ctx, st_c, opts, true);
+}
+static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts, bool trailing) {
   if (!ctx || !st_c) { set_error(ctx, "invalid argument"); return nullptr; }
   amh_staged* st = const_cast<amh_staged*>(st_c);
   if (const char* e = getenv("AMH_DEBUG_STOP_AFTER")) g_dbg_stop_after = atoi(e);
@@ -425,6 +433,8 @@ extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, cons
   if (!rt_d2h(b->status.data(), B.status, n * sizeof(i32), ctx->stream) || !rt_d2h(b->fail_line.data(), B.fail_line, n * sizeof(u32), ctx->stream) || !rt_sync(ctx->stream))
     return fail(std::string("device pipeline failed: ") + rt_last_error());
   collect_profile(ctx);
+  // change chunks: a first chunk that is a change, and everything behind the first chunk (automerge.rs:657-695)
+  if (trailing && load_trailing_chunks(ctx, b, opts) != AMH_SUCCESS) { amh_batch_free(b); return nullptr; }
   return b;
 }
 
@@ -844,6 +854,301 @@ struct Hash32 {
 };
 struct Hash32Hasher { size_t operator()(const Hash32& h) const { size_t v; memcpy(&v, h.b, sizeof v); return v; } };
 
+// everything the host decides for a merge / apply call (see MergeDev)
+struct MgPlan {
+  u32 P = 0;
+  std::vector<u32> d_pair, s_pair, p_a, p_b, a_len_pad;
+  std::vector<i32> p_status;
+  std::vector<u32> mapa_base, mapb_base, map_a, map_b, map_b2a;
+  std::vector<u8> s_added;
+  std::vector<u32> m_actor_base, m_actor_off, m_actor_len, m_actor_rank;
+  std::vector<u32> m_chg_base, mc_from, mc_ndeps, mc_dep_base, m_dep_idx, mc_doc;
+  std::vector<u8> mc_is_dep;
+  std::vector<DocDesc> m_desc;
+  std::vector<DocCounts> m_cnt;
+  u64 arena_len = 0;
+  int n_failed = 0;
+};
+// apply only: the staged change chunks (batch U, already decoded and verified) and the host's decisions
+struct ApplyRun {
+  BatchDev U{};
+  u32 n_chunks = 0;
+  ChgHdr* d_hdr = nullptr;
+  u32* d_u_chg = nullptr;
+  u32* d_u_fill = nullptr;
+  std::vector<u32> c_pair, c_rel, amap_base, amap, ix_base, ix_actor, ix_start, ix_nops, ix_row;
+  std::vector<u8> c_applied;
+  std::vector<DocDesc> s_desc;       // per pair: region of the arena holding its chunks
+  std::vector<DocCounts> s_cnt;      // per pair: rows of U
+  std::vector<u32> s_row_base;       // [P + 1]
+};
+#define MG_REFS(pl)                                                                                                   \
+  auto &d_pair = (pl).d_pair, &s_pair = (pl).s_pair, &p_a = (pl).p_a, &p_b = (pl).p_b, &a_len_pad = (pl).a_len_pad;   \
+  auto& p_status = (pl).p_status;                                                                                     \
+  auto &mapa_base = (pl).mapa_base, &mapb_base = (pl).mapb_base, &map_a = (pl).map_a, &map_b = (pl).map_b, &map_b2a = (pl).map_b2a; \
+  auto& s_added = (pl).s_added;                                                                                       \
+  auto &m_actor_base = (pl).m_actor_base, &m_actor_off = (pl).m_actor_off, &m_actor_len = (pl).m_actor_len, &m_actor_rank = (pl).m_actor_rank; \
+  auto &m_chg_base = (pl).m_chg_base, &mc_from = (pl).mc_from, &mc_ndeps = (pl).mc_ndeps, &mc_dep_base = (pl).mc_dep_base, &m_dep_idx = (pl).m_dep_idx, &mc_doc = (pl).mc_doc; \
+  auto& mc_is_dep = (pl).mc_is_dep;                                                                                   \
+  auto& m_desc = (pl).m_desc;                                                                                         \
+  auto& m_cnt = (pl).m_cnt;                                                                                           \
+  u64& arena_len = (pl).arena_len;                                                                                    \
+  int& n_failed = (pl).n_failed;                                                                                      \
+  (void)d_pair; (void)s_pair; (void)p_a; (void)p_b; (void)a_len_pad; (void)p_status; (void)mapa_base; (void)mapb_base; (void)map_a; (void)map_b; \
+  (void)map_b2a; (void)s_added; (void)m_actor_base; (void)m_actor_off; (void)m_actor_len; (void)m_actor_rank; (void)m_chg_base; (void)mc_from;   \
+  (void)mc_ndeps; (void)mc_dep_base; (void)m_dep_idx; (void)mc_doc; (void)mc_is_dep; (void)m_desc; (void)m_cnt; (void)arena_len; (void)n_failed;
+static void mg_plan_init(MgPlan& pl, u32 P, u32 nd, u32 ns, u32 s_tot_chg) {
+  pl.P = P;
+  pl.d_pair.assign(nd, AMH_NULL32); pl.s_pair.assign(ns, AMH_NULL32);
+  pl.p_a.assign(P, 0); pl.p_b.assign(P, 0); pl.a_len_pad.assign(P, 0); pl.p_status.assign(P, 0);
+  pl.mapa_base.assign(P + 1, 0); pl.mapb_base.assign(P + 1, 0); pl.s_added.assign((size_t)s_tot_chg + 1, 0);
+  pl.m_actor_base.assign(P + 1, 0); pl.m_chg_base.assign(P + 1, 0);
+  pl.m_desc.resize(P); pl.m_cnt.resize(P);
+}
+// length of the document chunk an input starts with: what a reload of an unchanged document feeds the
+// pipeline (the chunks behind it have been applied already).  0 when the input starts with a change chunk.
+static size_t first_doc_chunk_len(const u8* p, size_t avail) {
+  if (avail < 10 || p[0] != 0x85 || p[1] != 0x6f || p[2] != 0x4a || p[3] != 0x83) return avail;
+  if (p[8] == 1 || p[8] == 2) return 0;
+  if (p[8] != 0) return avail;
+  u64 len = 0; u32 shift = 0; size_t pos = 9;
+  for (;;) {
+    if (pos >= avail || shift > 63) return avail;
+    u8 b = p[pos++];
+    len |= (u64)(b & 0x7f) << shift;
+    if (!(b & 0x80)) break;
+    shift += 7;
+  }
+  if (len > avail - pos) return avail;
+  return pos + (size_t)len;
+}
+static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts, bool trailing);
+static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& pl, ApplyRun* ap, const char* who) {
+  MG_REFS(pl)
+  const BatchDev& DB = dst->B;
+  u32 P = pl.P;
+  // ---- device ---------------------------------------------------------------------------------
+  std::unique_ptr<amh_batch, void (*)(amh_batch*)> mbh(new amh_batch(), amh_batch_free);
+  amh_batch* mb = mbh.get();
+  mb->ctx = ctx;
+  MergeDev G;
+  memset(&G, 0, sizeof G);
+  G.D = DB; G.S = SB;
+  if (ap) G.U = ap->U;
+  BatchDev& M = G.M;
+  bool ok = true;
+  auto failm = [&](const char* m) { set_error(ctx, std::string(who) + ": " + m); collect_profile(ctx); return AMH_ERR_DEVICE; };
+  G.n_pairs = P;
+  G.p_a = upload(mb, p_a, &ok); G.p_b = upload(mb, p_b, &ok); G.p_status = upload(mb, p_status, &ok);
+  G.d_pair = upload(mb, d_pair, &ok); G.s_pair = upload(mb, s_pair, &ok);
+  G.mapa_base = upload(mb, mapa_base, &ok); G.mapb_base = upload(mb, mapb_base, &ok);
+  G.map_a = upload(mb, map_a, &ok); G.map_b = upload(mb, map_b, &ok); G.map_b2a = upload(mb, map_b2a, &ok);
+  G.s_added = upload(mb, s_added, &ok); G.a_len_pad = upload(mb, a_len_pad, &ok); G.mc_from = upload(mb, mc_from, &ok);
+  M.n_docs = P;
+  M.tot_chg = (u32)mc_from.size(); M.tot_actors = (u32)m_actor_off.size(); M.tot_deps = (u32)m_dep_idx.size();
+  M.status = balloc<i32>(mb, P + 1, &ok); M.fail_line = balloc<u32>(mb, P + 1, &ok);
+  M.desc = upload(mb, m_desc, &ok); M.cnt = upload(mb, m_cnt, &ok);
+  M.row_base = balloc<u32>(mb, P + 2, &ok); M.succ_base = balloc<u32>(mb, P + 2, &ok);
+  M.chg_base = upload(mb, m_chg_base, &ok); M.actor_base = upload(mb, m_actor_base, &ok);
+  M.actor_off = upload(mb, m_actor_off, &ok); M.actor_len = upload(mb, m_actor_len, &ok);
+  M.actor_rank = upload(mb, m_actor_rank, &ok); M.actor_by_rank = upload(mb, m_actor_rank, &ok);
+  size_t NC = M.tot_chg + 2;
+  M.c_actor = balloc<u32>(mb, NC, &ok); M.c_seq = balloc<u64>(mb, NC, &ok); M.c_max_op = balloc<u64>(mb, NC, &ok); M.c_time = balloc<i64>(mb, NC, &ok);
+  M.c_msg_off = balloc<u32>(mb, NC, &ok); M.c_msg_len = balloc<u32>(mb, NC, &ok); M.c_extra_off = balloc<u32>(mb, NC, &ok); M.c_extra_len = balloc<u32>(mb, NC, &ok);
+  M.c_hash = balloc<u8>(mb, NC * 32, &ok);
+  M.c_ndeps = upload(mb, mc_ndeps, &ok); M.c_dep_base = upload(mb, mc_dep_base, &ok); M.dep_idx = upload(mb, m_dep_idx, &ok);
+  M.c_doc = upload(mb, mc_doc, &ok); M.c_is_dep = upload(mb, mc_is_dep, &ok);
+  u8* m_arena = balloc<u8>(mb, (size_t)arena_len + 256, &ok);
+  M.arena = m_arena;
+  size_t NRD = DB.tot_rows + 2, NRS = SB.tot_rows + 2;
+  G.new_idx = balloc<u32>(mb, NRS, &ok); G.gap_base = balloc<u32>(mb, P + 2, &ok);
+  G.sub_end = balloc<u32>(mb, NRD, &ok); G.upd_end = balloc<u32>(mb, NRD, &ok); G.stack = balloc<u32>(mb, NRD, &ok);
+  G.x_cnt = balloc<u32>(mb, NRD, &ok); G.x_fill = balloc<u32>(mb, NRD, &ok); G.d_to_m = balloc<u32>(mb, NRD, &ok);
+  MergeDev* Gdev = (MergeDev*)balloc<u8>(mb, sizeof(MergeDev), &ok);
+  if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+  {
+    std::vector<i32> mst(P);
+    for (u32 p = 0; p < P; p++) mst[p] = p_status[p];   // documents of pairs that are not merged are skipped by the save kernels
+    if (!rt_h2d(M.status, mst.data(), P * sizeof(i32), ctx->stream)) return failm("H2D copy failed");
+  }
+  rt_memset(M.fail_line, 0, (P + 1) * 4, ctx->stream);
+  rt_memset(G.x_cnt, 0, NRD * 4, ctx->stream); rt_memset(G.x_fill, 0, NRD * 4, ctx->stream);
+  auto mg = [&](int k, u32 n) {
+    if (n == 0) return true;
+    if (!rt_h2d(Gdev, &G, sizeof(MergeDev), ctx->stream)) return false;
+#ifdef AMH_EMU
+    amh_launch_mg(k, &G, n, (void*)ctx->stream);
+#else
+    amh_launch_mg(k, Gdev, n, (void*)ctx->stream);
+#endif
+    return true;
+  };
+  if (ap) {
+    BatchDev &S = G.S, &U = G.U;
+    ApplyDev& A = G.A;
+    size_t NU = (size_t)U.tot_rows + 2, NC = (size_t)ap->n_chunks + 2;
+    S.desc = upload(mb, ap->s_desc, &ok); S.cnt = upload(mb, ap->s_cnt, &ok); S.row_base = upload(mb, ap->s_row_base, &ok);
+    S.r_succ_cnt = balloc<u32>(mb, NU, &ok); S.r_succ_base = balloc<u32>(mb, NU, &ok);
+    S.c_actor = balloc<u32>(mb, NC, &ok); S.c_seq = balloc<u64>(mb, NC, &ok); S.c_max_op = balloc<u64>(mb, NC, &ok); S.c_time = balloc<i64>(mb, NC, &ok);
+    S.c_msg_off = balloc<u32>(mb, NC, &ok); S.c_msg_len = balloc<u32>(mb, NC, &ok); S.c_extra_off = balloc<u32>(mb, NC, &ok); S.c_extra_len = balloc<u32>(mb, NC, &ok);
+    S.c_hash = balloc<u8>(mb, NC * 32, &ok);
+    A.hdr = ap->d_hdr; A.u_chg = ap->d_u_chg; A.u_fill = ap->d_u_fill;
+    A.c_pair = upload(mb, ap->c_pair, &ok); A.c_rel = upload(mb, ap->c_rel, &ok); A.c_applied = upload(mb, ap->c_applied, &ok);
+    A.amap_base = upload(mb, ap->amap_base, &ok); A.amap = upload(mb, ap->amap, &ok);
+    A.ix_base = upload(mb, ap->ix_base, &ok); A.ix_actor = upload(mb, ap->ix_actor, &ok); A.ix_start = upload(mb, ap->ix_start, &ok);
+    A.ix_nops = upload(mb, ap->ix_nops, &ok); A.ix_row = upload(mb, ap->ix_row, &ok);
+    u32** scr[] = {&A.gap, &A.anchor, &A.parent, &A.o_next, &A.o_head_upd, &A.o_head_ins, &A.o_top, &A.o_tmp, &A.o_stack};
+    for (auto ps : scr) *ps = balloc<u32>(mb, NU, &ok);
+    A.p_tgt = balloc<u32>(mb, (size_t)U.tot_succ + 2, &ok);
+    if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+    rt_memset(A.p_tgt, 0xFF, ((size_t)U.tot_succ + 2) * 4, ctx->stream);
+    mg(MK_AP_MAP, U.tot_rows);
+    mg(MK_AP_CHG_META, ap->n_chunks);
+    mg(MK_AP_NEW_FLAG, U.tot_rows);
+  } else
+  mg(MK_NEW_FLAG, SB.tot_rows);
+  u32 tot_new = 0;
+  if (!scan_inplace(mb, G.new_idx, SB.tot_rows, &tot_new)) return failm("scan failed");
+  G.tot_new = tot_new;
+  mg(MK_PAIR_COUNTS, P);
+  u32 m_rows = 0, gap_tot = 0;
+  if (!scan_inplace(mb, M.row_base, P, &m_rows) || !scan_inplace(mb, G.gap_base, P, &gap_tot)) return failm("scan failed");
+  if (m_rows >= 0x7FFFFFF0u) { set_error(ctx, std::string(who) + ": batch too large"); return AMH_ERR_BATCH_TOO_LARGE; }
+  M.tot_rows = m_rows;
+  G.new_src = balloc<u32>(mb, (size_t)tot_new + 1, &ok); G.new_gap = balloc<u32>(mb, (size_t)tot_new + 1, &ok);
+  G.gap_cnt = balloc<u32>(mb, (size_t)gap_tot + 2, &ok);
+  size_t NR = (size_t)m_rows + 2;
+  u32** rcols[] = {&M.r_id_actor, &M.r_id_ctr, &M.r_obj_actor, &M.r_obj_ctr, &M.r_key_actor, &M.r_key_ctr, &M.r_key_off, &M.r_key_len,
+                   &M.r_vraw_off, &M.r_mark_off, &M.r_mark_len, &M.r_succ_cnt, &M.r_succ_base, &M.r_doc};
+  for (auto pc : rcols) *pc = balloc<u32>(mb, NR, &ok);
+  M.r_insert = balloc<u8>(mb, NR, &ok); M.r_action = balloc<u8>(mb, NR, &ok); M.r_expand = balloc<u8>(mb, NR, &ok);
+  M.r_vmeta = balloc<u64>(mb, NR, &ok);
+  if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+  rt_memset(G.gap_cnt, 0, ((size_t)gap_tot + 2) * 4, ctx->stream);
+  rt_memset(M.r_succ_cnt, 0, NR * 4, ctx->stream);
+  mg(MK_SUBTREE, P);
+  if (ap) { mg(MK_AP_LINK, G.U.tot_rows); mg(MK_AP_ORDER, P); }
+  else mg(MK_GAP, SB.tot_rows);
+  mg(MK_INHERIT, P);
+  if (!scan_inplace(mb, G.gap_cnt, gap_tot, nullptr)) return failm("scan failed");
+  if (ap) {   // succ lists of the new rows themselves (a later op of the same call overwrote / deleted them)
+    BatchDev& S = G.S;
+    mg(MK_AP_PRED_CNT, G.U.tot_rows);
+#ifdef AMH_EMU
+    memcpy(S.r_succ_base, S.r_succ_cnt, (size_t)G.U.tot_rows * 4);
+#else
+    (void)hipMemcpyAsync(S.r_succ_base, S.r_succ_cnt, (size_t)G.U.tot_rows * 4, hipMemcpyDeviceToDevice, ctx->stream);
+#endif
+    u32 s_succ = 0;
+    if (!scan_inplace(mb, S.r_succ_base, G.U.tot_rows, &s_succ)) return failm("scan failed");
+    S.tot_succ = s_succ;
+    S.s_actor = balloc<u32>(mb, (size_t)s_succ + 1, &ok); S.s_ctr = balloc<u32>(mb, (size_t)s_succ + 1, &ok);
+    if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+    mg(MK_AP_SUCC_FILL_U, G.U.tot_succ);
+    mg(MK_AP_SUCC_SORT_U, G.U.tot_rows);
+  } else
+  mg(MK_EXTRA_CNT, SB.tot_succ);
+  mg(MK_ROWS_DST, DB.tot_rows);
+  mg(MK_ROWS_NEW, tot_new);
+#ifdef AMH_EMU
+  memcpy(M.r_succ_base, M.r_succ_cnt, (size_t)m_rows * 4);
+#else
+  (void)hipMemcpyAsync(M.r_succ_base, M.r_succ_cnt, (size_t)m_rows * 4, hipMemcpyDeviceToDevice, ctx->stream);
+#endif
+  u32 m_succ = 0;
+  if (!scan_inplace(mb, M.r_succ_base, m_rows, &m_succ)) return failm("scan failed");
+  M.tot_succ = m_succ;
+  M.s_actor = balloc<u32>(mb, (size_t)m_succ + 1, &ok); M.s_ctr = balloc<u32>(mb, (size_t)m_succ + 1, &ok);
+  if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+  mg(MK_SUCC_DST, DB.tot_rows);
+  mg(MK_SUCC_NEW, tot_new);
+  if (ap) mg(MK_AP_SUCC_FILL_D, G.U.tot_succ);
+  else mg(MK_SUCC_EXTRA, SB.tot_succ);
+  mg(MK_SUCC_SORT, DB.tot_rows);
+  mg(MK_DOC_SUCC, P);
+  mg(MK_CHANGES, M.tot_chg);
+  mg(MK_COPY_CHUNKS, P);
+  // pairs the kernels rejected
+  if (!rt_d2h(p_status.data(), G.p_status, P * sizeof(i32), ctx->stream)) return failm("D2H copy failed");
+  if (!rt_h2d(M.status, p_status.data(), P * sizeof(i32), ctx->stream)) return failm("H2D copy failed");
+  // ---- merged rows -> document chunks (the save kernels over M) ---------------------------------
+  M.sv_status = balloc<i32>(mb, P + 1, &ok); M.sv_col_len = balloc<u32>(mb, (size_t)P * 25 + 1, &ok);
+  M.sv_body_len = balloc<u32>(mb, P + 1, &ok); M.sv_off = balloc<u32>(mb, P + 2, &ok);
+  if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+  launch(ctx, AK_SAVE_CHECK, M, P);
+  launch(ctx, AK_SAVE_SIZE, M, P * 25);
+  launch(ctx, AK_SAVE_LAYOUT, M, P);
+  u32 sv_total = 0;
+  if (!scan_inplace(mb, M.sv_off, P, &sv_total)) return failm("scan failed");
+  if (sv_total == 0xFFFFFFFFu) { set_error(ctx, std::string(who) + ": merged documents exceed 4 GiB"); return AMH_ERR_BATCH_TOO_LARGE; }
+  M.sv_out = balloc<u8>(mb, (size_t)sv_total + 256, &ok);
+  if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+  launch(ctx, AK_SAVE_STORE, M, P * 25);
+  launch(ctx, AK_SAVE_FINISH, M, P);
+  std::vector<u8> merged((size_t)sv_total);
+  std::vector<u32> sv_off(P + 1), sv_body(P);
+  std::vector<i32> sv_st(P);
+  if (!rt_d2h(merged.data(), M.sv_out, sv_total, ctx->stream) || !rt_d2h(sv_off.data(), M.sv_off, (P + 1) * 4, ctx->stream) ||
+      !rt_d2h(sv_body.data(), M.sv_body_len, P * 4, ctx->stream) || !rt_d2h(sv_st.data(), M.sv_status, P * 4, ctx->stream))
+    return failm("D2H copy failed");
+  collect_profile(ctx);
+  // ---- reload: every document of dst, merged ones from their new bytes ---------------------------
+  u32 nd = DB.n_docs;
+  std::vector<const uint8_t*> ptrs(nd);
+  std::vector<size_t> lens(nd);
+  amh_batch* nb = nullptr;
+  int rc = AMH_SUCCESS;
+  for (int attempt = 0; attempt < 2; attempt++) {
+  for (u32 d = 0; d < nd; d++) {
+    ptrs[d] = dst->staged->h_arena.data() + dst->staged->h_doc_off[2 * (size_t)d];
+    lens[d] = first_doc_chunk_len(ptrs[d], dst->staged->h_doc_off[2 * (size_t)d + 1] - dst->staged->h_doc_off[2 * (size_t)d]);
+    u32 p = d_pair[d];
+    if (p == AMH_NULL32 || p_status[p] != 0) continue;
+    if (sv_st[p] != 0) { p_status[p] = sv_st[p]; continue; }
+    u32 bl = sv_body[p];
+    ptrs[d] = merged.data() + sv_off[p];
+    lens[d] = 9 + bl + (bl < 0x80 ? 1 : bl < 0x4000 ? 2 : bl < 0x200000 ? 3 : bl < 0x10000000 ? 4 : 5);
+  }
+  amh_load_opts lo;
+  lo.verify_heads = 1; lo.on_partial_load = 0;
+  {
+    amh_staged* st = amh_stage_batch(ctx, ptrs.data(), lens.data(), nd);
+    if (!st) return AMH_ERR_DEVICE;
+    nb = load_staged_impl(ctx, st, &lo, false);
+    staged_unref(st);
+  }
+  if (!nb) return AMH_ERR_DEVICE;
+  rc = AMH_SUCCESS;
+  bool again = false;
+  for (u32 p = 0; p < P; p++) {
+    if (p_status[p] > 0) { rc = AMH_ERR_DOC_FAILED; continue; }
+    if (p_status[p] == 0 && nb->status[p_a[p]] != 0) {
+      // Documents merged from loaded documents always verify: anything else is an engine bug, never a silent result.
+      // A change handed to apply may not survive the trip through the document format (its re-derived chunk
+      // hashes differently: a pred naming no op, a non-canonical encoding — the reference's own save + load
+      // rejects such a document too): that document is left as it was and reported.
+      if (!ap || attempt) rc = AMH_ERR_DEVICE;
+      else { p_status[p] = AMH_E_UNSUPPORTED; again = true; }
+    }
+  }
+  if (rc == AMH_ERR_DEVICE) { set_error(ctx, std::string(who) + ": a merged document failed verification on reload"); amh_batch_free(nb); return rc; }
+  if (!again) break;
+  amh_batch_free(nb);
+  nb = nullptr;
+  }
+  for (u32 p = 0; p < P; p++) if (p_status[p] > 0) rc = AMH_ERR_DOC_FAILED;
+  // documents of dst that failed earlier keep their status (a reload of their first chunk alone may succeed)
+  bool st_dirty = false;
+  for (u32 d = 0; d < nd; d++)
+    if (dst->status[d] != 0 && nb->status[d] == 0) { nb->status[d] = dst->status[d]; nb->fail_line[d] = dst->fail_line[d]; st_dirty = true; }
+  if (st_dirty && (!rt_h2d(nb->B.status, nb->status.data(), nd * sizeof(i32), ctx->stream) || !rt_sync(ctx->stream))) { amh_batch_free(nb); return AMH_ERR_DEVICE; }
+  nb->queue = std::move(dst->queue);
+  for (u32 p = 0; p < P; p++) pl.p_status[p] = p_status[p];
+  std::swap(*dst, *nb);
+  amh_batch_free(nb);
+  if (rc == AMH_ERR_DOC_FAILED) set_error(ctx, std::string(who) + ": some pairs were not merged (failed documents, duplicate seq numbers or unsupported shapes); their dst documents are unchanged");
+  return rc;
+}
 extern "C" int amh_merge_batch(amh_ctx* ctx, amh_batch* dst, const amh_batch* src, const uint32_t* dst_idx, const uint32_t* src_idx, size_t n_pairs) {
   if (!ctx || !dst || !src || dst == src || (n_pairs && (!dst_idx || !src_idx)) || n_pairs >= 0x7FFFFFFFull) { set_error(ctx, "amh_merge_batch: invalid argument"); return AMH_ERR_INVALID_ARG; }
   if (n_pairs == 0) return AMH_SUCCESS;
@@ -851,23 +1156,15 @@ extern "C" int amh_merge_batch(amh_ctx* ctx, amh_batch* dst, const amh_batch* sr
   const HostView &ha = dst->hv, &hb = src->hv;
   const BatchDev &DB = dst->B, &SB = src->B;
   u32 P = (u32)n_pairs;
-  std::vector<u32> d_pair(DB.n_docs, AMH_NULL32), s_pair(SB.n_docs, AMH_NULL32), p_a(P), p_b(P), a_len_pad(P, 0);
-  std::vector<i32> p_status(P, 0);
+  MgPlan pl;
+  mg_plan_init(pl, P, DB.n_docs, SB.n_docs, SB.tot_chg);
+  MG_REFS(pl)
   for (u32 p = 0; p < P; p++) {
     u32 a = dst_idx[p], b = src_idx[p];
     if (a >= DB.n_docs || b >= SB.n_docs || d_pair[a] != AMH_NULL32 || s_pair[b] != AMH_NULL32) { set_error(ctx, "amh_merge_batch: document index out of range or used twice"); return AMH_ERR_INVALID_ARG; }
     d_pair[a] = p; s_pair[b] = p; p_a[p] = a; p_b[p] = b;
   }
   // ---- host: actors and changes -----------------------------------------------------------------
-  std::vector<u32> mapa_base(P + 1, 0), mapb_base(P + 1, 0), map_a, map_b, map_b2a;
-  std::vector<u8> s_added(SB.tot_chg + 1, 0);
-  std::vector<u32> m_actor_base(P + 1, 0), m_actor_off, m_actor_len, m_actor_rank;
-  std::vector<u32> m_chg_base(P + 1, 0), mc_from, mc_ndeps, mc_dep_base, m_dep_idx, mc_doc;
-  std::vector<u8> mc_is_dep;
-  std::vector<DocDesc> m_desc(P);
-  std::vector<DocCounts> m_cnt(P);
-  u64 arena_len = 0;
-  int n_failed = 0;
   for (u32 p = 0; p < P; p++) {
     u32 a = p_a[p], b = p_b[p];
     mapa_base[p] = (u32)map_a.size(); mapb_base[p] = (u32)map_b.size();
@@ -988,161 +1285,470 @@ extern "C" int amh_merge_batch(amh_ctx* ctx, amh_batch* dst, const amh_batch* sr
     return AMH_SUCCESS;
   }
   if (arena_len >= 0xFFFFFFF0ull || mc_from.size() >= 0x7FFFFFFFull) { set_error(ctx, "amh_merge_batch: batch too large"); return AMH_ERR_BATCH_TOO_LARGE; }
-  // ---- device ---------------------------------------------------------------------------------
-  std::unique_ptr<amh_batch, void (*)(amh_batch*)> mbh(new amh_batch(), amh_batch_free);
-  amh_batch* mb = mbh.get();
-  mb->ctx = ctx;
-  MergeDev G;
-  memset(&G, 0, sizeof G);
-  G.D = DB; G.S = SB;
-  BatchDev& M = G.M;
-  bool ok = true;
-  auto failm = [&](const char* m) { set_error(ctx, std::string("amh_merge_batch: ") + m); collect_profile(ctx); return AMH_ERR_DEVICE; };
-  G.n_pairs = P;
-  G.p_a = upload(mb, p_a, &ok); G.p_b = upload(mb, p_b, &ok); G.p_status = upload(mb, p_status, &ok);
-  G.d_pair = upload(mb, d_pair, &ok); G.s_pair = upload(mb, s_pair, &ok);
-  G.mapa_base = upload(mb, mapa_base, &ok); G.mapb_base = upload(mb, mapb_base, &ok);
-  G.map_a = upload(mb, map_a, &ok); G.map_b = upload(mb, map_b, &ok); G.map_b2a = upload(mb, map_b2a, &ok);
-  G.s_added = upload(mb, s_added, &ok); G.a_len_pad = upload(mb, a_len_pad, &ok); G.mc_from = upload(mb, mc_from, &ok);
-  M.n_docs = P;
-  M.tot_chg = (u32)mc_from.size(); M.tot_actors = (u32)m_actor_off.size(); M.tot_deps = (u32)m_dep_idx.size();
-  M.status = balloc<i32>(mb, P + 1, &ok); M.fail_line = balloc<u32>(mb, P + 1, &ok);
-  M.desc = upload(mb, m_desc, &ok); M.cnt = upload(mb, m_cnt, &ok);
-  M.row_base = balloc<u32>(mb, P + 2, &ok); M.succ_base = balloc<u32>(mb, P + 2, &ok);
-  M.chg_base = upload(mb, m_chg_base, &ok); M.actor_base = upload(mb, m_actor_base, &ok);
-  M.actor_off = upload(mb, m_actor_off, &ok); M.actor_len = upload(mb, m_actor_len, &ok);
-  M.actor_rank = upload(mb, m_actor_rank, &ok); M.actor_by_rank = upload(mb, m_actor_rank, &ok);
-  size_t NC = M.tot_chg + 2;
-  M.c_actor = balloc<u32>(mb, NC, &ok); M.c_seq = balloc<u64>(mb, NC, &ok); M.c_max_op = balloc<u64>(mb, NC, &ok); M.c_time = balloc<i64>(mb, NC, &ok);
-  M.c_msg_off = balloc<u32>(mb, NC, &ok); M.c_msg_len = balloc<u32>(mb, NC, &ok); M.c_extra_off = balloc<u32>(mb, NC, &ok); M.c_extra_len = balloc<u32>(mb, NC, &ok);
-  M.c_hash = balloc<u8>(mb, NC * 32, &ok);
-  M.c_ndeps = upload(mb, mc_ndeps, &ok); M.c_dep_base = upload(mb, mc_dep_base, &ok); M.dep_idx = upload(mb, m_dep_idx, &ok);
-  M.c_doc = upload(mb, mc_doc, &ok); M.c_is_dep = upload(mb, mc_is_dep, &ok);
-  u8* m_arena = balloc<u8>(mb, (size_t)arena_len + 256, &ok);
-  M.arena = m_arena;
-  size_t NRD = DB.tot_rows + 2, NRS = SB.tot_rows + 2;
-  G.new_idx = balloc<u32>(mb, NRS, &ok); G.gap_base = balloc<u32>(mb, P + 2, &ok);
-  G.sub_end = balloc<u32>(mb, NRD, &ok); G.upd_end = balloc<u32>(mb, NRD, &ok); G.stack = balloc<u32>(mb, NRD, &ok);
-  G.x_cnt = balloc<u32>(mb, NRD, &ok); G.x_fill = balloc<u32>(mb, NRD, &ok); G.d_to_m = balloc<u32>(mb, NRD, &ok);
-  MergeDev* Gdev = (MergeDev*)balloc<u8>(mb, sizeof(MergeDev), &ok);
-  if (!ok) { set_error(ctx, "amh_merge_batch: device out of memory"); return AMH_ERR_OOM; }
-  {
-    std::vector<i32> mst(P);
-    for (u32 p = 0; p < P; p++) mst[p] = p_status[p];   // documents of pairs that are not merged are skipped by the save kernels
-    if (!rt_h2d(M.status, mst.data(), P * sizeof(i32), ctx->stream)) return failm("H2D copy failed");
+  return mg_execute(ctx, dst, SB, pl, nullptr, "amh_merge_batch");
+}
+// ---------------------------------------------------------------------------------------------
+// apply_changes / load_incremental / chunks behind the first one of a loaded input
+// ---------------------------------------------------------------------------------------------
+enum { APM_STRICT = 0, APM_PREFIX = 1, APM_LOAD_ERROR = 2, APM_LOAD_IGNORE = 3 };
+struct ApplyItem {
+  u32 doc = 0;
+  int mode = APM_STRICT;
+  bool first_was_doc = true;
+  std::vector<std::pair<const u8*, size_t>> bufs;   // each: one or more concatenated chunks
+};
+struct HostChunk {
+  u32 pair = 0;
+  const u8* p = nullptr;       // whole type-1 chunk (caller memory, the queue, or `owned`)
+  size_t len = 0;
+  std::vector<u8> owned;
+  i32 bad = 0;                 // host-level failure of this position of the stream (nothing staged)
+  bool from_queue = false;
+  u32 staged = AMH_NULL32;     // index in U
+};
+static bool host_uleb(const u8* p, size_t& pos, size_t end, u64& out) {
+  out = 0;
+  for (u32 shift = 0; shift < 64; shift += 7) {
+    if (pos >= end) return false;
+    u8 b = p[pos++];
+    out |= (u64)(b & 0x7f) << shift;
+    if (!(b & 0x80)) return true;
   }
-  rt_memset(M.fail_line, 0, (P + 1) * 4, ctx->stream);
-  rt_memset(G.x_cnt, 0, NRD * 4, ctx->stream); rt_memset(G.x_fill, 0, NRD * 4, ctx->stream);
-  auto mg = [&](int k, u32 n) {
-    if (n == 0) return true;
-    if (!rt_h2d(Gdev, &G, sizeof(MergeDev), ctx->stream)) return false;
-#ifdef AMH_EMU
-    amh_launch_mg(k, &G, n, (void*)ctx->stream);
-#else
-    amh_launch_mg(k, Gdev, n, (void*)ctx->stream);
-#endif
-    return true;
-  };
-  mg(MK_NEW_FLAG, SB.tot_rows);
-  u32 tot_new = 0;
-  if (!scan_inplace(mb, G.new_idx, SB.tot_rows, &tot_new)) return failm("scan failed");
-  G.tot_new = tot_new;
-  mg(MK_PAIR_COUNTS, P);
-  u32 m_rows = 0, gap_tot = 0;
-  if (!scan_inplace(mb, M.row_base, P, &m_rows) || !scan_inplace(mb, G.gap_base, P, &gap_tot)) return failm("scan failed");
-  if (m_rows >= 0x7FFFFFF0u) { set_error(ctx, "amh_merge_batch: batch too large"); return AMH_ERR_BATCH_TOO_LARGE; }
-  M.tot_rows = m_rows;
-  G.new_src = balloc<u32>(mb, (size_t)tot_new + 1, &ok); G.new_gap = balloc<u32>(mb, (size_t)tot_new + 1, &ok);
-  G.gap_cnt = balloc<u32>(mb, (size_t)gap_tot + 2, &ok);
-  size_t NR = (size_t)m_rows + 2;
-  u32** rcols[] = {&M.r_id_actor, &M.r_id_ctr, &M.r_obj_actor, &M.r_obj_ctr, &M.r_key_actor, &M.r_key_ctr, &M.r_key_off, &M.r_key_len,
-                   &M.r_vraw_off, &M.r_mark_off, &M.r_mark_len, &M.r_succ_cnt, &M.r_succ_base, &M.r_doc};
-  for (auto pc : rcols) *pc = balloc<u32>(mb, NR, &ok);
-  M.r_insert = balloc<u8>(mb, NR, &ok); M.r_action = balloc<u8>(mb, NR, &ok); M.r_expand = balloc<u8>(mb, NR, &ok);
-  M.r_vmeta = balloc<u64>(mb, NR, &ok);
-  if (!ok) { set_error(ctx, "amh_merge_batch: device out of memory"); return AMH_ERR_OOM; }
-  rt_memset(G.gap_cnt, 0, ((size_t)gap_tot + 2) * 4, ctx->stream);
-  rt_memset(M.r_succ_cnt, 0, NR * 4, ctx->stream);
-  mg(MK_SUBTREE, P);
-  mg(MK_GAP, SB.tot_rows);
-  mg(MK_INHERIT, P);
-  if (!scan_inplace(mb, G.gap_cnt, gap_tot, nullptr)) return failm("scan failed");
-  mg(MK_EXTRA_CNT, SB.tot_succ);
-  mg(MK_ROWS_DST, DB.tot_rows);
-  mg(MK_ROWS_NEW, tot_new);
-#ifdef AMH_EMU
-  memcpy(M.r_succ_base, M.r_succ_cnt, (size_t)m_rows * 4);
-#else
-  (void)hipMemcpyAsync(M.r_succ_base, M.r_succ_cnt, (size_t)m_rows * 4, hipMemcpyDeviceToDevice, ctx->stream);
-#endif
-  u32 m_succ = 0;
-  if (!scan_inplace(mb, M.r_succ_base, m_rows, &m_succ)) return failm("scan failed");
-  M.tot_succ = m_succ;
-  M.s_actor = balloc<u32>(mb, (size_t)m_succ + 1, &ok); M.s_ctr = balloc<u32>(mb, (size_t)m_succ + 1, &ok);
-  if (!ok) { set_error(ctx, "amh_merge_batch: device out of memory"); return AMH_ERR_OOM; }
-  mg(MK_SUCC_DST, DB.tot_rows);
-  mg(MK_SUCC_NEW, tot_new);
-  mg(MK_SUCC_EXTRA, SB.tot_succ);
-  mg(MK_SUCC_SORT, DB.tot_rows);
-  mg(MK_DOC_SUCC, P);
-  mg(MK_CHANGES, M.tot_chg);
-  mg(MK_COPY_CHUNKS, P);
-  // pairs the kernels rejected
-  if (!rt_d2h(p_status.data(), G.p_status, P * sizeof(i32), ctx->stream)) return failm("D2H copy failed");
-  if (!rt_h2d(M.status, p_status.data(), P * sizeof(i32), ctx->stream)) return failm("H2D copy failed");
-  // ---- merged rows -> document chunks (the save kernels over M) ---------------------------------
-  M.sv_status = balloc<i32>(mb, P + 1, &ok); M.sv_col_len = balloc<u32>(mb, (size_t)P * 25 + 1, &ok);
-  M.sv_body_len = balloc<u32>(mb, P + 1, &ok); M.sv_off = balloc<u32>(mb, P + 2, &ok);
-  if (!ok) { set_error(ctx, "amh_merge_batch: device out of memory"); return AMH_ERR_OOM; }
-  launch(ctx, AK_SAVE_CHECK, M, P);
-  launch(ctx, AK_SAVE_SIZE, M, P * 25);
-  launch(ctx, AK_SAVE_LAYOUT, M, P);
-  u32 sv_total = 0;
-  if (!scan_inplace(mb, M.sv_off, P, &sv_total)) return failm("scan failed");
-  if (sv_total == 0xFFFFFFFFu) { set_error(ctx, "amh_merge_batch: merged documents exceed 4 GiB"); return AMH_ERR_BATCH_TOO_LARGE; }
-  M.sv_out = balloc<u8>(mb, (size_t)sv_total + 256, &ok);
-  if (!ok) { set_error(ctx, "amh_merge_batch: device out of memory"); return AMH_ERR_OOM; }
-  launch(ctx, AK_SAVE_STORE, M, P * 25);
-  launch(ctx, AK_SAVE_FINISH, M, P);
-  std::vector<u8> merged((size_t)sv_total);
-  std::vector<u32> sv_off(P + 1), sv_body(P);
-  std::vector<i32> sv_st(P);
-  if (!rt_d2h(merged.data(), M.sv_out, sv_total, ctx->stream) || !rt_d2h(sv_off.data(), M.sv_off, (P + 1) * 4, ctx->stream) ||
-      !rt_d2h(sv_body.data(), M.sv_body_len, P * 4, ctx->stream) || !rt_d2h(sv_st.data(), M.sv_status, P * 4, ctx->stream))
-    return failm("D2H copy failed");
-  collect_profile(ctx);
-  // ---- reload: every document of dst, merged ones from their new bytes ---------------------------
-  u32 nd = DB.n_docs;
-  std::vector<const uint8_t*> ptrs(nd);
-  std::vector<size_t> lens(nd);
-  for (u32 d = 0; d < nd; d++) {
-    ptrs[d] = dst->staged->h_arena.data() + dst->staged->h_doc_off[2 * (size_t)d];
-    lens[d] = dst->staged->h_doc_off[2 * (size_t)d + 1] - dst->staged->h_doc_off[2 * (size_t)d];
-    u32 p = d_pair[d];
-    if (p == AMH_NULL32 || p_status[p] != 0) continue;
-    if (sv_st[p] != 0) { p_status[p] = sv_st[p]; continue; }
-    u32 bl = sv_body[p];
-    ptrs[d] = merged.data() + sv_off[p];
-    lens[d] = 9 + bl + (bl < 0x80 ? 1 : bl < 0x4000 ? 2 : bl < 0x200000 ? 3 : bl < 0x10000000 ? 4 : 5);
+  return false;
+}
+static i32 change_err_kind(i32 dev_status) {   // storage/load.rs:15-30 as seen through load_changes
+  if (dev_status == 0 || dev_status == AMH_E_PARSE || dev_status == AMH_E_BAD_CHECKSUM || dev_status >= AMH_E_TOO_LARGE) return dev_status;
+  return AMH_E_INVALID_CHANGE_COLUMNS;
+}
+// split a byte stream into chunks (storage/load.rs:56-114); stops at the first position that is not a chunk
+static void split_chunks(u32 pair, const u8* p, size_t len, std::vector<HostChunk>& out) {
+  size_t off = 0;
+  while (off < len) {
+    HostChunk hc;
+    hc.pair = pair;
+    const u8* q = p + off;
+    size_t avail = len - off;
+    size_t pos = 9;
+    u64 dlen = 0;
+    if (avail < 10 || q[0] != 0x85 || q[1] != 0x6f || q[2] != 0x4a || q[3] != 0x83 || q[8] > 2 || !host_uleb(q, pos, avail, dlen) || dlen > avail - pos) {
+      hc.bad = AMH_E_PARSE;
+      out.push_back(std::move(hc));
+      return;
+    }
+    size_t total = pos + (size_t)dlen;
+    if (q[8] == 0) {   // a document chunk inside a change stream (load.rs:84-100): not on this path yet
+      hc.bad = AMH_E_UNSUPPORTED;
+      out.push_back(std::move(hc));
+      return;
+    }
+    if (q[8] == 2) {
+      if (!amh_ingest_inflate_change(q, total, hc.owned)) { hc.bad = AMH_E_PARSE; out.push_back(std::move(hc)); return; }
+      hc.p = nullptr; hc.len = hc.owned.size();
+    } else {
+      hc.p = q; hc.len = total;
+    }
+    out.push_back(std::move(hc));
+    off += total;
   }
-  amh_load_opts lo;
-  lo.verify_heads = 1; lo.on_partial_load = 0;
-  amh_batch* nb = amh_load_batch(ctx, ptrs.data(), lens.data(), nd, &lo);
-  if (!nb) return AMH_ERR_DEVICE;
-  int rc = AMH_SUCCESS;
+}
+
+// results[i] = outcome for items[i] (0, or the AutomergeError kind); documents with outcome != 0 are left as
+// they were, except under APM_LOAD_ERROR where the document's status becomes the outcome.
+static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& items, std::vector<i32>& results, const char* who) {
+  u32 P = (u32)items.size();
+  results.assign(P, 0);
+  if (P == 0) return AMH_SUCCESS;
+  if (!ensure_chg(dst)) { set_error(ctx, std::string(who) + ": D2H copy failed"); return AMH_ERR_DEVICE; }
+  const HostView& ha = dst->hv;
+  const BatchDev& DB = dst->B;
+  // ---- chunks of every pair: the new ones, then the document's queue -------------------------------
+  std::vector<HostChunk> chunks;
+  std::vector<u32> pc_base(P + 1, 0);
   for (u32 p = 0; p < P; p++) {
-    if (p_status[p] > 0) { rc = AMH_ERR_DOC_FAILED; continue; }
-    if (p_status[p] == 0 && nb->status[p_a[p]] != 0) rc = AMH_ERR_DEVICE;   // a merged document that does not verify is an engine bug, never a silent result
+    pc_base[p] = (u32)chunks.size();
+    for (auto& bf : items[p].bufs) {
+      size_t before = chunks.size();
+      split_chunks(p, bf.first, bf.second, chunks);
+      if (chunks.size() > before && chunks.back().bad) break;   // nothing behind a bad position is looked at
+    }
+    auto qit = dst->queue.find(items[p].doc);
+    if (qit != dst->queue.end())
+      for (auto& qb : qit->second) {
+        HostChunk hc;
+        hc.pair = p; hc.p = qb.data(); hc.len = qb.size(); hc.from_queue = true;
+        chunks.push_back(std::move(hc));
+      }
   }
-  if (rc == AMH_ERR_DEVICE) { set_error(ctx, "amh_merge_batch: a merged document failed verification on reload"); amh_batch_free(nb); return rc; }
-  std::swap(*dst, *nb);
-  amh_batch_free(nb);
-  if (rc == AMH_ERR_DOC_FAILED) set_error(ctx, "amh_merge_batch: some pairs were not merged (failed documents, duplicate seq numbers or unsupported shapes); their dst documents are unchanged");
+  pc_base[P] = (u32)chunks.size();
+  for (auto& hc : chunks) if (!hc.p && !hc.bad) hc.p = hc.owned.data();
+  // ---- stage the good ones -----------------------------------------------------------------------
+  std::unique_ptr<amh_batch, void (*)(amh_batch*)> holder(new amh_batch(), amh_batch_free);
+  amh_batch* hb = holder.get();
+  hb->ctx = ctx;
+  ApplyRun ap;
+  std::vector<u64> doc_off;
+  std::vector<u8> h_arena;
+  ap.s_desc.resize(P); ap.s_cnt.resize(P); ap.s_row_base.assign(P + 1, 0);
+  std::vector<u32> staged_of;   // U index -> chunks index
+  {
+    u64 off = 0;
+    for (u32 p = 0; p < P; p++) {
+      memset(&ap.s_desc[p], 0, sizeof(DocDesc)); memset(&ap.s_cnt[p], 0, sizeof(DocCounts));
+      u64 region = off;
+      ap.s_desc[p].chunk_off = region;
+      for (u32 k = pc_base[p]; k < pc_base[p + 1]; k++) {
+        HostChunk& hc = chunks[k];
+        if (hc.bad) continue;
+        hc.staged = (u32)staged_of.size();
+        staged_of.push_back(k);
+        ap.c_pair.push_back(p);
+        ap.c_rel.push_back((u32)(off - region));
+        doc_off.push_back(off); doc_off.push_back(off + hc.len);
+        off += hc.len;
+        off = (off + 15) & ~(u64)15;
+      }
+      if (off - region >= 0xFFFFFFF0ull) { set_error(ctx, std::string(who) + ": changes of one document exceed 4 GiB"); return AMH_ERR_BATCH_TOO_LARGE; }
+      ap.s_desc[p].chunk_len = (u32)(off - region);
+    }
+    h_arena.assign(off + 256, 0);
+    for (size_t u = 0; u < staged_of.size(); u++) memcpy(h_arena.data() + doc_off[2 * u], chunks[staged_of[u]].p, chunks[staged_of[u]].len);
+  }
+  u32 NCH = (u32)staged_of.size();
+  ap.n_chunks = NCH;
+  std::vector<i32> u_status(NCH, 0);
+  std::vector<ChgHdr> hdr(NCH);
+  std::vector<DocCounts> u_cnt(NCH);
+  std::vector<DocDesc> u_desc(NCH);
+  std::vector<u8> u_hash((size_t)NCH * 32 + 32);
+  std::vector<u32> u_row_base(NCH + 1, 0);
+  BatchDev& U = ap.U;
+  bool ok = true;
+  auto faild = [&](const char* m) { set_error(ctx, std::string(who) + ": " + m); collect_profile(ctx); return AMH_ERR_DEVICE; };
+  MergeDev G0;
+  memset(&G0, 0, sizeof G0);
+  MergeDev* G0dev = nullptr;
+  if (NCH) {
+    U.n_docs = NCH;
+    U.no_checksum = items[0].mode == APM_STRICT;
+    u8* d_arena = balloc<u8>(hb, h_arena.size(), &ok);
+    u64* d_off = balloc<u64>(hb, doc_off.size() + 2, &ok);
+    U.status = balloc<i32>(hb, NCH + 1, &ok); U.fail_line = balloc<u32>(hb, NCH + 1, &ok);
+    U.desc = balloc<DocDesc>(hb, NCH + 1, &ok); U.cnt = balloc<DocCounts>(hb, NCH + 1, &ok);
+    U.row_base = balloc<u32>(hb, NCH + 2, &ok); U.succ_base = balloc<u32>(hb, NCH + 2, &ok);
+    U.doc_hash = balloc<u8>(hb, (size_t)NCH * 32 + 32, &ok); U.doc_max_op = balloc<u32>(hb, NCH + 1, &ok);
+    ap.d_hdr = balloc<ChgHdr>(hb, NCH + 1, &ok);
+    G0dev = (MergeDev*)balloc<u8>(hb, sizeof(MergeDev), &ok);
+    if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+    U.arena = d_arena; U.doc_off = d_off;
+    if (!rt_h2d(d_arena, h_arena.data(), h_arena.size(), ctx->stream) || !rt_h2d(d_off, doc_off.data(), doc_off.size() * sizeof(u64), ctx->stream)) return faild("H2D copy failed");
+    rt_memset(U.status, 0, (NCH + 1) * sizeof(i32), ctx->stream);
+    rt_memset(U.fail_line, 0, (NCH + 1) * sizeof(u32), ctx->stream);
+    rt_memset(U.doc_max_op, 0, (NCH + 1) * sizeof(u32), ctx->stream);
+    auto mg0 = [&](int k, u32 n) {
+      if (n == 0) return true;
+      G0.U = U; G0.A.hdr = ap.d_hdr; G0.A.u_chg = ap.d_u_chg; G0.A.u_fill = ap.d_u_fill;
+      if (!rt_h2d(G0dev, &G0, sizeof(MergeDev), ctx->stream)) return false;
+#ifdef AMH_EMU
+      amh_launch_mg(k, &G0, n, (void*)ctx->stream);
+#else
+      amh_launch_mg(k, G0dev, n, (void*)ctx->stream);
+#endif
+      return true;
+    };
+    mg0(MK_AP_PARSE, NCH);
+    launch(ctx, AK_SHA_DOC, U, NCH);
+    mg0(MK_AP_COUNT, NCH);
+    u32 tot_rows = 0, tot_preds = 0;
+    if (!scan_inplace(hb, U.row_base, NCH, &tot_rows) || !scan_inplace(hb, U.succ_base, NCH, &tot_preds)) return faild("scan failed");
+    if (tot_rows >= 0x7FFFFFF0u || tot_preds >= 0x7FFFFFF0u) { set_error(ctx, std::string(who) + ": batch too large"); return AMH_ERR_BATCH_TOO_LARGE; }
+    U.tot_rows = tot_rows; U.tot_succ = tot_preds;
+    size_t NR = (size_t)tot_rows + 2, NS = (size_t)tot_preds + 2;
+    u32** rcols[] = {&U.r_id_actor, &U.r_id_ctr, &U.r_obj_actor, &U.r_obj_ctr, &U.r_key_actor, &U.r_key_ctr, &U.r_key_off, &U.r_key_len,
+                     &U.r_vraw_off, &U.r_mark_off, &U.r_mark_len, &U.r_succ_cnt, &U.r_succ_base, &U.r_doc};
+    for (auto pc : rcols) *pc = balloc<u32>(hb, NR, &ok);
+    U.r_insert = balloc<u8>(hb, NR, &ok); U.r_action = balloc<u8>(hb, NR, &ok); U.r_expand = balloc<u8>(hb, NR, &ok);
+    U.r_vmeta = balloc<u64>(hb, NR, &ok);
+    U.s_actor = balloc<u32>(hb, NS, &ok); U.s_ctr = balloc<u32>(hb, NS, &ok); U.s_row = balloc<u32>(hb, NS, &ok);
+    ap.d_u_chg = balloc<u32>(hb, NR, &ok); ap.d_u_fill = balloc<u32>(hb, NR, &ok);
+    if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+    rt_memset(U.r_doc, 0xFF, NR * 4, ctx->stream);
+    rt_memset(U.r_obj_actor, 0xFF, NR * 4, ctx->stream); rt_memset(U.r_obj_ctr, 0xFF, NR * 4, ctx->stream);
+    rt_memset(U.r_key_actor, 0xFF, NR * 4, ctx->stream); rt_memset(U.r_key_ctr, 0xFF, NR * 4, ctx->stream);
+    rt_memset(U.r_key_off, 0, NR * 4, ctx->stream); rt_memset(U.r_key_len, 0xFF, NR * 4, ctx->stream);
+    rt_memset(U.r_mark_off, 0, NR * 4, ctx->stream); rt_memset(U.r_mark_len, 0xFF, NR * 4, ctx->stream);
+    rt_memset(U.r_expand, 0, NR, ctx->stream);
+    rt_memset(U.s_row, 0xFF, NS * 4, ctx->stream);
+    launch(ctx, AK_DECODE_OPS, U, NCH * OC_COUNT);
+    mg0(MK_AP_VERIFY, tot_rows);
+    if (!rt_d2h(u_status.data(), U.status, NCH * sizeof(i32), ctx->stream) || !rt_d2h(hdr.data(), ap.d_hdr, NCH * sizeof(ChgHdr), ctx->stream) ||
+        !rt_d2h(u_cnt.data(), U.cnt, NCH * sizeof(DocCounts), ctx->stream) || !rt_d2h(u_desc.data(), U.desc, NCH * sizeof(DocDesc), ctx->stream) ||
+        !rt_d2h(u_hash.data(), U.doc_hash, (size_t)NCH * 32, ctx->stream) || !rt_d2h(u_row_base.data(), U.row_base, (NCH + 1) * sizeof(u32), ctx->stream) ||
+        !rt_sync(ctx->stream))
+      return faild("device pipeline failed");
+    collect_profile(ctx);
+  }
+  // ---- host: which changes apply, in which order (automerge.rs:797-858); actors; merged history -----
+  MgPlan pl;
+  mg_plan_init(pl, P, DB.n_docs, P, NCH);
+  MG_REFS(pl)
+  ap.c_applied.assign((size_t)NCH + 1, 0);
+  ap.amap_base.assign((size_t)NCH + 1, 0);
+  ap.ix_base.assign(P + 1, 0);
+  std::vector<std::vector<u32>> new_queue(P), amap_of(NCH);
+  std::vector<u8> queue_dirty(P, 0);
+  typedef std::pair<const u8*, u32> Bytes;
+  auto bcmp = [](Bytes x, Bytes y) { int c = memcmp(x.first, y.first, std::min(x.second, y.second)); return c ? c : (x.second < y.second ? -1 : (x.second > y.second ? 1 : 0)); };
+  // per staged chunk: author + other actors as byte ranges of h_arena
+  auto chunk_actors = [&](u32 u, std::vector<Bytes>& out) {
+    const u8* q = h_arena.data() + doc_off[2 * (size_t)u];
+    out.clear();
+    out.push_back(Bytes(q + hdr[u].actor_off, hdr[u].actor_len));
+    size_t pos = hdr[u].others_off, end = (size_t)(doc_off[2 * (size_t)u + 1] - doc_off[2 * (size_t)u]);
+    for (u32 i = 0; i < hdr[u].n_other; i++) {
+      u64 l = 0;
+      host_uleb(q, pos, end, l);
+      out.push_back(Bytes(q + pos, (u32)l));
+      pos += (size_t)l;
+    }
+  };
+  for (u32 p = 0; p < P; p++) {
+    u32 a = items[p].doc;
+    int mode = items[p].mode;
+    d_pair[a] = p; s_pair[p] = p; p_a[p] = a; p_b[p] = p;
+    mapa_base[p] = (u32)map_a.size(); mapb_base[p] = (u32)map_b.size();
+    m_actor_base[p] = (u32)m_actor_off.size(); m_chg_base[p] = (u32)mc_from.size();
+    ap.ix_base[p] = (u32)ap.ix_actor.size();
+    memset(&m_desc[p], 0, sizeof(DocDesc)); memset(&m_cnt[p], 0, sizeof(DocCounts));
+    // rows of U per pair
+    {
+      u32 first_u = AMH_NULL32, last_u = AMH_NULL32;
+      for (u32 k = pc_base[p]; k < pc_base[p + 1]; k++) if (chunks[k].staged != AMH_NULL32) { if (first_u == AMH_NULL32) first_u = chunks[k].staged; last_u = chunks[k].staged; }
+      u32 rb0 = first_u == AMH_NULL32 ? (p ? ap.s_row_base[p] : 0) : u_row_base[first_u];
+      u32 rb1 = first_u == AMH_NULL32 ? rb0 : u_row_base[last_u + 1];
+      ap.s_row_base[p] = rb0; ap.s_row_base[p + 1] = rb1;
+      ap.s_cnt[p].n_rows = rb1 - rb0;
+    }
+    if (dst->status[a]) { p_status[p] = dst->status[a]; results[p] = dst->status[a]; n_failed++; continue; }
+    // usable new chunks under the call's policy
+    std::vector<u32> fresh, oldq;
+    i32 first_err = 0;
+    for (u32 k = pc_base[p]; k < pc_base[p + 1]; k++) {
+      HostChunk& hc = chunks[k];
+      i32 e = hc.bad ? hc.bad : change_err_kind(u_status[hc.staged]);
+      if (hc.from_queue) { if (!e) oldq.push_back(k); continue; }
+      if (e) { first_err = e; break; }
+      fresh.push_back(k);
+    }
+    if (first_err) {
+      if (mode == APM_STRICT && first_err < AMH_E_TOO_LARGE) first_err = AMH_E_PARSE;   // change::LoadError::Parse covers header and column errors alike
+      if (mode == APM_STRICT || mode == APM_LOAD_ERROR) { p_status[p] = first_err; results[p] = first_err; n_failed++; continue; }
+      if (mode == APM_LOAD_IGNORE) { p_status[p] = -1; continue; }   // nothing behind the first chunk is applied (automerge.rs:690-694)
+    }
+    const u8* ca = dst->staged->h_arena.data() + dst->staged->h_doc_off[2 * (size_t)a];
+    u32 na = ha.desc[a].n_actors, aba = ha.actor_base[a];
+    auto abytes = [&](u32 i) { return Bytes(ca + ha.actor_off[aba + i], ha.actor_len[aba + i]); };
+    bool sorted = true;
+    for (u32 i = 1; i < na && sorted; i++) sorted = bcmp(abytes(i - 1), abytes(i)) < 0;
+    if (!sorted) { p_status[p] = AMH_E_UNSUPPORTED; results[p] = AMH_E_UNSUPPORTED; n_failed++; continue; }
+    u32 nca = ha.cnt[a].n_chg, cba = ha.chg_base[a];
+    std::unordered_map<Hash32, u32, Hash32Hasher> history;
+    history.reserve((size_t)nca * 2 + fresh.size() * 2 + 1);
+    for (u32 i = 0; i < nca; i++) { Hash32 h; memcpy(h.b, ha.c_hash.data() + (size_t)(cba + i) * 32, 32); history.emplace(h, i); }
+    std::map<std::string, u64> per_actor;   // actor -> number of its changes in the history (states, automerge.rs:771-779)
+    for (u32 i = 0; i < nca; i++) { Bytes ab = abytes(ha.c_actor[cba + i]); per_actor[std::string((const char*)ab.first, ab.second)]++; }
+    auto hash_of = [&](u32 k) { Hash32 h; memcpy(h.b, u_hash.data() + (size_t)chunks[k].staged * 32, 32); return h; };
+    auto actor_of = [&](u32 k) { u32 u = chunks[k].staged; const u8* q = h_arena.data() + doc_off[2 * (size_t)u]; return std::string((const char*)q + hdr[u].actor_off, hdr[u].actor_len); };
+    auto ready = [&](u32 k) {
+      u32 u = chunks[k].staged;
+      const u8* q = h_arena.data() + doc_off[2 * (size_t)u] + hdr[u].deps_off;
+      for (u32 i = 0; i < hdr[u].n_deps; i++) { Hash32 h; memcpy(h.b, q + 32 * (size_t)i, 32); if (!history.count(h)) return false; }
+      return true;
+    };
+    std::vector<u32> order, queue = oldq;
+    auto apply = [&](u32 k) { history.emplace(hash_of(k), nca + (u32)order.size()); order.push_back(k); per_actor[actor_of(k)]++; };
+    bool dup = false;
+    for (u32 k : fresh) {
+      if (history.count(hash_of(k))) continue;
+      auto it = per_actor.find(actor_of(k));
+      if (it != per_actor.end() && it->second >= hdr[chunks[k].staged].seq) { dup = true; break; }
+      if (ready(k)) apply(k); else queue.push_back(k);
+    }
+    while (!dup) {
+      bool got = false;
+      for (size_t q = 0; q < queue.size(); q++)
+        if (ready(queue[q])) { u32 k = queue[q]; queue[q] = queue.back(); queue.pop_back(); if (!history.count(hash_of(k))) apply(k); got = true; break; }
+      if (!got) break;
+    }
+    if (dup) { p_status[p] = AMH_E_DUPLICATE_SEQ; results[p] = AMH_E_DUPLICATE_SEQ; n_failed++; continue; }
+    if (mode == APM_LOAD_ERROR && !items[p].first_was_doc && !queue.empty()) { p_status[p] = AMH_E_MISSING_DEPS; results[p] = AMH_E_MISSING_DEPS; n_failed++; continue; }
+    new_queue[p] = queue; queue_dirty[p] = 1;
+    if (order.empty()) { p_status[p] = -1; continue; }
+    // actor table of S for this pair: the actors of the applied changes, bytewise sorted
+    std::vector<Bytes> sact, tmp;
+    for (u32 k : order) { chunk_actors(chunks[k].staged, tmp); sact.insert(sact.end(), tmp.begin(), tmp.end()); }
+    std::sort(sact.begin(), sact.end(), [&](Bytes x, Bytes y) { return bcmp(x, y) < 0; });
+    sact.erase(std::unique(sact.begin(), sact.end(), [&](Bytes x, Bytes y) { return bcmp(x, y) == 0; }), sact.end());
+    u32 nb = (u32)sact.size();
+    const u8* region = h_arena.data() + ap.s_desc[p].chunk_off;
+    u32 lenA = ha.desc[a].chunk_len, lenApad = (lenA + 15u) & ~15u, lenB = ap.s_desc[p].chunk_len;
+    a_len_pad[p] = lenApad;
+    std::vector<u32> la(na), lb(nb), lb2a(nb, AMH_NULL32);
+    {
+      u32 i = 0, j = 0, k = 0;
+      while (i < na || j < nb) {
+        int c = i >= na ? 1 : (j >= nb ? -1 : bcmp(abytes(i), sact[j]));
+        if (c <= 0) { m_actor_off.push_back(ha.actor_off[aba + i]); m_actor_len.push_back(ha.actor_len[aba + i]); }
+        else { m_actor_off.push_back(lenApad + (u32)(sact[j].first - region)); m_actor_len.push_back(sact[j].second); }
+        m_actor_rank.push_back(k);
+        if (c == 0) lb2a[j] = i;
+        if (c <= 0) la[i++] = k;
+        if (c >= 0) lb[j++] = k;
+        k++;
+      }
+    }
+    map_a.insert(map_a.end(), la.begin(), la.end());
+    map_b.insert(map_b.end(), lb.begin(), lb.end());
+    map_b2a.insert(map_b2a.end(), lb2a.begin(), lb2a.end());
+    auto s_index = [&](Bytes x) { return (u32)(std::lower_bound(sact.begin(), sact.end(), x, [&](Bytes y, Bytes z) { return bcmp(y, z) < 0; }) - sact.begin()); };
+    // merged history = dst's history, then the applied changes
+    size_t first_c = mc_from.size();
+    for (u32 i = 0; i < nca; i++) {
+      mc_from.push_back(cba + i); mc_doc.push_back(p); mc_is_dep.push_back(0);
+      mc_ndeps.push_back(ha.c_ndeps[cba + i]); mc_dep_base.push_back((u32)m_dep_idx.size());
+      for (u32 k = 0; k < ha.c_ndeps[cba + i]; k++) m_dep_idx.push_back(ha.dep_idx[ha.c_dep_base[cba + i] + k]);
+    }
+    u32 mark_len = ha.desc[a].ocol[OC_MARK_NAME].len;
+    struct Ix { u32 actor, start, nops, row; };
+    std::vector<Ix> ix;
+    for (u32 k : order) {
+      u32 u = chunks[k].staged;
+      ap.c_applied[u] = 1;
+      mc_from.push_back(0x80000000u | u); mc_doc.push_back(p); mc_is_dep.push_back(0);
+      mc_ndeps.push_back(hdr[u].n_deps); mc_dep_base.push_back((u32)m_dep_idx.size());
+      const u8* q = h_arena.data() + doc_off[2 * (size_t)u] + hdr[u].deps_off;
+      for (u32 i = 0; i < hdr[u].n_deps; i++) { Hash32 h; memcpy(h.b, q + 32 * (size_t)i, 32); m_dep_idx.push_back(history[h]); }
+      mark_len |= u_desc[u].ocol[OC_MARK_NAME].len;
+      chunk_actors(u, tmp);
+      for (auto& x : tmp) amap_of[u].push_back(s_index(x));
+      ix.push_back(Ix{s_index(tmp[0]), (u32)hdr[u].start_op, u_cnt[u].n_rows, u_row_base[u]});
+    }
+    std::sort(ix.begin(), ix.end(), [](const Ix& x, const Ix& y) { return x.actor != y.actor ? x.actor < y.actor : x.start < y.start; });
+    for (auto& e : ix) { ap.ix_actor.push_back(e.actor); ap.ix_start.push_back(e.start); ap.ix_nops.push_back(e.nops); ap.ix_row.push_back(e.row); }
+    for (size_t c = first_c; c < mc_from.size(); c++)
+      for (u32 k = 0; k < mc_ndeps[c]; k++) mc_is_dep[first_c + m_dep_idx[mc_dep_base[c] + k]] = 1;
+    m_cnt[p].n_chg = nca + (u32)order.size();
+    m_desc[p].chunk_off = arena_len;
+    m_desc[p].chunk_len = lenApad + lenB;
+    m_desc[p].n_actors = (u32)(m_actor_off.size() - m_actor_base[p]);
+    m_desc[p].ocol[OC_MARK_NAME].len = mark_len;
+    arena_len += (lenApad + lenB + 15u) & ~15ull;
+  }
+  for (u32 u = 0; u < NCH; u++) {
+    ap.amap_base[u] = (u32)ap.amap.size();
+    ap.amap.insert(ap.amap.end(), amap_of[u].begin(), amap_of[u].end());
+  }
+  ap.amap_base[NCH] = (u32)ap.amap.size();
+  mapa_base[P] = (u32)map_a.size(); mapb_base[P] = (u32)map_b.size();
+  m_actor_base[P] = (u32)m_actor_off.size(); m_chg_base[P] = (u32)mc_from.size();
+  ap.ix_base[P] = (u32)ap.ix_actor.size();
+  auto commit_queues = [&]() {
+    for (u32 p = 0; p < P; p++) {
+      if (!queue_dirty[p] || (p_status[p] > 0)) continue;
+      std::vector<std::vector<u8>> nq;
+      for (u32 k : new_queue[p]) {
+        nq.emplace_back(chunks[k].p, chunks[k].p + chunks[k].len);
+        memcpy(nq.back().data() + 4, u_hash.data() + (size_t)chunks[k].staged * 32, 4);   // a change accepted with a stale checksum keeps its content hash
+      }
+      if (nq.empty()) dst->queue.erase(items[p].doc); else dst->queue[items[p].doc] = std::move(nq);
+    }
+  };
+  bool any_work = false;
+  for (u32 p = 0; p < P; p++) any_work = any_work || p_status[p] == 0;
+  int rc = AMH_SUCCESS;
+  if (any_work) {
+    if (arena_len >= 0xFFFFFFF0ull || mc_from.size() >= 0x7FFFFFFFull) { set_error(ctx, std::string(who) + ": batch too large"); return AMH_ERR_BATCH_TOO_LARGE; }
+    BatchDev SB;
+    memset(&SB, 0, sizeof SB);
+    SB = U;   // S shares U's row arrays; its per-pair tables and succ lists are set up by mg_execute
+    SB.n_docs = P; SB.tot_chg = NCH;
+    rc = mg_execute(ctx, dst, SB, pl, &ap, who);
+    if (rc != AMH_SUCCESS && rc != AMH_ERR_DOC_FAILED) return rc;
+    for (u32 p = 0; p < P; p++) if (p_status[p] > 0 && results[p] == 0) results[p] = p_status[p];
+  }
+  commit_queues();
+  for (u32 p = 0; p < P; p++) if (results[p]) rc = AMH_ERR_DOC_FAILED;
+  if (rc == AMH_ERR_DOC_FAILED) set_error(ctx, std::string(who) + ": some documents were left unchanged (see the per-document results)");
   return rc;
 }
-extern "C" int amh_apply_changes(amh_ctx* ctx, amh_batch*, uint32_t, const uint8_t* const*, const size_t*, size_t) {
-  set_error(ctx, "amh_apply_changes: not implemented in this round");
-  return AMH_ERR_UNIMPLEMENTED;
+
+static int load_trailing_chunks(amh_ctx* ctx, amh_batch* b, const amh_load_opts* opts) {
+  const amh_staged* st = b->staged;
+  std::vector<ApplyItem> items;
+  for (u32 d = 0; d < b->B.n_docs; d++) {
+    if (b->status[d]) continue;
+    const u8* ptr = st->h_arena.data() + st->h_doc_off[2 * (size_t)d];
+    size_t avail = (size_t)(st->h_doc_off[2 * (size_t)d + 1] - st->h_doc_off[2 * (size_t)d]);
+    size_t fl = first_doc_chunk_len(ptr, avail);
+    if (fl == avail) continue;
+    ApplyItem it;
+    it.doc = d;
+    it.mode = (opts && opts->on_partial_load == 1) ? APM_LOAD_IGNORE : APM_LOAD_ERROR;
+    it.first_was_doc = fl != 0;
+    it.bufs.push_back({ptr + fl, avail - fl});
+    items.push_back(std::move(it));
+  }
+  if (items.empty()) return AMH_SUCCESS;
+  // the inputs are read from b's staging arena, which apply_core replaces: keep it alive for the call
+  amh_staged* keep = b->staged;
+  keep->refs++;
+  std::vector<i32> results;
+  int rc = apply_core(ctx, b, items, results, "amh_load_batch");
+  staged_unref(keep);
+  if (rc != AMH_SUCCESS && rc != AMH_ERR_DOC_FAILED) return rc;
+  bool dirty = false;
+  for (size_t i = 0; i < items.size(); i++)
+    if (results[i]) { b->status[items[i].doc] = results[i]; b->fail_line[items[i].doc] = 0; dirty = true; }
+  if (dirty && (!rt_h2d(b->B.status, b->status.data(), b->status.size() * sizeof(i32), ctx->stream) || !rt_sync(ctx->stream))) return AMH_ERR_DEVICE;
+  return AMH_SUCCESS;
+}
+
+extern "C" int amh_apply_batch(amh_ctx* ctx, amh_batch* b, const uint32_t* doc_idx, const uint8_t* const* bufs, const size_t* lens, size_t n, int incremental, int* results) {
+  if (!ctx || !b || (n && (!doc_idx || !bufs || !lens)) || n >= 0x7FFFFFFFull) { set_error(ctx, "amh_apply_batch: invalid argument"); return AMH_ERR_INVALID_ARG; }
+  std::vector<ApplyItem> items;
+  std::unordered_map<u32, u32> item_of;
+  std::vector<u32> buf_item(n);
+  for (size_t i = 0; i < n; i++) {
+    if (doc_idx[i] >= b->B.n_docs) { set_error(ctx, "amh_apply_batch: document index out of range"); return AMH_ERR_INVALID_ARG; }
+    auto it = item_of.find(doc_idx[i]);
+    if (it == item_of.end()) {
+      it = item_of.emplace(doc_idx[i], (u32)items.size()).first;
+      ApplyItem ai;
+      ai.doc = doc_idx[i];
+      ai.mode = incremental ? APM_PREFIX : APM_STRICT;
+      items.push_back(std::move(ai));
+    }
+    buf_item[i] = it->second;
+    if (lens[i]) items[it->second].bufs.push_back({bufs[i], lens[i]});
+  }
+  std::vector<i32> res;
+  int rc = apply_core(ctx, b, items, res, "amh_apply_batch");
+  if (results && res.size() == items.size()) for (size_t i = 0; i < n; i++) results[i] = res[buf_item[i]];
+  return rc;
+}
+extern "C" int amh_apply_changes(amh_ctx* ctx, amh_batch* b, uint32_t doc, const uint8_t* const* changes, const size_t* lens, size_t n) {
+  if (!ctx || !b || doc >= b->B.n_docs || (n && (!changes || !lens))) { set_error(ctx, "amh_apply_changes: invalid argument"); return AMH_ERR_INVALID_ARG; }
+  std::vector<ApplyItem> items(1);
+  items[0].doc = doc;
+  items[0].mode = APM_STRICT;
+  for (size_t i = 0; i < n; i++) if (lens[i]) items[0].bufs.push_back({changes[i], lens[i]});
+  std::vector<i32> res;
+  return apply_core(ctx, b, items, res, "amh_apply_changes");
+}
+extern "C" int amh_doc_queue_len(const amh_batch* b, uint32_t doc, size_t* n) {
+  if (!b || !n || doc >= b->B.n_docs) return AMH_ERR_INVALID_ARG;
+  auto it = b->queue.find(doc);
+  *n = it == b->queue.end() ? 0 : it->second.size();
+  return AMH_SUCCESS;
 }
 extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch* bc, const amh_save_opts* opts, amh_bytes_out* out) {
   if (!ctx || !bc || !out) { set_error(ctx, "invalid argument"); return AMH_ERR_INVALID_ARG; }
@@ -1184,10 +1790,16 @@ extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch* bc, const amh_save_
     const u8* src = host.data() + off[d];
     std::vector<u8> z;
     if (deflate && amh_host_deflate_document(src, len, z)) { src = z.data(); len = z.size(); }
-    out[d].data = (uint8_t*)malloc(len ? len : 1);
+    // retain_orphans: the queued changes follow the document chunk as they are (automerge.rs:959-963)
+    size_t orphans = 0;
+    auto qit = b->queue.find(d);
+    bool keep = (!opts || opts->retain_orphans) && qit != b->queue.end();
+    if (keep) for (auto& q : qit->second) orphans += q.size();
+    out[d].data = (uint8_t*)malloc(len + orphans ? len + orphans : 1);
     if (!out[d].data) return AMH_ERR_OOM;
     memcpy(out[d].data, src, len);
-    out[d].len = len;
+    if (keep) { size_t o = len; for (auto& q : qit->second) { memcpy(out[d].data + o, q.data(), q.size()); o += q.size(); } }
+    out[d].len = len + orphans;
   }
   return AMH_SUCCESS;
 }

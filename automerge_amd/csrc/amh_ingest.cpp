@@ -52,7 +52,8 @@ static void push_uleb(std::vector<u8>& o, u64 v) {
 bool amh_ingest_normalise(const u8* p, size_t len, std::vector<u8>& out) {
   if (len < 10 || p[0] != 0x85 || p[1] != 0x6f || p[2] != 0x4a || p[3] != 0x83 || p[8] != 0) return false;
   u64 pos = 9, end = len, dlen;
-  if (rd_uleb_strict(p, pos, end, dlen) || dlen != end - pos) return false;
+  if (rd_uleb_strict(p, pos, end, dlen) || dlen > end - pos) return false;
+  end = pos + dlen;   // chunks behind the document chunk (trailing changes) are carried over as they are
   u64 data_off = pos;
   u64 n;
   if (rd_uleb_strict(p, pos, end, n)) return false;
@@ -115,6 +116,23 @@ bool amh_ingest_normalise(const u8* p, size_t len, std::vector<u8>& out) {
   out.insert(out.end(), p, p + 4);
   out.insert(out.end(), h, h + 4);
   out.insert(out.end(), pre.begin(), pre.end());
+  out.insert(out.end(), body.begin(), body.end());
+  out.insert(out.end(), p + end, p + len);
+  return true;
+}
+
+// A compressed change chunk (type 2) as the type-1 chunk it stands for: same checksum, inflated body
+// (chunk.rs:77-97, 106-108).  false = not a type-2 chunk or the body does not inflate.
+bool amh_ingest_inflate_change(const u8* p, size_t len, std::vector<u8>& out) {
+  if (len < 10 || p[8] != 2) return false;
+  u64 pos = 9, end = len, dlen;
+  if (rd_uleb_strict(p, pos, end, dlen) || dlen != end - pos) return false;
+  std::vector<u8> body;
+  if (!inflate_raw(p + pos, dlen, body)) return false;
+  out.clear();
+  out.insert(out.end(), p, p + 8);
+  out.push_back(1);
+  push_uleb(out, body.size());
   out.insert(out.end(), body.begin(), body.end());
   return true;
 }

@@ -54,8 +54,11 @@ AMH_DEV void cm_set(ColMapper& m, int slot, u64 s, u64 e) {
   m.slots[slot].off = (u32)(m.data_rel_off + s);
   m.slots[slot].len = (u32)(e - s);
 }
-template <bool IS_OPS>
+template <int KIND>
 AMH_DEV void cm_emit_simple(ColMapper& m, u32 id, u32 type, u64 s, u64 e) {
+  // KIND: 0 = change metadata columns of a document, 1 = op columns of a document, 2 = op columns of a change
+  // chunk (change_op_columns.rs:422-523: no id columns, the group is pred = 7)
+  constexpr bool IS_OPS = KIND != 0;
   int slot = -1;
   if (IS_OPS) {
     if (id == 0 && type == 1) slot = OC_OBJ_ACTOR;
@@ -63,8 +66,8 @@ AMH_DEV void cm_emit_simple(ColMapper& m, u32 id, u32 type, u64 s, u64 e) {
     else if (id == 1 && type == 1) slot = OC_KEY_ACTOR;
     else if (id == 1 && type == 3) slot = OC_KEY_CTR;
     else if (id == 1 && type == 5) slot = OC_KEY_STR;
-    else if (id == 2 && type == 1) slot = OC_ID_ACTOR;
-    else if (id == 2 && type == 3) slot = OC_ID_CTR;
+    else if (KIND == 1 && id == 2 && type == 1) slot = OC_ID_ACTOR;
+    else if (KIND == 1 && id == 2 && type == 3) slot = OC_ID_CTR;
     else if (id == 3 && type == 4) slot = OC_INSERT;
     else if (id == 4 && type == 2) slot = OC_ACTION;
     else if (id == 9 && type == 4) slot = OC_EXPAND;
@@ -78,16 +81,18 @@ AMH_DEV void cm_emit_simple(ColMapper& m, u32 id, u32 type, u64 s, u64 e) {
   }
   if (slot >= 0) cm_set(m, slot, s, e);
 }
-template <bool IS_OPS>
+template <int KIND>
 AMH_DEV void cm_emit_value(ColMapper& m) {
+  constexpr bool IS_OPS = KIND != 0;
   if (m.cur_id == 5) {
     cm_set(m, IS_OPS ? (int)OC_VAL_META : (int)CC_EXTRA_META, m.cur_s, m.cur_e);
     cm_set(m, IS_OPS ? (int)OC_VAL_RAW : (int)CC_EXTRA_RAW, m.cur_rs, m.cur_re);
   }
 }
-template <bool IS_OPS>
+template <int KIND>
 AMH_DEV void cm_emit_group(ColMapper& m) {
-  if (IS_OPS && m.cur_id == 8) {
+  constexpr bool IS_OPS = KIND != 0;
+  if (IS_OPS && m.cur_id == (KIND == 2 ? 7u : 8u)) {
     cm_set(m, OC_SUCC_NUM, m.cur_s, m.cur_e);
     if (m.nkids == 0) { cm_set(m, OC_SUCC_ACTOR, 0, 0); cm_set(m, OC_SUCC_CTR, 0, 0); }
     else if (m.nkids == 2 && (m.kid0_type == 1 || m.kid0_type == 2) && m.kid1_type == 3) {
@@ -112,7 +117,7 @@ AMH_DEV void cm_init(ColMapper& m, u64 data_rel_off, u64 data_len, ColRef* slots
   m.g_in_value = false; m.bad = false; m.off = 0; m.data_rel_off = data_rel_off; m.data_len = data_len; m.slots = slots;
 }
 // one raw column; 1 = layout error
-template <bool IS_OPS>
+template <int KIND>
 AMH_DEV_NOINLINE int cm_feed(ColMapper& m, u32 spec, u64 len) {
   u32 id = spec >> 4, type = spec & 7;
   u64 s = m.off, e = m.off + len;
@@ -123,23 +128,23 @@ AMH_DEV_NOINLINE int cm_feed(ColMapper& m, u32 spec, u64 len) {
       if (type == 0) { m.st = 2; m.cur_id = id; m.cur_s = s; m.cur_e = e; m.nkids = 0; m.g_in_value = false; }
       else if (type == 6) { m.st = 1; m.cur_id = id; m.cur_s = s; m.cur_e = e; m.cur_rs = m.cur_re = 0; }
       else if (type == 7) return 1;  // LoneRawValueColumn
-      else cm_emit_simple<IS_OPS>(m, id, type, s, e);
+      else cm_emit_simple<KIND>(m, id, type, s, e);
       return 0;
     }
     if (m.st == 1) {
       if (type == 7) {
         if (m.cur_id != id) return 1;  // MismatchingValueMetadataId
         m.cur_rs = s; m.cur_re = e;
-        cm_emit_value<IS_OPS>(m);
+        cm_emit_value<KIND>(m);
         m.st = 0;
         return 0;
       }
-      cm_emit_value<IS_OPS>(m);
+      cm_emit_value<KIND>(m);
       m.st = 0;
       continue;
     }
     // in group
-    if (m.cur_id != id) { cm_emit_group<IS_OPS>(m); m.st = 0; continue; }
+    if (m.cur_id != id) { cm_emit_group<KIND>(m); m.st = 0; continue; }
     if (!m.g_in_value) {
       if (type == 0 || type == 7) return 1;  // NestedGroup / LoneRawValueColumn
       if (type == 6) m.g_in_value = true;    // a value column inside a group: not a shape this path maps
@@ -157,17 +162,17 @@ AMH_DEV_NOINLINE int cm_feed(ColMapper& m, u32 spec, u64 len) {
   }
   return 0;
 }
-template <bool IS_OPS>
+template <int KIND>
 AMH_DEV_NOINLINE int cm_finish(ColMapper& m) {
-  if (m.st == 1) cm_emit_value<IS_OPS>(m);
-  else if (m.st == 2) { if (m.g_in_value) cm_add_kid(m, 6, 0, 0); cm_emit_group<IS_OPS>(m); }
+  if (m.st == 1) cm_emit_value<KIND>(m);
+  else if (m.st == 2) { if (m.g_in_value) cm_add_kid(m, 6, 0, 0); cm_emit_group<KIND>(m); }
   return m.bad ? 1 : 0;
 }
 
 // one column-metadata block (raw_column.rs:205-272): count, then (spec, len) pairs in normal order.
 // mapper == null: validate and total the lengths; otherwise feed the layout machine.
 // 0 ok, 1 parse error, 2 too many columns for this engine
-template <bool IS_OPS>
+template <int KIND>
 AMH_DEV_NOINLINE int parse_col_meta(const u8* p, u64& pos, u64 end, u64 chunk_data_len, u64& total, ColMapper* mapper) {
   u64 nc;
   if (rd_uleb_strict(p, pos, end, nc)) return 1;
@@ -187,7 +192,7 @@ AMH_DEV_NOINLINE int parse_col_meta(const u8* p, u64& pos, u64 end, u64 chunk_da
     if (spec & 8) return 1;  // a column that ingest could not inflate (ParseError::Deflate)
     if (clen > chunk_data_len) return 1;
     total += clen;
-    if (mapper && cm_feed<IS_OPS>(*mapper, (u32)spec, clen)) return 1;
+    if (mapper && cm_feed<KIND>(*mapper, (u32)spec, clen)) return 1;
   }
   return 0;
 }
@@ -218,9 +223,9 @@ AMH_DEV void k_parse(const BatchDev& B, u32 d) {
   D.data_off = (u32)pos;
   D.data_len = (u32)len;
   D.chunk_len = (u32)(pos + len);
-  // this round's device path loads exactly one document chunk per input; change chunks (first or
-  // trailing) go through apply_changes, which is not on the device yet
-  if (type != 0 || D.chunk_len != avail) { amh_fail(B, d, AMH_E_UNSUPPORTED); return; }
+  // a change chunk first = an empty document that the changes are then applied to; chunks after the
+  // first one are applied as well (automerge.rs:657-695): the host hands both to the apply path
+  if (type != 0) { D.chunk_len = 0; D.data_off = D.data_len = 0; return; }
   end = pos + len;
   u64 n;
   if (rd_uleb_strict(p, pos, end, n)) { amh_fail(B, d, AMH_E_PARSE); return; }
@@ -277,7 +282,7 @@ AMH_DEV void k_sha_doc(const BatchDev& B, u32 d) {
   // type byte + uleb(len) exactly as stored (strict parse => canonical) and the data: one contiguous range
   u8* h = B.doc_hash + (u64)d * 32;
   sha256_contig(p + 8, (u64)(D.data_off - 8) + D.data_len, h);
-  if (h[0] != p[4] || h[1] != p[5] || h[2] != p[6] || h[3] != p[7]) amh_fail(B, d, AMH_E_BAD_CHECKSUM);
+  if (!B.no_checksum && (h[0] != p[4] || h[1] != p[5] || h[2] != p[6] || h[3] != p[7])) amh_fail(B, d, AMH_E_BAD_CHECKSUM);
 }
 
 // ------------------------------------------------------------------------------------------

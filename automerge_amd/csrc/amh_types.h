@@ -81,6 +81,7 @@ struct BatchDev {
   u32 n_docs;
   u32 tot_rows, tot_succ, tot_chg, tot_deps, tot_actors, tot_dt, tot_ops;
   u32 check_heads;         // VerificationMode::Check (reconstruct_document.rs:86-90)
+  u32 no_checksum;         // the stored checksum is not compared (Change::try_from, change.rs:161-180, does not look at it)
   u32 cur_level;           // start, in lvl_order, of the dependency level hashed by the current k_chg_hash launch
   u32* lvl_order;          // [tot_chg] changes grouped by dependency level
   u32* lvl_start;          // [AMH_LEVEL_CAP + 2] start of each level in lvl_order
@@ -175,8 +176,39 @@ struct BatchDev {
 // The host decides which changes are new and in which order they apply (O(changes) replay of
 // automerge.rs:797-858, 1311-1334) and unions the actor tables; everything per op is on the device.
 // ---------------------------------------------------------------------------------------------
+// change chunk header (storage/change.rs:99-156); offsets are relative to the start of the chunk
+struct ChgHdr {
+  u32 deps_off, n_deps;            // 32-byte hashes
+  u32 actor_off, actor_len;
+  u32 msg_off, msg_len;            // len 0 = no message
+  u32 others_off, n_other;         // length-prefixed actor ids
+  u32 extra_off, extra_len;
+  u64 seq, start_op;
+  i64 time;
+};
+// apply_changes (automerge.rs:785-914): the change chunks of all pairs are staged as one batch U whose
+// "documents" are the chunks (same column decoders as the document path; the pred group sits in the succ
+// slots, there are no id columns).  S is then a view of U's rows per pair, and the merge kernels run with
+// new rows = the ops of the applied changes in document order (k_ap_order).
+struct ApplyDev {
+  ChgHdr* hdr;                     // [n_chunks]
+  const u32* c_pair;               // [n_chunks] pair the chunk belongs to
+  const u32* c_rel;                // [n_chunks] offset of the chunk inside its pair's region of the arena
+  const u8* c_applied;             // [n_chunks] host decision: the change is applied by this call
+  const u32* amap_base;            // [n_chunks + 1]
+  const u32* amap;                 // change-local actor index -> index in the pair's actor table of S
+  const u32* ix_base;              // [P + 1] applied changes of a pair sorted by (actor, start_op): id -> row of U
+  const u32 *ix_actor, *ix_start, *ix_nops, *ix_row;
+  u32* u_chg;                      // [U rows] chunk of the row
+  u32 *gap, *anchor, *parent;      // [U rows] dst-local gap (AMH_NULL32 = inside a new subtree), dst row it hangs off, parent row in U
+  u32* p_tgt;                      // [U preds] bit 31 set: dst row (global), else row of U; AMH_NULL32 = none
+  u32 *o_next, *o_head_upd, *o_head_ins, *o_top, *o_tmp, *o_stack;   // [U rows] scratch of k_ap_order
+  u32* u_fill;                     // [U rows]
+};
 struct MergeDev {
   BatchDev D, S, M;
+  BatchDev U;                      // apply only
+  ApplyDev A;
   u32 n_pairs;
   const u32 *p_a, *p_b;            // [P] document index in D / S
   i32* p_status;                   // [P] 0 = ok (host pre-sets failures; kernels may add AMH_E_UNSUPPORTED)

@@ -115,7 +115,10 @@ const char* amh_last_error(const amh_ctx*);   /* message of the last failed call
  * == Automerge::load_with_options per document (automerge/src/automerge.rs:601-705; C precedent
  *    AMload, automerge-c/src/doc.rs:512).
  * amh_load_batch = amh_stage_batch (host ingest: inflate of DEFLATEd columns, document.rs /
- * compression.rs:51-74, + one H2D copy) followed by amh_load_staged (the device pipeline). */
+ * compression.rs:51-74, + one H2D copy) followed by amh_load_staged (the device pipeline).
+ * An input is what the reference's load accepts: a document chunk, optionally followed by change chunks
+ * (save_incremental output), or change chunks alone; the change chunks go through the apply path with the
+ * reference's policies (MissingDeps when the first chunk is not a document, on_partial_load). */
 amh_staged* amh_stage_batch(amh_ctx*, const uint8_t* const* docs, const size_t* lens, size_t n);
 void amh_staged_free(amh_staged*);
 amh_batch* amh_load_staged(amh_ctx*, const amh_staged*, const amh_load_opts*);
@@ -145,9 +148,28 @@ int amh_doc_max_op(const amh_batch*, uint32_t doc, uint64_t* max_op);
  * DuplicateSeqNumber); their dst documents are unchanged.  Every merged document is re-verified (change
  * hashes, heads) before it replaces the old one. */
 int amh_merge_batch(amh_ctx*, amh_batch* dst, const amh_batch* src, const uint32_t* dst_idx, const uint32_t* src_idx, size_t n_pairs);
-/* == Automerge::apply_changes (automerge.rs:785; AMapplyChanges, automerge-c/src/doc.rs:84).
- * Not built yet: returns AMH_ERR_UNIMPLEMENTED. */
+/* == Automerge::apply_changes (automerge.rs:785-858; AMapplyChanges, automerge-c/src/doc.rs:84) on one document:
+ * changes[i] = one change chunk, plain or compressed (what Change::try_from takes, change.rs:161-180: the stored
+ * checksum is not compared).  Changes the document already has are skipped; changes whose dependencies are missing
+ * wait in the document's queue (amh_doc_queue_len) and apply when a later call brings the missing ones; save keeps
+ * them behind the document chunk (retain_orphans).  Returns AMH_ERR_DOC_FAILED and leaves the document unchanged when
+ * a chunk does not parse or a change repeats a sequence number (DuplicateSeqNumber: unlike the reference, which has
+ * applied the changes in front of the offending one by then).  This is the n = 1 form of amh_apply_batch and, like
+ * it, reloads the whole batch: apply to many documents with one amh_apply_batch call. */
 int amh_apply_changes(amh_ctx*, amh_batch*, uint32_t doc, const uint8_t* const* changes, const size_t* lens, size_t n);
+/* Batched form.  Buffer i holds one or more concatenated chunks for document doc_idx[i]; several buffers may name
+ * the same document (applied in the order given).
+ *   incremental = 0: apply_changes per document, as above.
+ *   incremental = 1: == Automerge::load_incremental on a loaded document (automerge.rs:730-769; AMloadIncremental,
+ *                    automerge-c/src/doc.rs:537): checksums are verified and the chunks in front of the first
+ *                    unreadable one are applied (storage/load.rs:56-114).
+ * results (may be NULL) receives per buffer the outcome for its document: AMH_DOC_OK or the AutomergeError kind
+ * (AMH_DOC_PARSE, AMH_DOC_DUPLICATE_SEQ, AMH_DOC_UNSUPPORTED = the applied changes do not survive the trip through
+ * the document format, e.g. a pred naming no op).  Every changed document is re-verified (change hashes, heads). */
+int amh_apply_batch(amh_ctx*, amh_batch*, const uint32_t* doc_idx, const uint8_t* const* bufs, const size_t* lens, size_t n,
+                    int incremental, int* results);
+/* number of changes waiting for dependencies (Automerge::queue, automerge.rs:168) */
+int amh_doc_queue_len(const amh_batch*, uint32_t doc, size_t* n);
 /* == Automerge::save_with_options (automerge.rs:943-965; AMsave, automerge-c/src/doc.rs:751);
  * out = array of n_docs amh_bytes_out, each freed with amh_bytes_free.  A document that failed to load (or whose
  * stored actor table is not in bytewise order: not a shape writers produce) gets data = NULL.

@@ -71,6 +71,27 @@ amo_doc* amo_load(const uint8_t* data, size_t len, int check_heads) {
   GUARD_END(nullptr)
 }
 
+// load_with_options with OnPartialLoad::{Error, Ignore} — automerge.rs:58-135, 678-695
+amo_doc* amo_load_opts(const uint8_t* data, size_t len, int check_heads, int ignore_partial) {
+  GUARD_BEGIN
+  auto* d = new amo_doc();
+  try {
+    d->doc = load(data, len, check_heads != 0, ignore_partial == 0);
+  } catch (...) {
+    delete d;
+    throw;
+  }
+  return d;
+  GUARD_END(nullptr)
+}
+// Change::compress (storage/change.rs:287-293) of one change chunk; bytes are zlib's: parity unpinned, used as test input only
+int amo_change_compress(const uint8_t* data, size_t len, const uint8_t** out, size_t* olen) {
+  GUARD_BEGIN
+  StoredChange ch = change_from_bytes(data, len);
+  return give(compress_change(ch), out, olen);
+  GUARD_END(-1)
+}
+
 // Automerge::load_incremental — automerge.rs:730
 long amo_load_incremental(amo_doc* d, const uint8_t* data, size_t len) {
   GUARD_BEGIN

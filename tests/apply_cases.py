@@ -1,0 +1,182 @@
+"""apply_changes / load_incremental / trailing-chunk scenarios shared by the CPU-tier (emulation) and GPU tests:
+the engine and the oracle get the same bytes; everything observable must agree bit for bit."""
+import random
+
+import oracle_lib as o
+
+
+def check_doc(batch, i, ref):
+    batch.check(i)
+    assert batch.hydrate_json(i) == ref.hydrate_json(), i
+    assert batch.get_heads(i) == ref.get_heads(), i
+    assert [c["hash"] for c in batch.get_changes(i)] == [c["hash"] for c in ref.changes()], i   # history order
+    assert batch.max_op(i) == ref.max_op()
+    assert batch.queue_len(i) == ref.queue_len()
+
+
+def changes_of(data):
+    return [c["raw"] for c in o.Doc.load(bytes(data)).changes()]
+
+
+def check_apply_tail(engine, docs, cut):
+    """every document is rebuilt from its first cut(n) changes, then gets the rest through apply_changes"""
+    bases, tails = [], []
+    for data in docs:
+        chunks = changes_of(data)
+        k = cut(len(chunks))
+        base = o.Doc()
+        base.apply_changes(chunks[:k])
+        bases.append(base.save(deflate=False))
+        tails.append(chunks[k:])
+    b = engine.load_batch(bases)
+    res = b.apply_batch([(i, c) for i, t in enumerate(tails) for c in t])
+    assert not any(res), res
+    saved = b.save_all(deflate=False)
+    for i in range(len(docs)):
+        ref = o.Doc.load(bases[i])
+        ref.apply_changes(tails[i])
+        check_doc(b, i, ref)
+        assert saved[i] == ref.save(deflate=False), i
+    return b
+
+
+def check_apply_replicas(engine, docs, n_replicas):
+    """docs[d * n_replicas + r] = replica r of document d: replica 0 receives the other replicas' changes one replica per
+    call — in order, shuffled (queueing inside a call) and with duplicates"""
+    nd = len(docs) // n_replicas
+    bases = [bytes(docs[d * n_replicas]) for d in range(nd)]
+    b = engine.load_batch(bases)
+    refs = [o.Doc.load(x) for x in bases]
+    rng = random.Random(5)
+    for r in range(1, n_replicas):
+        items = []
+        for d in range(nd):
+            have = {c["hash"] for c in refs[d].changes()}
+            new = [c["raw"] for c in o.Doc.load(bytes(docs[d * n_replicas + r])).changes() if c["hash"] not in have]
+            if d % 3 == 1:
+                rng.shuffle(new)
+            if d % 3 == 2:
+                new = new + new[:2]
+            refs[d].apply_changes(new)
+            items += [(d, c) for c in new]
+        res = b.apply_batch(items)
+        assert not any(res), res
+        saved = b.save_all(deflate=False)
+        for d in range(nd):
+            check_doc(b, d, refs[d])
+            assert saved[d] == refs[d].save(deflate=False)
+    return b
+
+
+def check_queue_across_calls(engine, base, other):
+    """changes delivered before their dependencies wait in the queue (automerge.rs:797-858), are kept by save
+    (retain_orphans, :959-963) and apply once the missing change arrives"""
+    have = {c["hash"] for c in o.Doc.load(base).changes()}
+    new = [c for c in changes_of(other) if o.change_hash(c) not in have]
+    assert len(new) >= 2
+    b = engine.load_batch([base])
+    ref = o.Doc.load(base)
+    b.apply_changes(0, new[1:])
+    ref.apply_changes(new[1:])
+    check_doc(b, 0, ref)
+    assert b.queue_len(0) == len(new) - 1
+    saved = b.save_all(deflate=False)[0]
+    assert saved == ref.save(deflate=False)
+    # the saved form (document chunk + orphans) loads back into the same state
+    b2 = engine.load_batch([saved])
+    check_doc(b2, 0, o.Doc.load(saved))
+    b.apply_changes(0, new[:1])
+    ref.apply_changes(new[:1])
+    check_doc(b, 0, ref)
+    assert b.queue_len(0) == 0
+    assert b.save_all(deflate=False)[0] == ref.save(deflate=False)
+
+
+def corrupt(chunk):
+    c = bytearray(chunk)
+    c[-1] ^= 0x55
+    return bytes(c)
+
+
+def check_trailing_and_policies(engine, data):
+    """inputs of the shapes load accepts (automerge.rs:601-705): document + change chunks (save_incremental), change
+    chunks alone, a change stream missing its first change (MissingDeps), a bad chunk in the tail under both policies"""
+    chunks = changes_of(data)
+    assert len(chunks) >= 4
+    k = len(chunks) // 2
+    base = o.Doc()
+    base.apply_changes(chunks[:k])
+    head = base.save(deflate=False)
+    inputs = [
+        head + b"".join(chunks[k:]),                                 # document + incremental changes
+        b"".join(chunks),                                            # changes only
+        b"".join(chunks[1:]),                                        # changes only, first one missing
+        head + b"".join(chunks[k:-1]) + corrupt(chunks[-1]),         # bad checksum in the tail
+        head + b"".join(chunks[k + 1:]),                             # tail whose first change is missing: queued
+        head + chunks[k][:len(chunks[k]) // 2],                      # truncated tail
+        b"",
+    ]
+    for policy in ("error", "ignore"):
+        b = engine.load_batch(inputs, on_partial_load=policy)
+        for i, inp in enumerate(inputs):
+            try:
+                ref = o.Doc.load(inp, on_partial_load=policy)
+            except o.OracleError as ex:
+                kind, _ = b.status(i)
+                assert kind != 0 and (ex.kind == 4 or kind == ex.kind), (policy, i, kind, ex)
+                continue
+            check_doc(b, i, ref)
+            assert b.save_all(deflate=False)[i] == ref.save(deflate=False), (policy, i)
+
+
+def check_incremental_and_errors(engine, data):
+    chunks = changes_of(data)
+    k = len(chunks) // 2
+    base = o.Doc()
+    base.apply_changes(chunks[:k])
+    head = base.save(deflate=False)
+    # load_incremental: the chunks in front of the first unreadable one are applied (automerge.rs:758-764)
+    stream = b"".join(chunks[k:k + 2]) + corrupt(chunks[k + 2]) + b"".join(chunks[k + 3:])
+    b = engine.load_batch([head, head, head])
+    res = b.apply_batch([(0, stream)], incremental=True)
+    assert res == [0]
+    ref = o.Doc.load(head)
+    ref.load_incremental(stream)
+    check_doc(b, 0, ref)
+    # apply_changes proper takes parsed changes: an unreadable one fails the call for that document only
+    # (Change::try_from does not compare the checksum, change.rs:161-180: a damaged change that still parses is a
+    # different change with a different hash)
+    bad = corrupt(chunks[k])
+    res = b.apply_batch([(1, bad), (2, chunks[k])])
+    ref1 = o.Doc.load(head)
+    try:
+        ref1.apply_changes([bad])
+        # a damaged change the document format cannot carry (its re-derived chunk hashes differently) is refused
+        assert res[0] in (0, 91), res
+        if res[0] == 91:
+            ref1 = o.Doc.load(head)
+    except o.OracleError as ex:
+        assert res[0] == ex.kind, (res, ex)
+        ref1 = o.Doc.load(head)
+    assert res[1] == 0, res
+    check_doc(b, 1, ref1)
+    trunc = chunks[k][:-3]
+    assert b.apply_batch([(1, trunc)]) == [1]
+    check_doc(b, 1, ref1)
+    ref2 = o.Doc.load(head)
+    ref2.apply_changes([chunks[k]])
+    check_doc(b, 2, ref2)
+    # idempotent
+    assert b.apply_batch([(2, chunks[k])]) == [0]
+    check_doc(b, 2, ref2)
+    # compressed changes (chunk type 2) are the changes they inflate to (chunk.rs:77-97)
+    big = [c for c in chunks[k:] if len(c) > 256]
+    if big:
+        comp = o.change_compress(big[0])
+        assert comp[8] == 2
+        b3 = engine.load_batch([head])
+        ref3 = o.Doc.load(head)
+        pre = chunks[k:chunks.index(big[0])]
+        b3.apply_changes(0, pre + [comp])
+        ref3.apply_changes(pre + [big[0]])
+        check_doc(b3, 0, ref3)

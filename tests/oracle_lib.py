@@ -25,6 +25,9 @@ lib.amo_clone.argtypes = [C.c_void_p]
 lib.amo_free.argtypes = [C.c_void_p]
 lib.amo_load.restype = C.c_void_p
 lib.amo_load.argtypes = [C.c_char_p, C.c_size_t, C.c_int]
+lib.amo_load_opts.restype = C.c_void_p
+lib.amo_load_opts.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int]
+lib.amo_change_compress.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
 lib.amo_load_incremental.restype = C.c_long
 lib.amo_load_incremental.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
 lib.amo_apply_changes.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
@@ -82,8 +85,8 @@ class Doc:
             self.h = None
 
     @staticmethod
-    def load(data: bytes, check_heads=True) -> "Doc":
-        h = lib.amo_load(data, len(data), 1 if check_heads else 0)
+    def load(data: bytes, check_heads=True, on_partial_load="error") -> "Doc":
+        h = lib.amo_load_opts(data, len(data), 1 if check_heads else 0, 1 if on_partial_load == "ignore" else 0)
         if not h:
             raise OracleError()
         return Doc(h)
@@ -157,6 +160,10 @@ def sha256(data: bytes) -> bytes:
 
 def change_rebuild(chunk: bytes) -> bytes:
     return _out(lib.amo_change_rebuild, chunk, len(chunk))
+
+
+def change_compress(chunk: bytes) -> bytes:
+    return _out(lib.amo_change_compress, chunk, len(chunk))
 
 
 def change_hash(chunk: bytes) -> bytes:

@@ -8,6 +8,7 @@ import os
 import pytest
 
 import oracle_lib as o
+import apply_cases as ac
 from emu_engine import emu_engine
 
 
@@ -52,8 +53,7 @@ def test_bad_documents_fail_like_the_oracle(emu, golden_dir):
         except o.OracleError:
             ref = None
         kind, _ = batch.status(i)
-        if kind == 91:   # shape this round's device path declares unsupported (change chunks): never a silent success
-            continue
+        assert kind != 91   # every fixture shape is handled, change-chunk inputs included (tests/test.rs:1422-1464)
         assert (kind == 0) == (ref is not None), (files[i // 2] if i % 2 == 0 else "good", kind)
         if ref is not None:
             compare(batch, i, d)
@@ -192,3 +192,30 @@ def test_merge_nothing_new_and_failures(emu):
     import oracle_lib as o
     ref = o.Doc.load(a); ref.merge(o.Doc.load(b))
     assert bd.save_all(deflate=False)[2] == ref.save(deflate=False)
+
+
+def test_apply_changes_map_documents(emu):
+    blob, offs = emu.gen_map_docs(7, 6, 3, 3, 12, 16, 1)
+    docs = [blob[offs[i]:offs[i + 1]] for i in range(6)]
+    ac.check_apply_tail(emu, docs, lambda n: n // 2)
+    ac.check_apply_tail(emu, docs, lambda n: 0)        # onto empty documents
+    ac.check_apply_tail(emu, docs, lambda n: n - 1)
+
+
+def test_apply_changes_text_replicas(emu):
+    blob, offs = emu.gen_text_docs(0xC0DE, 3, 4, 80, 400, 50, 1)
+    docs = [bytes(blob[offs[i]:offs[i + 1]]) for i in range(12)]
+    ac.check_apply_tail(emu, docs[:4], lambda n: 1)
+    ac.check_apply_replicas(emu, docs, 4)
+    ac.check_queue_across_calls(emu, docs[0], docs[1])
+
+
+def test_load_with_change_chunks_and_incremental(emu):
+    blob, offs = emu.gen_map_docs(21, 2, 3, 3, 40, 24, 1)
+    for i in range(2):
+        d = bytes(blob[offs[i]:offs[i + 1]])
+        ac.check_trailing_and_policies(emu, d)
+        ac.check_incremental_and_errors(emu, d)
+    blob, offs = emu.gen_text_docs(0xC1, 1, 2, 50, 300, 60, 1)
+    ac.check_trailing_and_policies(emu, bytes(blob[offs[1]:offs[2]]))
+    ac.check_incremental_and_errors(emu, bytes(blob[offs[1]:offs[2]]))

@@ -80,8 +80,7 @@ def test_bad_documents_do_not_poison_the_batch(engine, golden_dir):
         except o.OracleError:
             ref = None
         kind, _ = batch.status(i)
-        if kind == 91:
-            continue
+        assert kind != 91, i   # change-chunk inputs included (tests/test.rs:1422-1464)
         assert (kind == 0) == (ref is not None), (i, kind)
         if ref is not None:
             _compare(batch, i, d)
@@ -218,3 +217,41 @@ def test_merge_nothing_new_and_failures(engine):
     import oracle_lib as o
     ref = o.Doc.load(a); ref.merge(o.Doc.load(b))
     assert bd.save_all(deflate=False)[2] == ref.save(deflate=False)
+
+
+def test_apply_changes_map_documents(engine):
+    import apply_cases as ac
+    blob, offs = engine.gen_map_docs(7, 40, 3, 3, 12, 16, 1)
+    docs = [blob[offs[i]:offs[i + 1]] for i in range(40)]
+    ac.check_apply_tail(engine, docs, lambda n: n // 2)
+    ac.check_apply_tail(engine, docs, lambda n: 0)
+    ac.check_apply_tail(engine, docs, lambda n: n - 1)
+
+
+def test_apply_changes_text_replicas(engine):
+    import apply_cases as ac
+    blob, offs = engine.gen_text_docs(0xC0DE, 6, 4, 80, 400, 50, 1)
+    docs = [bytes(blob[offs[i]:offs[i + 1]]) for i in range(24)]
+    ac.check_apply_tail(engine, docs[:4], lambda n: 1)
+    ac.check_apply_replicas(engine, docs, 4)
+    ac.check_queue_across_calls(engine, docs[0], docs[1])
+
+
+def test_load_with_change_chunks_and_incremental(engine):
+    import apply_cases as ac
+    blob, offs = engine.gen_map_docs(21, 2, 3, 3, 40, 24, 1)
+    for i in range(2):
+        d = bytes(blob[offs[i]:offs[i + 1]])
+        ac.check_trailing_and_policies(engine, d)
+        ac.check_incremental_and_errors(engine, d)
+    blob, offs = engine.gen_text_docs(0xC1, 1, 2, 50, 300, 60, 1)
+    ac.check_trailing_and_policies(engine, bytes(blob[offs[1]:offs[2]]))
+    ac.check_incremental_and_errors(engine, bytes(blob[offs[1]:offs[2]]))
+
+
+def test_apply_large_text_changes(engine):
+    """changes of thousands of ops applied onto a large document: long new subtrees, many gaps"""
+    import apply_cases as ac
+    blob, offs = engine.gen_text_docs(0xBEEF, 2, 3, 1000, 5000, 500, 2)
+    docs = [bytes(blob[offs[i]:offs[i + 1]]) for i in range(6)]
+    ac.check_apply_replicas(engine, docs, 3)
