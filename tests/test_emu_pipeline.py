@@ -219,3 +219,8 @@ def test_load_with_change_chunks_and_incremental(emu):
     blob, offs = emu.gen_text_docs(0xC1, 1, 2, 50, 300, 60, 1)
     ac.check_trailing_and_policies(emu, bytes(blob[offs[1]:offs[2]]))
     ac.check_incremental_and_errors(emu, bytes(blob[offs[1]:offs[2]]))
+
+
+def test_edit_trace(emu, golden_dir):
+    import edit_trace_case as et
+    et.check_engine(emu, golden_dir)

@@ -255,3 +255,9 @@ def test_apply_large_text_changes(engine):
     blob, offs = engine.gen_text_docs(0xBEEF, 2, 3, 1000, 5000, 500, 2)
     docs = [bytes(blob[offs[i]:offs[i + 1]]) for i in range(6)]
     ac.check_apply_replicas(engine, docs, 3)
+
+
+def test_edit_trace(engine, golden_dir):
+    """BASELINE.json configs[0] on the device: one document, one change of 259,779 ops"""
+    import edit_trace_case as et
+    et.check_engine(engine, golden_dir)

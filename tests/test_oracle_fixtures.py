@@ -74,3 +74,14 @@ def test_saved_documents_decode_in_reference_js(golden_dir):
             assert mine["len"] == js["nops"] and mine["start_op"] == js["startOp"] and mine["seq"] == js["seq"]
         plain = name.replace(".deflate", "")
         assert d.save_nocompress() == _read(golden_dir, "docs", plain)
+
+
+def test_edit_trace_fixture(golden_dir):
+    """configs[0]: hash pinned by the legacy JS encoder, text pinned by a plain replay of the trace"""
+    import edit_trace_case as et
+    data, meta = et.load_fixture(golden_dir)
+    d = o.Doc.load(data)
+    (c,) = d.changes()
+    assert c["hash"].hex() == meta["change_hash"] and c["len"] == meta["n_ops"]
+    et.check_hydrated(d.hydrate_json(), meta)
+    assert d.save(deflate=False) == data

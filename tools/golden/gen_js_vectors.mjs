@@ -259,3 +259,16 @@ if (mode === "decode_docs") {
   }
   fs.writeFileSync(process.argv[4], JSON.stringify(out))
 }
+
+if (mode === "encode_change") {
+  // argv[3] = one change as JSON (shape of `mk` above); argv[4] = output {hash, hex}
+  const c = JSON.parse(fs.readFileSync(process.argv[3], "utf8"))
+  const bin = encodeChange(c)
+  fs.writeFileSync(process.argv[4], JSON.stringify({ hash: decodeChange(bin).hash, hex: hex(bin) }))
+}
+
+if (mode === "decode_doc") {
+  // argv[3] = a document written by our oracle; argv[4] = output: per re-derived change its hash and op count
+  const changes = decodeDocument(fs.readFileSync(process.argv[3]))
+  fs.writeFileSync(process.argv[4], JSON.stringify(changes.map(c => ({ hash: decodeChange(encodeChange(c)).hash, actor: c.actor, seq: c.seq, startOp: c.startOp, nops: c.ops.length }))))
+}
