@@ -40,7 +40,7 @@ EXPORTS = [
     "amh_load_batch", "amh_batch_free", "amh_bytes_free", "amh_doc_status", "amh_batch_get_stats", "amh_heads",
     "amh_changes", "amh_hydrate_json", "amh_doc_max_op", "amh_merge_batch", "amh_apply_changes", "amh_save_batch",
     "amh_sync_summaries", "amh_ctx_set_profiling", "amh_ctx_num_kernels", "amh_ctx_kernel_name", "amh_ctx_kernel_time",
-    "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free", "amh_apply_batch", "amh_doc_queue_len",
+    "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free", "amh_apply_batch", "amh_doc_queue_len", "amh_merge_many",
 ]
 
 DOC_ERRORS = {
@@ -93,6 +93,7 @@ def bind(lib):
     lib.amh_apply_batch.argtypes = [vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int,
                                     C.POINTER(C.c_int)]
     lib.amh_doc_queue_len.argtypes = [vp, C.c_uint32, C.POINTER(C.c_size_t)]
+    lib.amh_merge_many.argtypes = [vp, vp, C.POINTER(vp), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]
     return lib
 
 
@@ -225,15 +226,28 @@ class Batch:
             raise EngineError(f"amh_merge_batch failed: {rc} {self.engine._err()}")
         return rc
 
+    def merge_many(self, others, dst_idx, src_idx):
+        """== self[dst_idx[p]].merge(others[0][src_idx[0][p]]); .merge(others[1][...]); ... in one pass over the rows.
+        src_idx[s][p] = document of others[s] (None = nothing from that source).  Returns 0 or -7 like merge."""
+        ns, n = len(others), len(dst_idx)
+        hs = (C.c_void_p * max(1, ns))(*[o.h for o in others])
+        a = (C.c_uint32 * max(1, n))(*dst_idx)
+        flat = [0xFFFFFFFF if src_idx[s][p] is None else src_idx[s][p] for s in range(ns) for p in range(n)]
+        b = (C.c_uint32 * max(1, ns * n))(*flat)
+        rc = self.engine.lib.amh_merge_many(self.engine.ctx, self.h, hs, ns, a, b, n)
+        if rc not in (0, -7):
+            raise EngineError(f"amh_merge_many failed: {rc} {self.engine._err()}")
+        return rc
+
     def apply_changes(self, i, changes):
         """== self[i].apply_changes(changes) (automerge.rs:785): `changes` = change chunks (Change::raw_bytes).
         Raises AutomergeError with the reference's kind when the call fails for the document."""
-        res = self.apply_batch([(i, c) for c in changes])
+        res = self.apply_batch([(i, b"".join(bytes(c) for c in changes))])
         if res and res[0]:
             raise AutomergeError(res[0], "apply_changes")
 
     def apply_batch(self, items, incremental=False):
-        """items = [(document, bytes)]: every buffer holds one or more chunks for that document, applied in order.
+        """items = [(document, bytes)]: every buffer holds one or more chunks and is one apply_changes call on that document.
         incremental=False is apply_changes per document; True is load_incremental (automerge.rs:730-769: chunks in
         front of the first unreadable one are applied).  Returns the per-item outcome (0 or the AutomergeError kind)."""
         n = len(items)

@@ -1295,6 +1295,7 @@ struct ApplyItem {
   u32 doc = 0;
   int mode = APM_STRICT;
   bool first_was_doc = true;
+  bool one_call = false;       // all buffers together are one apply_changes call (else: one call per buffer)
   std::vector<std::pair<const u8*, size_t>> bufs;   // each: one or more concatenated chunks
 };
 struct HostChunk {
@@ -1304,6 +1305,7 @@ struct HostChunk {
   std::vector<u8> owned;
   i32 bad = 0;                 // host-level failure of this position of the stream (nothing staged)
   bool from_queue = false;
+  u32 buf = 0;                 // which of the item's buffers it came from (one buffer = one apply_changes call)
   u32 staged = AMH_NULL32;     // index in U
 };
 static bool host_uleb(const u8* p, size_t& pos, size_t end, u64& out) {
@@ -1366,9 +1368,12 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   std::vector<u32> pc_base(P + 1, 0);
   for (u32 p = 0; p < P; p++) {
     pc_base[p] = (u32)chunks.size();
+    u32 bi = 0;
     for (auto& bf : items[p].bufs) {
       size_t before = chunks.size();
       split_chunks(p, bf.first, bf.second, chunks);
+      for (size_t k = before; k < chunks.size(); k++) chunks[k].buf = bi;
+      if (!items[p].one_call) bi++;
       if (chunks.size() > before && chunks.back().bad) break;   // nothing behind a bad position is looked at
     }
     auto qit = dst->queue.find(items[p].doc);
@@ -1567,18 +1572,25 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     std::vector<u32> order, queue = oldq;
     auto apply = [&](u32 k) { history.emplace(hash_of(k), nca + (u32)order.size()); order.push_back(k); per_actor[actor_of(k)]++; };
     bool dup = false;
-    for (u32 k : fresh) {
-      if (history.count(hash_of(k))) continue;
-      auto it = per_actor.find(actor_of(k));
-      if (it != per_actor.end() && it->second >= hdr[chunks[k].staged].seq) { dup = true; break; }
-      if (ready(k)) apply(k); else queue.push_back(k);
+    auto drain = [&]() {   // pop_next_causally_ready_change (automerge.rs:849-858): linear scan + swap_remove
+      for (;;) {
+        bool got = false;
+        for (size_t q = 0; q < queue.size(); q++)
+          if (ready(queue[q])) { u32 k = queue[q]; queue[q] = queue.back(); queue.pop_back(); if (!history.count(hash_of(k))) apply(k); got = true; break; }
+        if (!got) break;
+      }
+    };
+    for (size_t fi = 0; fi < fresh.size() && !dup; fi++) {
+      u32 k = fresh[fi];
+      if (!history.count(hash_of(k))) {
+        auto it = per_actor.find(actor_of(k));
+        if (it != per_actor.end() && it->second >= hdr[chunks[k].staged].seq) { dup = true; break; }
+        if (ready(k)) apply(k); else queue.push_back(k);
+      }
+      // every buffer is one apply_changes call: the queue is drained at its end
+      if (fi + 1 == fresh.size() || chunks[fresh[fi + 1]].buf != chunks[k].buf) drain();
     }
-    while (!dup) {
-      bool got = false;
-      for (size_t q = 0; q < queue.size(); q++)
-        if (ready(queue[q])) { u32 k = queue[q]; queue[q] = queue.back(); queue.pop_back(); if (!history.count(hash_of(k))) apply(k); got = true; break; }
-      if (!got) break;
-    }
+    if (fresh.empty() && !dup) drain();
     if (dup) { p_status[p] = AMH_E_DUPLICATE_SEQ; results[p] = AMH_E_DUPLICATE_SEQ; n_failed++; continue; }
     if (mode == APM_LOAD_ERROR && !items[p].first_was_doc && !queue.empty()) { p_status[p] = AMH_E_MISSING_DEPS; results[p] = AMH_E_MISSING_DEPS; n_failed++; continue; }
     new_queue[p] = queue; queue_dirty[p] = 1;
@@ -1740,9 +1752,92 @@ extern "C" int amh_apply_changes(amh_ctx* ctx, amh_batch* b, uint32_t doc, const
   std::vector<ApplyItem> items(1);
   items[0].doc = doc;
   items[0].mode = APM_STRICT;
+  items[0].one_call = true;
   for (size_t i = 0; i < n; i++) if (lens[i]) items[0].bufs.push_back({changes[i], lens[i]});
   std::vector<i32> res;
   return apply_core(ctx, b, items, res, "amh_apply_changes");
+}
+// dst[dst_idx[p]].merge(srcs[0][..]); .merge(srcs[1][..]); ... in one pass: the changes each source adds
+// (get_changes_added, automerge.rs:1311-1334, against the history as it stands after the sources before it) are
+// handed to the apply path as one apply_changes call per source, so the result — history order included — is that
+// of the sequential merges, while rows are placed, saved and re-verified once instead of once per source.
+extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* const* srcs, size_t n_srcs, const uint32_t* dst_idx, const uint32_t* src_idx, size_t n_pairs) {
+  if (!ctx || !dst || (n_srcs && !srcs) || (n_pairs && (!dst_idx || (n_srcs && !src_idx))) || n_pairs >= 0x7FFFFFFFull || n_srcs > 4096) { set_error(ctx, "amh_merge_many: invalid argument"); return AMH_ERR_INVALID_ARG; }
+  if (n_pairs == 0 || n_srcs == 0) return AMH_SUCCESS;
+  if (!ensure_chg(dst)) { set_error(ctx, "amh_merge_many: D2H copy failed"); return AMH_ERR_DEVICE; }
+  for (size_t s = 0; s < n_srcs; s++) {
+    const amh_batch* sb = srcs[s];
+    if (!sb || sb == dst) { set_error(ctx, "amh_merge_many: invalid source batch"); return AMH_ERR_INVALID_ARG; }
+    if (!ensure_chg(sb)) { set_error(ctx, "amh_merge_many: D2H copy failed"); return AMH_ERR_DEVICE; }
+    HostView& hv = sb->hv;
+    if (!hv.out_ok) {
+      if (!fetch(sb, hv.out_arena, sb->B.out_arena, (size_t)sb->tot_out) || !rt_sync(ctx->stream)) { set_error(ctx, "amh_merge_many: D2H copy failed"); return AMH_ERR_DEVICE; }
+      hv.out_ok = true;
+    }
+  }
+  if (!rt_sync(ctx->stream)) return AMH_ERR_DEVICE;
+  const HostView& ha = dst->hv;
+  u32 P = (u32)n_pairs;
+  std::vector<ApplyItem> items(P);
+  std::vector<std::vector<std::vector<u8>>> owned(P);
+  std::vector<i32> pre_fail(P, 0);
+  std::vector<u8> seen_doc(dst->B.n_docs, 0);
+  for (u32 p = 0; p < P; p++) {
+    u32 a = dst_idx[p];
+    if (a >= dst->B.n_docs || seen_doc[a]) { set_error(ctx, "amh_merge_many: document index out of range or used twice"); return AMH_ERR_INVALID_ARG; }
+    seen_doc[a] = 1;
+    items[p].doc = a;
+    items[p].mode = APM_STRICT;
+    if (dst->status[a]) continue;   // apply_core reports it
+    u32 nca = ha.cnt[a].n_chg, cba = ha.chg_base[a];
+    std::unordered_map<Hash32, u32, Hash32Hasher> known;
+    known.reserve((size_t)nca * 2 + 16);
+    for (u32 i = 0; i < nca; i++) { Hash32 h; memcpy(h.b, ha.c_hash.data() + (size_t)(cba + i) * 32, 32); known.emplace(h, i); }
+    for (size_t s = 0; s < n_srcs; s++) {
+      u32 b = src_idx[s * n_pairs + p];
+      if (b == AMH_NULL32) continue;
+      const amh_batch* sb = srcs[s];
+      if (b >= sb->B.n_docs) { set_error(ctx, "amh_merge_many: source document index out of range"); return AMH_ERR_INVALID_ARG; }
+      if (sb->status[b]) { pre_fail[p] = sb->status[b]; break; }
+      const HostView& hb = sb->hv;
+      u32 ncb = hb.cnt[b].n_chg, cbb = hb.chg_base[b];
+      auto bhash = [&](u32 j) { return hb.c_hash.data() + (size_t)(cbb + j) * 32; };
+      std::vector<u8> is_dep(ncb, 0), seen(ncb, 0);
+      for (u32 j = 0; j < ncb; j++) for (u32 k = 0; k < hb.c_ndeps[cbb + j]; k++) is_dep[hb.dep_idx[hb.c_dep_base[cbb + j] + k]] = 1;
+      std::vector<u32> stack, added, deps;
+      for (u32 j = 0; j < ncb; j++) if (!is_dep[j]) stack.push_back(j);
+      std::sort(stack.begin(), stack.end(), [&](u32 x, u32 y) { return memcmp(bhash(x), bhash(y), 32) < 0; });
+      while (!stack.empty()) {
+        u32 j = stack.back(); stack.pop_back();
+        if (seen[j]) continue;
+        Hash32 h; memcpy(h.b, bhash(j), 32);
+        if (known.count(h)) continue;
+        seen[j] = 1; added.push_back(j);
+        deps.clear();
+        for (u32 k = 0; k < hb.c_ndeps[cbb + j]; k++) deps.push_back(hb.dep_idx[hb.c_dep_base[cbb + j] + k]);
+        std::sort(deps.begin(), deps.end(), [&](u32 x, u32 y) { return memcmp(bhash(x), bhash(y), 32) < 0; });
+        for (u32 dj : deps) stack.push_back(dj);
+      }
+      std::reverse(added.begin(), added.end());
+      if (added.empty()) continue;
+      std::vector<u8> buf;
+      for (u32 j : added) {
+        const u8* q = hb.out_arena.data() + hb.c_out_off[cbb + j];
+        buf.insert(buf.end(), q, q + hb.c_out_len[cbb + j]);
+        Hash32 h; memcpy(h.b, bhash(j), 32);
+        known.emplace(h, 0);   // every added change applies (the source's history is causally closed)
+      }
+      owned[p].push_back(std::move(buf));
+    }
+    if (pre_fail[p]) owned[p].clear();
+    for (auto& buf : owned[p]) items[p].bufs.push_back({buf.data(), buf.size()});
+  }
+  std::vector<i32> results;
+  int rc = apply_core(ctx, dst, items, results, "amh_merge_many");
+  if (rc != AMH_SUCCESS && rc != AMH_ERR_DOC_FAILED) return rc;
+  for (u32 p = 0; p < P; p++) if (pre_fail[p]) rc = AMH_ERR_DOC_FAILED;
+  if (rc == AMH_ERR_DOC_FAILED) set_error(ctx, "amh_merge_many: some documents were left unmerged (failed documents, duplicate seq numbers or unsupported shapes)");
+  return rc;
 }
 extern "C" int amh_doc_queue_len(const amh_batch* b, uint32_t doc, size_t* n) {
   if (!b || !n || doc >= b->B.n_docs) return AMH_ERR_INVALID_ARG;

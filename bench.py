@@ -105,8 +105,13 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
     def step():
         batches = [eng.load_staged(s) for s in staged]
         t_load = time.perf_counter()
-        for r in range(1, R):
-            rc = batches[0].merge(batches[r], pairs)
+        if args.sequential_merges:
+            for r in range(1, R):
+                rc = batches[0].merge(batches[r], pairs)
+                assert rc == 0, rc
+        else:   # the same result (history order included) with one pass over the rows
+            ids = list(range(args.docs))
+            rc = batches[0].merge_many(batches[1:], ids, [ids] * (R - 1))
             assert rc == 0, rc
         return batches, t_load
 
@@ -144,6 +149,7 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
                "config": {"workload": f"configs[2]: text documents x {R} divergent replicas of 5k edits, load {R} + merge {R - 1}",
                           "docs_per_gpu": args.docs, "ops_per_merged_doc": ops / args.docs, "gen_s": round(t_gen, 2),
                           "load_ms_per_step": load_s / args.steps * 1e3, "merge_ms_per_step": (elapsed - load_s) / args.steps * 1e3,
+                          "merge_call": "sequential amh_merge_batch" if args.sequential_merges else "amh_merge_many",
                           "note": "merge round-trips the merged documents through the host (save bytes -> reload); ops counted once per merged document"}}
         if not args.no_cpu and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -175,6 +181,7 @@ def main():
     ap.add_argument("--workload", default="load", choices=["load", "merge"],
                     help="load = configs[1] (the headline line); merge = configs[2]: text documents x 8 divergent replicas, load 8 + merge 7")
     ap.add_argument("--replicas", type=int, default=8)
+    ap.add_argument("--sequential-merges", action="store_true", help="merge workload: R-1 amh_merge_batch calls instead of one amh_merge_many")
     args = ap.parse_args()
 
     import torch

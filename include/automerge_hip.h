@@ -148,6 +148,13 @@ int amh_doc_max_op(const amh_batch*, uint32_t doc, uint64_t* max_op);
  * DuplicateSeqNumber); their dst documents are unchanged.  Every merged document is re-verified (change
  * hashes, heads) before it replaces the old one. */
 int amh_merge_batch(amh_ctx*, amh_batch* dst, const amh_batch* src, const uint32_t* dst_idx, const uint32_t* src_idx, size_t n_pairs);
+/* == dst.merge(&mut s0); dst.merge(&mut s1); ... per pair with ONE pass over the rows (same result, history order
+ * included, as the sequential amh_merge_batch calls: the changes each source adds, automerge.rs:1311-1334, go through
+ * the apply path as one apply_changes call per source).  src_idx[s * n_pairs + p] = document of srcs[s] merged into
+ * dst[dst_idx[p]], or 0xFFFFFFFF for none.  Built for configs[2] (8 replicas per document): rows are placed, saved and
+ * re-verified once instead of 7 times.  On DuplicateSeqNumber in any source the document is left untouched. */
+int amh_merge_many(amh_ctx*, amh_batch* dst, const amh_batch* const* srcs, size_t n_srcs, const uint32_t* dst_idx,
+                   const uint32_t* src_idx, size_t n_pairs);
 /* == Automerge::apply_changes (automerge.rs:785-858; AMapplyChanges, automerge-c/src/doc.rs:84) on one document:
  * changes[i] = one change chunk, plain or compressed (what Change::try_from takes, change.rs:161-180: the stored
  * checksum is not compared).  Changes the document already has are skipped; changes whose dependencies are missing
@@ -158,7 +165,8 @@ int amh_merge_batch(amh_ctx*, amh_batch* dst, const amh_batch* src, const uint32
  * it, reloads the whole batch: apply to many documents with one amh_apply_batch call. */
 int amh_apply_changes(amh_ctx*, amh_batch*, uint32_t doc, const uint8_t* const* changes, const size_t* lens, size_t n);
 /* Batched form.  Buffer i holds one or more concatenated chunks for document doc_idx[i]; several buffers may name
- * the same document (applied in the order given).
+ * the same document: each buffer is one apply_changes / load_incremental call on it, in the order given (the queue
+ * of waiting changes is drained at the end of every buffer, automerge.rs:797-827).
  *   incremental = 0: apply_changes per document, as above.
  *   incremental = 1: == Automerge::load_incremental on a loaded document (automerge.rs:730-769; AMloadIncremental,
  *                    automerge-c/src/doc.rs:537): checksums are verified and the chunks in front of the first

@@ -29,7 +29,7 @@ def check_apply_tail(engine, docs, cut):
         bases.append(base.save(deflate=False))
         tails.append(chunks[k:])
     b = engine.load_batch(bases)
-    res = b.apply_batch([(i, c) for i, t in enumerate(tails) for c in t])
+    res = b.apply_batch([(i, b"".join(t)) for i, t in enumerate(tails) if t])
     assert not any(res), res
     saved = b.save_all(deflate=False)
     for i in range(len(docs)):
@@ -58,7 +58,8 @@ def check_apply_replicas(engine, docs, n_replicas):
             if d % 3 == 2:
                 new = new + new[:2]
             refs[d].apply_changes(new)
-            items += [(d, c) for c in new]
+            if new:
+                items.append((d, b"".join(new)))
         res = b.apply_batch(items)
         assert not any(res), res
         saved = b.save_all(deflate=False)

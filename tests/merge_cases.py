@@ -42,3 +42,29 @@ def check_merge(engine, dst_docs, src_docs, pairs):
             ref.merge(o.Doc.load(src_docs[paired[a]]))
         assert saved[a] == ref.save(deflate=False), a
     return bd
+
+
+def check_merge_many(engine, reps):
+    """reps[r][i] = replica r of document i.  One merge_many call == replica 0 merging replicas 1.. one after the other
+    (oracle); state, heads, history order and saved bytes must agree.  Sources are given per document in a rotated
+    order and one document skips a source, so that the per-source bookkeeping is exercised."""
+    n_rep, n_docs = len(reps), len(reps[0])
+    bd = engine.load_batch(reps[0])
+    others = [engine.load_batch(reps[r]) for r in range(1, n_rep)]
+    src_idx = [[i for i in range(n_docs)] for _ in range(n_rep - 1)]
+    if n_docs > 1 and n_rep > 2:
+        src_idx[1][1] = None
+    rc = bd.merge_many(others, list(range(n_docs)), src_idx)
+    assert rc == 0
+    saved = bd.save_all(deflate=False)
+    for i in range(n_docs):
+        ref = o.Doc.load(bytes(reps[0][i]))
+        for s in range(n_rep - 1):
+            if src_idx[s][i] is not None:
+                ref.merge(o.Doc.load(bytes(reps[s + 1][src_idx[s][i]])))
+        bd.check(i)
+        assert bd.hydrate_json(i) == ref.hydrate_json(), i
+        assert bd.get_heads(i) == ref.get_heads(), i
+        assert [c["hash"] for c in bd.get_changes(i)] == [c["hash"] for c in ref.changes()], i
+        assert saved[i] == ref.save(deflate=False), i
+    return bd

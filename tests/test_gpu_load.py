@@ -204,6 +204,16 @@ def test_merge_text_replicas(engine):
         cur = bd.save_all(deflate=False)
 
 
+def test_merge_many_replicas_in_one_pass(engine):
+    from merge_cases import check_merge_many, split_map_doc
+    n_docs, n_rep = 6, 8
+    blob, offs = engine.gen_text_docs(0xE171, n_docs, n_rep, 200, 1000, 100, 2)
+    check_merge_many(engine, [[bytes(blob[offs[i * n_rep + r]:offs[i * n_rep + r + 1]]) for i in range(n_docs)] for r in range(n_rep)])
+    blob, offs = engine.gen_map_docs(47, 3, 4, 5, 30, 24, 2)
+    halves = [split_map_doc(bytes(blob[offs[i]:offs[i + 1]])) for i in range(3)]
+    check_merge_many(engine, [[a for a, _ in halves], [b for _, b in halves], [bytes(blob[offs[i]:offs[i + 1]]) for i in range(3)]])
+
+
 def test_merge_nothing_new_and_failures(engine):
     from merge_cases import split_map_doc
     blob, offs = engine.gen_map_docs(43, 2, 4, 5, 10, 8, 1)
