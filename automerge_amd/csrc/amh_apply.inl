@@ -319,8 +319,9 @@ AMH_DEV void k_ap_link(const MergeDev& G, u32 r) {
 // A6  document order of the new rows of a pair.  Rows that hang off another new row form subtrees
 //     (an element: its updates in ascending id, then its child elements in descending id, each with its
 //     subtree — query/opid.rs:170-183, op_tree.rs:212-239); the remaining "top" rows are sorted by where
-//     they go among the dst rows.  Thread per pair (serial per document, like the reference; the top rows
-//     use a merge sort, so the cost is O(n log n)).
+//     they go among the dst rows.  All per row: child lists by lock-free push + per-parent ordering, subtree
+//     weights by pointer jumping, a counting sort of the top rows on their gap (ties ranked pairwise), and one
+//     thread per top row that writes its subtree in preorder.
 // ------------------------------------------------------------------------------------------
 AMH_DEV int ap_id_cmp(const MergeDev& G, u32 p, u32 x, u32 y) {
   const BatchDev& S = G.S;
@@ -353,67 +354,109 @@ AMH_DEV bool ap_top_less(const MergeDev& G, u32 p, u32 x, u32 y) {
   c = ap_id_cmp(G, p, x, y);
   return xi ? c > 0 : c < 0;
 }
-AMH_DEV void k_ap_order(const MergeDev& G, u32 p) {
+// A6a  child lists: every new row that hangs off a new row is pushed onto its parent's list (lock-free; the lists
+//      are put in order by A6b).  Also the start of the pointer jumping of A6c.  Thread per row of U.
+AMH_DEV bool ap_row_new(const MergeDev& G, u32 r) { return G.new_idx[r + 1] != G.new_idx[r]; }
+AMH_DEV void k_ap_children(const MergeDev& G, u32 r) {
+  const ApplyDev& A = G.A;
+  A.o_top[r] = AMH_NULL32;   // jump pointer
+  A.o_tmp[r] = 0;            // weight
+  if (!ap_row_new(G, r)) return;
+  u32 p = G.S.r_doc[r];
   if (!mg_pair_ok(G, p)) return;
+  u32 par = A.parent[r];
+  if (par == AMH_NULL32) return;
+  if (!ap_row_new(G, par)) { G.p_status[p] = AMH_E_UNSUPPORTED; return; }   // hangs off a row that is not applied: cannot happen for causally ready changes
+  A.o_top[r] = par;
+  u32* head = G.S.r_insert[r] ? &A.o_head_ins[par] : &A.o_head_upd[par];
+  A.o_next[r] = amh_atomic_exch(head, r);
+}
+// A6b  order the two child lists of a row: updates ascending, child elements descending by lamport id (lists are
+//      short: one or two entries except when many elements are typed behind the same new element).  Thread per row.
+AMH_DEV u32 ap_sort_list(const MergeDev& G, u32 p, u32 head, bool desc) {
+  const ApplyDev& A = G.A;
+  u32 sorted = AMH_NULL32, cur = head;
+  while (cur != AMH_NULL32) {
+    u32 nx = A.o_next[cur];
+    u32 prev = AMH_NULL32, q = sorted;
+    while (q != AMH_NULL32) {
+      int c = ap_id_cmp(G, p, q, cur);
+      if (desc ? c < 0 : c > 0) break;
+      prev = q; q = A.o_next[q];
+    }
+    A.o_next[cur] = q;
+    if (prev == AMH_NULL32) sorted = cur; else A.o_next[prev] = cur;
+    cur = nx;
+  }
+  return sorted;
+}
+AMH_DEV void k_ap_sort_children(const MergeDev& G, u32 r) {
+  const ApplyDev& A = G.A;
+  u32 hu = A.o_head_upd[r], hi = A.o_head_ins[r];
+  if (hu == AMH_NULL32 && hi == AMH_NULL32) return;
+  u32 p = G.S.r_doc[r];
+  if (p >= G.n_pairs || !mg_pair_ok(G, p)) return;
+  if (hu != AMH_NULL32 && A.o_next[hu] != AMH_NULL32) A.o_head_upd[r] = ap_sort_list(G, p, hu, false);
+  if (hi != AMH_NULL32 && A.o_next[hi] != AMH_NULL32) A.o_head_ins[r] = ap_sort_list(G, p, hi, true);
+}
+// A6c  the top row every new row sits under, by pointer jumping (one launch halves the distances; the host
+//      repeats it until no pointer moved).  Thread per row.
+AMH_DEV void k_ap_jump(const MergeDev& G, u32 r) {
+  const ApplyDev& A = G.A;
+  u32 j = A.o_top[r];
+  if (j == AMH_NULL32) return;
+  u32 jj = A.o_top[j];
+  if (jj == AMH_NULL32) return;
+  A.o_top[r] = jj;
+  *A.flag = 1;
+}
+// A6d  weight of a top row = rows of its subtree, itself included.  Thread per row.
+AMH_DEV void k_ap_weight(const MergeDev& G, u32 r) {
+  if (!ap_row_new(G, r)) return;
+  u32 j = G.A.o_top[r];
+  amh_atomic_add(&G.A.o_tmp[j == AMH_NULL32 ? r : j], 1);
+}
+// A6e  top rows per gap: rows in front of a dst row (gap_cnt, scanned next) and the list of top rows sharing the gap.
+AMH_DEV void k_ap_top_place(const MergeDev& G, u32 r) {
+  const ApplyDev& A = G.A;
+  if (!ap_row_new(G, r) || A.parent[r] != AMH_NULL32) return;
+  u32 p = G.S.r_doc[r];
+  if (!mg_pair_ok(G, p)) return;
+  u32 g = A.gap[r];
+  if (g == AMH_NULL32) { G.p_status[p] = AMH_E_UNSUPPORTED; return; }
+  u32 slot = G.gap_base[p] + g;
+  amh_atomic_add(&G.gap_cnt[slot], A.o_tmp[r]);
+  A.o_next[r] = amh_atomic_exch(&A.g_head[slot], r);
+}
+// A6f  emit: a top row starts behind the new rows of smaller gaps (scanned gap_cnt) and behind the top rows of its
+//      own gap that sort in front of it (with their subtrees); its subtree follows in preorder.  Thread per top row.
+AMH_DEV void k_ap_emit(const MergeDev& G, u32 r) {
   const BatchDev& S = G.S;
   const ApplyDev& A = G.A;
-  u32 rb = S.row_base[p], n = S.cnt[p].n_rows;
-  u32 k0 = G.new_idx[rb], k1 = G.new_idx[rb + n];
-  if (k1 == k0) return;
-  u32* top = A.o_top + rb;
-  u32* tmp = A.o_tmp + rb;
-  u32* stack = A.o_stack + rb;
-  u32 nt = 0;
-  for (u32 i = 0; i < n; i++) {
-    u32 r = rb + i;
-    if (G.new_idx[r + 1] == G.new_idx[r]) continue;
-    u32 par = A.parent[r];
-    if (par == AMH_NULL32) { top[nt++] = r; continue; }
-    if (S.r_insert[r]) {   // child elements: descending id (arrival in ascending id makes this a push at the head)
-      u32 prev = AMH_NULL32, cur = A.o_head_ins[par];
-      while (cur != AMH_NULL32 && ap_id_cmp(G, p, cur, r) > 0) { prev = cur; cur = A.o_next[cur]; }
-      A.o_next[r] = cur;
-      if (prev == AMH_NULL32) A.o_head_ins[par] = r; else A.o_next[prev] = r;
-    } else {               // updates of the element: ascending id
-      u32 prev = AMH_NULL32, cur = A.o_head_upd[par];
-      while (cur != AMH_NULL32 && ap_id_cmp(G, p, cur, r) < 0) { prev = cur; cur = A.o_next[cur]; }
-      A.o_next[r] = cur;
-      if (prev == AMH_NULL32) A.o_head_upd[par] = r; else A.o_next[prev] = r;
-    }
+  if (!ap_row_new(G, r) || A.parent[r] != AMH_NULL32) return;
+  u32 p = S.r_doc[r];
+  if (!mg_pair_ok(G, p)) return;
+  u32 g = A.gap[r];
+  const u32* pre = G.gap_cnt + G.gap_base[p];
+  u32 k = G.new_idx[S.row_base[p]] + (pre[g] - pre[0]);
+  for (u32 m = A.g_head[G.gap_base[p] + g]; m != AMH_NULL32; m = A.o_next[m])
+    if (m != r && ap_top_less(G, p, m, r)) k += A.o_tmp[m];
+  u32* stack = A.o_stack + k;   // at most weight - 1 entries: the rows this thread emits
+  G.new_src[k] = r; G.new_gap[k] = g; k++;
+  if (row_is_prop(S, r) || !S.r_insert[r]) return;
+  u32 sp = 0, cur = r;
+  bool first = true;
+  for (;;) {
+    if (!first) { G.new_src[k] = cur; G.new_gap[k] = g; k++; }
+    first = false;
+    for (u32 u = A.o_head_upd[cur]; u != AMH_NULL32; u = A.o_next[u]) { G.new_src[k] = u; G.new_gap[k] = g; k++; }
+    u32 child = A.o_head_ins[cur];
+    u32 sib = cur == r ? AMH_NULL32 : A.o_next[cur];
+    if (child != AMH_NULL32) { if (sib != AMH_NULL32) stack[sp++] = sib; cur = child; }
+    else if (sib != AMH_NULL32) cur = sib;
+    else if (sp) cur = stack[--sp];
+    else break;
   }
-  // bottom-up merge sort of the top rows
-  u32 *src = top, *dst = tmp;
-  for (u32 w = 1; w < nt; w *= 2) {
-    for (u32 lo = 0; lo < nt; lo += 2 * w) {
-      u32 mid = lo + w < nt ? lo + w : nt, hi = lo + 2 * w < nt ? lo + 2 * w : nt;
-      u32 i = lo, j = mid, o = lo;
-      while (i < mid && j < hi) dst[o++] = ap_top_less(G, p, src[j], src[i]) ? src[j++] : src[i++];
-      while (i < mid) dst[o++] = src[i++];
-      while (j < hi) dst[o++] = src[j++];
-    }
-    u32* t = src; src = dst; dst = t;
-  }
-  // emit: every top row, then (for an element) its subtree in preorder
-  u32 k = k0;
-  for (u32 t = 0; t < nt; t++) {
-    u32 root = src[t];
-    G.new_src[k] = root; G.new_gap[k] = A.gap[root]; k++;
-    if (row_is_prop(S, root) || !S.r_insert[root]) continue;
-    u32 sp = 0, cur = root;
-    bool first = true;
-    for (;;) {
-      if (!first) { G.new_src[k] = cur; G.new_gap[k] = AMH_NULL32; k++; }
-      first = false;
-      for (u32 u = A.o_head_upd[cur]; u != AMH_NULL32; u = A.o_next[u]) { G.new_src[k] = u; G.new_gap[k] = AMH_NULL32; k++; }
-      u32 child = A.o_head_ins[cur];
-      u32 sib = cur == root ? AMH_NULL32 : A.o_next[cur];
-      if (child != AMH_NULL32) { if (sib != AMH_NULL32) stack[sp++] = sib; cur = child; }
-      else if (sib != AMH_NULL32) cur = sib;
-      else if (sp) cur = stack[--sp];
-      else break;
-    }
-  }
-  if (k != k1) G.p_status[p] = AMH_E_UNSUPPORTED;   // a row hanging off a row that is not applied (cannot happen for causally ready changes)
 }
 
 // ------------------------------------------------------------------------------------------

@@ -18,6 +18,7 @@ static inline void amh_atomic_add_i64(i64* p, i64 v) { *p += v; }
 static inline u32 amh_atomic_min(u32* p, u32 v) { u32 o = *p; if (v < o) *p = v; return o; }
 static inline u32 amh_atomic_max(u32* p, u32 v) { u32 o = *p; if (v > o) *p = v; return o; }
 static inline u32 amh_atomic_cas(u32* p, u32 cmp, u32 val) { u32 o = *p; if (o == cmp) *p = val; return o; }
+static inline u32 amh_atomic_exch(u32* p, u32 val) { u32 o = *p; *p = val; return o; }
 static inline u64 amh_atomic_cas64(u64* p, u64 cmp, u64 val) { u64 o = *p; if (o == cmp) *p = val; return o; }
 static inline i32 amh_atomic_cas_i32(i32* p, i32 cmp, i32 val) { i32 o = *p; if (o == cmp) *p = val; return o; }
 #else
@@ -31,6 +32,7 @@ AMH_DEV void amh_atomic_add_i64(i64* p, i64 v) { atomicAdd((unsigned long long*)
 AMH_DEV u32 amh_atomic_min(u32* p, u32 v) { return atomicMin(p, v); }
 AMH_DEV u32 amh_atomic_max(u32* p, u32 v) { return atomicMax(p, v); }
 AMH_DEV u32 amh_atomic_cas(u32* p, u32 cmp, u32 val) { return atomicCAS(p, cmp, val); }
+AMH_DEV u32 amh_atomic_exch(u32* p, u32 val) { return atomicExch(p, val); }
 AMH_DEV u64 amh_atomic_cas64(u64* p, u64 cmp, u64 val) {
   return atomicCAS((unsigned long long*)p, (unsigned long long)cmp, (unsigned long long)val);
 }

@@ -26,6 +26,22 @@
 
 static thread_local std::string g_last_error;
 
+// AMH_TIMING=1: wall-clock of the host phases of merge / apply on stderr (diagnostics)
+#include <chrono>
+struct PhaseTimer {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  const char* who;
+  PhaseTimer(const char* w) : on(getenv("AMH_TIMING") != nullptr), t0(std::chrono::steady_clock::now()), who(w) {}
+  void mark(const char* phase, rt_stream* s = nullptr) {
+    if (!on) return;
+    if (s) rt_sync(*s);
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[amh timing] %s: %-28s %8.2f ms\n", who, phase, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // caching device allocator: steady-state batches allocate nothing
 // ---------------------------------------------------------------------------------------------
@@ -927,6 +943,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   MG_REFS(pl)
   const BatchDev& DB = dst->B;
   u32 P = pl.P;
+  PhaseTimer pt(who);
   // ---- device ---------------------------------------------------------------------------------
   std::unique_ptr<amh_batch, void (*)(amh_batch*)> mbh(new amh_batch(), amh_batch_free);
   amh_batch* mb = mbh.get();
@@ -1027,10 +1044,31 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   rt_memset(G.gap_cnt, 0, ((size_t)gap_tot + 2) * 4, ctx->stream);
   rt_memset(M.r_succ_cnt, 0, NR * 4, ctx->stream);
   mg(MK_SUBTREE, P);
-  if (ap) { mg(MK_AP_LINK, G.U.tot_rows); mg(MK_AP_ORDER, P); }
-  else mg(MK_GAP, SB.tot_rows);
-  mg(MK_INHERIT, P);
+  pt.mark("exec: setup + subtree", &ctx->stream);
+  if (ap) {
+    u32 nr = G.U.tot_rows;
+    G.A.g_head = balloc<u32>(mb, (size_t)gap_tot + 2, &ok); G.A.flag = balloc<u32>(mb, 4, &ok);
+    if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+    rt_memset(G.A.g_head, 0xFF, ((size_t)gap_tot + 2) * 4, ctx->stream);
+    mg(MK_AP_LINK, nr);
+    mg(MK_AP_CHILDREN, nr);
+    mg(MK_AP_SORT_CHILDREN, nr);
+    for (int round = 0; round < 40; round++) {   // pointer jumping: distances halve per launch
+      u32 moved = 0;
+      rt_memset(G.A.flag, 0, 4, ctx->stream);
+      mg(MK_AP_JUMP, nr);
+      if (!rt_d2h(&moved, G.A.flag, 4, ctx->stream) || !rt_sync(ctx->stream)) return failm("D2H copy failed");
+      if (!moved) break;
+    }
+    mg(MK_AP_WEIGHT, nr);
+    mg(MK_AP_TOP_PLACE, nr);
+    pt.mark("exec: ap link .. top_place", &ctx->stream);
+  } else {
+    mg(MK_GAP, SB.tot_rows);
+    mg(MK_INHERIT, P);
+  }
   if (!scan_inplace(mb, G.gap_cnt, gap_tot, nullptr)) return failm("scan failed");
+  if (ap) { mg(MK_AP_EMIT, G.U.tot_rows); pt.mark("exec: ap_emit", &ctx->stream); }
   if (ap) {   // succ lists of the new rows themselves (a later op of the same call overwrote / deleted them)
     BatchDev& S = G.S;
     mg(MK_AP_PRED_CNT, G.U.tot_rows);
@@ -1071,6 +1109,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   // pairs the kernels rejected
   if (!rt_d2h(p_status.data(), G.p_status, P * sizeof(i32), ctx->stream)) return failm("D2H copy failed");
   if (!rt_h2d(M.status, p_status.data(), P * sizeof(i32), ctx->stream)) return failm("H2D copy failed");
+  pt.mark("exec: rows + succ + chunks", &ctx->stream);
   // ---- merged rows -> document chunks (the save kernels over M) ---------------------------------
   M.sv_status = balloc<i32>(mb, P + 1, &ok); M.sv_col_len = balloc<u32>(mb, (size_t)P * 25 + 1, &ok);
   M.sv_body_len = balloc<u32>(mb, P + 1, &ok); M.sv_off = balloc<u32>(mb, P + 2, &ok);
@@ -1092,6 +1131,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
       !rt_d2h(sv_body.data(), M.sv_body_len, P * 4, ctx->stream) || !rt_d2h(sv_st.data(), M.sv_status, P * 4, ctx->stream))
     return failm("D2H copy failed");
   collect_profile(ctx);
+  pt.mark("exec: save kernels + D2H", &ctx->stream);
   // ---- reload: every document of dst, merged ones from their new bytes ---------------------------
   u32 nd = DB.n_docs;
   std::vector<const uint8_t*> ptrs(nd);
@@ -1137,6 +1177,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   nb = nullptr;
   }
   for (u32 p = 0; p < P; p++) if (p_status[p] > 0) rc = AMH_ERR_DOC_FAILED;
+  pt.mark("exec: reload", &ctx->stream);
   // documents of dst that failed earlier keep their status (a reload of their first chunk alone may succeed)
   bool st_dirty = false;
   for (u32 d = 0; d < nd; d++)
@@ -1360,6 +1401,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   u32 P = (u32)items.size();
   results.assign(P, 0);
   if (P == 0) return AMH_SUCCESS;
+  PhaseTimer pt(who);
   if (!ensure_chg(dst)) { set_error(ctx, std::string(who) + ": D2H copy failed"); return AMH_ERR_DEVICE; }
   const HostView& ha = dst->hv;
   const BatchDev& DB = dst->B;
@@ -1420,6 +1462,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   }
   u32 NCH = (u32)staged_of.size();
   ap.n_chunks = NCH;
+  pt.mark("apply: split + stage (host)");
   std::vector<i32> u_status(NCH, 0);
   std::vector<ChgHdr> hdr(NCH);
   std::vector<DocCounts> u_cnt(NCH);
@@ -1492,6 +1535,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       return faild("device pipeline failed");
     collect_profile(ctx);
   }
+  pt.mark("apply: U decode + verify", &ctx->stream);
   // ---- host: which changes apply, in which order (automerge.rs:797-858); actors; merged history -----
   MgPlan pl;
   mg_plan_init(pl, P, DB.n_docs, P, NCH);
@@ -1677,6 +1721,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   bool any_work = false;
   for (u32 p = 0; p < P; p++) any_work = any_work || p_status[p] == 0;
   int rc = AMH_SUCCESS;
+  pt.mark("apply: decisions (host)");
   if (any_work) {
     if (arena_len >= 0xFFFFFFF0ull || mc_from.size() >= 0x7FFFFFFFull) { set_error(ctx, std::string(who) + ": batch too large"); return AMH_ERR_BATCH_TOO_LARGE; }
     BatchDev SB;
@@ -1778,6 +1823,7 @@ extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* con
   if (!rt_sync(ctx->stream)) return AMH_ERR_DEVICE;
   const HostView& ha = dst->hv;
   u32 P = (u32)n_pairs;
+  PhaseTimer pt("amh_merge_many");
   std::vector<ApplyItem> items(P);
   std::vector<std::vector<std::vector<u8>>> owned(P);
   std::vector<i32> pre_fail(P, 0);
@@ -1832,6 +1878,7 @@ extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* con
     if (pre_fail[p]) owned[p].clear();
     for (auto& buf : owned[p]) items[p].bufs.push_back({buf.data(), buf.size()});
   }
+  pt.mark("added changes (host)");
   std::vector<i32> results;
   int rc = apply_core(ctx, dst, items, results, "amh_merge_many");
   if (rc != AMH_SUCCESS && rc != AMH_ERR_DOC_FAILED) return rc;

@@ -202,7 +202,10 @@ struct ApplyDev {
   u32* u_chg;                      // [U rows] chunk of the row
   u32 *gap, *anchor, *parent;      // [U rows] dst-local gap (AMH_NULL32 = inside a new subtree), dst row it hangs off, parent row in U
   u32* p_tgt;                      // [U preds] bit 31 set: dst row (global), else row of U; AMH_NULL32 = none
-  u32 *o_next, *o_head_upd, *o_head_ins, *o_top, *o_tmp, *o_stack;   // [U rows] scratch of k_ap_order
+  u32 *o_next, *o_head_upd, *o_head_ins;   // [U rows] sibling / same-gap list links, heads of a row's update and child-element lists
+  u32 *o_top, *o_tmp, *o_stack;            // [U rows] jump pointer (-> top row), weight of a top row, DFS stacks of k_ap_emit
+  u32* g_head;                     // [gap counters] top rows sharing a gap
+  u32* flag;                       // [1] a pointer moved in this k_ap_jump launch
   u32* u_fill;                     // [U rows]
 };
 struct MergeDev {
