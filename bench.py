@@ -175,7 +175,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--docs", type=int, default=100000, help="documents per GPU (configs[1]: 100k)")
+    ap.add_argument("--docs", type=int, default=None, help="documents per GPU (default: 100k for load = configs[1]; 4000 for merge, "
+                    "a 40 % share of configs[2]'s 10k documents: the 8 source batches, the merged rows and the reloaded batch of all 10k "
+                    "do not fit one GPU's HBM together)")
     ap.add_argument("--cpu-sample", type=int, default=4000, help="documents of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--workload", default="load", choices=["load", "merge"],
@@ -183,6 +185,8 @@ def main():
     ap.add_argument("--replicas", type=int, default=8)
     ap.add_argument("--sequential-merges", action="store_true", help="merge workload: R-1 amh_merge_batch calls instead of one amh_merge_many")
     args = ap.parse_args()
+    if args.docs is None:
+        args.docs = 100000 if args.workload == "load" else 4000
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
