@@ -170,6 +170,78 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
         dist.destroy_process_group()
 
 
+def bench_sync(args, eng, rank, world, dist, torch, red_dev):
+    """configs[4]: sync-server sweep.  `--docs` documents per GPU (default 125k = 1M over 8 GPUs) of 8 changes x 20 map puts.
+    One step = load the rank's documents (every change re-derived and SHA-256 hashed, heads), heads + Bloom summary per
+    document (amh_sync_summaries), and the all-gather of the summary records over the process group (RCCL over xGMI)."""
+    from automerge_amd import dist as amd_dist
+    threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")) // max(1, world if world > 1 else 1) or 1, 32))
+    t0 = time.time()
+    arena = eng.gen_map_arena(0x5A5A + rank * args.docs, args.docs, 2, 4, 20, 64, max(4, threads))
+    t_gen = time.time() - t0
+    staged = eng.stage_arena(arena)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gathered_bytes = 0
+
+    def step():
+        nonlocal gathered_bytes
+        b = eng.load_staged(staged)
+        raw = b.sync_summaries_raw()
+        if dist is not None:
+            parts = amd_dist.all_gather_summaries(raw)
+            gathered_bytes = sum(len(x) for x in parts)
+        else:
+            gathered_bytes = len(raw)
+        return b
+
+    for _ in range(args.warmup):
+        step().close()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        b = step()
+        if _ + 1 < args.steps:
+            b.close()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = b.stats()
+    assert st["n_ok"] == args.docs
+    eng.set_profiling(True)
+    eng.reset_profile()
+    b2 = eng.load_staged(staged)
+    b2.sync_summaries_raw()
+    eng.set_profiling(False)
+    kt = eng.kernel_times()
+    tot = torch.tensor([float(elapsed), float(st["ops_loaded"]), float(st["changes"]), float(st["change_bytes"])], dtype=torch.float64, device=red_dev)
+    if dist is not None:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed_max = float(tmax[0])
+    else:
+        elapsed_max = elapsed
+    ops_all, chg_all, chg_bytes_all = float(tot[1]), float(tot[2]), float(tot[3])
+    if rank == 0:
+        sha_ms = kt.get("chg_hash", (0, 0))[0] + kt.get("chg_hash_seq", (0, 0))[0] + kt.get("sha_doc", (0, 0))[0]
+        out = {"metric": "ops loaded+merged/sec (node)", "value": ops_all * args.steps / elapsed_max, "unit": "ops/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64", "data": "synthetic",
+               "config": {"workload": "configs[4]: sync sweep — load (re-derive + SHA-256 every change, heads) + heads/Bloom summary per document + all-gather",
+                          "docs_per_gpu": args.docs, "docs_per_s": world * args.docs * args.steps / elapsed_max,
+                          "changes_hashed_per_s": chg_all * args.steps / elapsed_max, "summary_bytes_gathered": gathered_bytes,
+                          "sha256": {"kernel_ms": round(sha_ms, 3), "GB_hashed_per_s": round((chg_bytes_all / max(1, world) + st["encoded_bytes"]) / max(sha_ms, 1e-9) / 1e6, 2),
+                                     "note": "VALU-integer bound (64 rounds of 32-bit ALU per 64-byte block), reported as bytes hashed, not against HBM"},
+                          "sync_kernels_ms": {k: round(kt[k][0], 3) for k in ("sync_size", "sync_fill") if k in kt}, "gen_s": round(t_gen, 2)}}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,13 +252,13 @@ def main():
                     "do not fit one GPU's HBM together)")
     ap.add_argument("--cpu-sample", type=int, default=4000, help="documents of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", default="load", choices=["load", "merge"],
+    ap.add_argument("--workload", default="load", choices=["load", "merge", "sync"],
                     help="load = configs[1] (the headline line); merge = configs[2]: text documents x 8 divergent replicas, load 8 + merge 7")
     ap.add_argument("--replicas", type=int, default=8)
     ap.add_argument("--sequential-merges", action="store_true", help="merge workload: R-1 amh_merge_batch calls instead of one amh_merge_many")
     args = ap.parse_args()
     if args.docs is None:
-        args.docs = 100000 if args.workload == "load" else 4000
+        args.docs = {"load": 100000, "merge": 4000, "sync": 125000}[args.workload]
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -199,7 +271,7 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("AMH_BENCH_FORCE_DIST"):   # the latter: rehearse the RCCL code path with one rank on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -212,6 +284,8 @@ def main():
     eng = Engine(gpu=local_rank)
     if args.workload == "merge":
         return bench_merge(args, eng, rank, world, dist, torch, red_dev)
+    if args.workload == "sync":
+        return bench_sync(args, eng, rank, world, dist, torch, red_dev)
     omp = int(os.environ.get("OMP_NUM_THREADS", "16"))
     threads = max(1, min(omp if world == 1 else max(4, omp // world), 32))   # host threads of the (untimed) generator
     seed = 0xA070 + rank * args.docs
