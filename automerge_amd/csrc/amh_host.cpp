@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <string>
@@ -870,6 +871,26 @@ struct Hash32 {
 };
 struct Hash32Hasher { size_t operator()(const Hash32& h) const { size_t v; memcpy(&v, h.b, sizeof v); return v; } };
 
+// per-document host bookkeeping of a batch call on a few threads (documents are independent)
+template <class F>
+static void host_parallel_for(u32 n, F f) {
+  unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
+  if (const char* e = getenv("OMP_NUM_THREADS")) { int v = atoi(e); if (v > 0) nt = std::min<unsigned>(nt, (unsigned)v); }
+  if (n < 128 || nt < 2) { for (u32 i = 0; i < n; i++) f(i); return; }
+  std::atomic<u32> next{0};
+  std::vector<std::thread> ts;
+  for (unsigned t = 0; t < nt; t++)
+    ts.emplace_back([&]() {
+      for (;;) {
+        u32 lo = next.fetch_add(32);
+        if (lo >= n) break;
+        u32 hi = std::min(n, lo + 32);
+        for (u32 i = lo; i < hi; i++) f(i);
+      }
+    });
+  for (auto& th : ts) th.join();
+}
+
 // everything the host decides for a merge / apply call (see MergeDev)
 struct MgPlan {
   u32 P = 0;
@@ -1408,23 +1429,33 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   // ---- chunks of every pair: the new ones, then the document's queue -------------------------------
   std::vector<HostChunk> chunks;
   std::vector<u32> pc_base(P + 1, 0);
-  for (u32 p = 0; p < P; p++) {
-    pc_base[p] = (u32)chunks.size();
-    u32 bi = 0;
-    for (auto& bf : items[p].bufs) {
-      size_t before = chunks.size();
-      split_chunks(p, bf.first, bf.second, chunks);
-      for (size_t k = before; k < chunks.size(); k++) chunks[k].buf = bi;
-      if (!items[p].one_call) bi++;
-      if (chunks.size() > before && chunks.back().bad) break;   // nothing behind a bad position is looked at
-    }
-    auto qit = dst->queue.find(items[p].doc);
-    if (qit != dst->queue.end())
-      for (auto& qb : qit->second) {
-        HostChunk hc;
-        hc.pair = p; hc.p = qb.data(); hc.len = qb.size(); hc.from_queue = true;
-        chunks.push_back(std::move(hc));
+  {
+    std::vector<std::vector<HostChunk>> per_pair(P);
+    host_parallel_for(P, [&](u32 p) {
+      std::vector<HostChunk>& out = per_pair[p];
+      u32 bi = 0;
+      for (auto& bf : items[p].bufs) {
+        size_t before = out.size();
+        split_chunks(p, bf.first, bf.second, out);
+        for (size_t k = before; k < out.size(); k++) out[k].buf = bi;
+        if (!items[p].one_call) bi++;
+        if (out.size() > before && out.back().bad) break;   // nothing behind a bad position is looked at
       }
+      auto qit = dst->queue.find(items[p].doc);
+      if (qit != dst->queue.end())
+        for (auto& qb : qit->second) {
+          HostChunk hc;
+          hc.pair = p; hc.p = qb.data(); hc.len = qb.size(); hc.from_queue = true;
+          out.push_back(std::move(hc));
+        }
+    });
+    size_t total = 0;
+    for (u32 p = 0; p < P; p++) total += per_pair[p].size();
+    chunks.reserve(total);
+    for (u32 p = 0; p < P; p++) {
+      pc_base[p] = (u32)chunks.size();
+      for (auto& hc : per_pair[p]) chunks.push_back(std::move(hc));
+    }
   }
   pc_base[P] = (u32)chunks.size();
   for (auto& hc : chunks) if (!hc.p && !hc.bad) hc.p = hc.owned.data();
@@ -1458,7 +1489,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       ap.s_desc[p].chunk_len = (u32)(off - region);
     }
     h_arena.assign(off + 256, 0);
-    for (size_t u = 0; u < staged_of.size(); u++) memcpy(h_arena.data() + doc_off[2 * u], chunks[staged_of[u]].p, chunks[staged_of[u]].len);
+    host_parallel_for((u32)staged_of.size(), [&](u32 u) { memcpy(h_arena.data() + doc_off[2 * (size_t)u], chunks[staged_of[u]].p, chunks[staged_of[u]].len); });
   }
   u32 NCH = (u32)staged_of.size();
   ap.n_chunks = NCH;
@@ -1562,11 +1593,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   };
   for (u32 p = 0; p < P; p++) {
     u32 a = items[p].doc;
-    int mode = items[p].mode;
     d_pair[a] = p; s_pair[p] = p; p_a[p] = a; p_b[p] = p;
-    mapa_base[p] = (u32)map_a.size(); mapb_base[p] = (u32)map_b.size();
-    m_actor_base[p] = (u32)m_actor_off.size(); m_chg_base[p] = (u32)mc_from.size();
-    ap.ix_base[p] = (u32)ap.ix_actor.size();
     memset(&m_desc[p], 0, sizeof(DocDesc)); memset(&m_cnt[p], 0, sizeof(DocCounts));
     // rows of U per pair
     {
@@ -1577,7 +1604,23 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       ap.s_row_base[p] = rb0; ap.s_row_base[p + 1] = rb1;
       ap.s_cnt[p].n_rows = rb1 - rb0;
     }
-    if (dst->status[a]) { p_status[p] = dst->status[a]; results[p] = dst->status[a]; n_failed++; continue; }
+  }
+  struct PairOut {
+    std::vector<u32> map_a, map_b, map_b2a, m_actor_off, m_actor_len, m_actor_rank, mc_from, mc_ndeps, mc_dep_base, m_dep_idx, mc_doc;
+    std::vector<u8> mc_is_dep;
+    std::vector<u32> ix_actor, ix_start, ix_nops, ix_row;
+    u64 arena_need = 0;
+    int failed = 0;
+  };
+  std::vector<PairOut> outs(P);
+  // the decisions of a pair only read shared state: pairs are worked on by a few host threads, results joined below
+  auto decide = [&](u32 p, PairOut& o) {
+    u32 a = items[p].doc;
+    int mode = items[p].mode;
+    auto &map_a = o.map_a, &map_b = o.map_b, &map_b2a = o.map_b2a, &m_actor_off = o.m_actor_off, &m_actor_len = o.m_actor_len, &m_actor_rank = o.m_actor_rank;
+    auto &mc_from = o.mc_from, &mc_ndeps = o.mc_ndeps, &mc_dep_base = o.mc_dep_base, &m_dep_idx = o.m_dep_idx, &mc_doc = o.mc_doc;
+    auto& mc_is_dep = o.mc_is_dep;
+    if (dst->status[a]) { p_status[p] = dst->status[a]; results[p] = dst->status[a]; o.failed = 1; return; }
     // usable new chunks under the call's policy
     std::vector<u32> fresh, oldq;
     i32 first_err = 0;
@@ -1590,15 +1633,15 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     }
     if (first_err) {
       if (mode == APM_STRICT && first_err < AMH_E_TOO_LARGE) first_err = AMH_E_PARSE;   // change::LoadError::Parse covers header and column errors alike
-      if (mode == APM_STRICT || mode == APM_LOAD_ERROR) { p_status[p] = first_err; results[p] = first_err; n_failed++; continue; }
-      if (mode == APM_LOAD_IGNORE) { p_status[p] = -1; continue; }   // nothing behind the first chunk is applied (automerge.rs:690-694)
+      if (mode == APM_STRICT || mode == APM_LOAD_ERROR) { p_status[p] = first_err; results[p] = first_err; o.failed = 1; return; }
+      if (mode == APM_LOAD_IGNORE) { p_status[p] = -1; return; }   // nothing behind the first chunk is applied (automerge.rs:690-694)
     }
     const u8* ca = dst->staged->h_arena.data() + dst->staged->h_doc_off[2 * (size_t)a];
     u32 na = ha.desc[a].n_actors, aba = ha.actor_base[a];
     auto abytes = [&](u32 i) { return Bytes(ca + ha.actor_off[aba + i], ha.actor_len[aba + i]); };
     bool sorted = true;
     for (u32 i = 1; i < na && sorted; i++) sorted = bcmp(abytes(i - 1), abytes(i)) < 0;
-    if (!sorted) { p_status[p] = AMH_E_UNSUPPORTED; results[p] = AMH_E_UNSUPPORTED; n_failed++; continue; }
+    if (!sorted) { p_status[p] = AMH_E_UNSUPPORTED; results[p] = AMH_E_UNSUPPORTED; o.failed = 1; return; }
     u32 nca = ha.cnt[a].n_chg, cba = ha.chg_base[a];
     std::unordered_map<Hash32, u32, Hash32Hasher> history;
     history.reserve((size_t)nca * 2 + fresh.size() * 2 + 1);
@@ -1635,10 +1678,10 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       if (fi + 1 == fresh.size() || chunks[fresh[fi + 1]].buf != chunks[k].buf) drain();
     }
     if (fresh.empty() && !dup) drain();
-    if (dup) { p_status[p] = AMH_E_DUPLICATE_SEQ; results[p] = AMH_E_DUPLICATE_SEQ; n_failed++; continue; }
-    if (mode == APM_LOAD_ERROR && !items[p].first_was_doc && !queue.empty()) { p_status[p] = AMH_E_MISSING_DEPS; results[p] = AMH_E_MISSING_DEPS; n_failed++; continue; }
+    if (dup) { p_status[p] = AMH_E_DUPLICATE_SEQ; results[p] = AMH_E_DUPLICATE_SEQ; o.failed = 1; return; }
+    if (mode == APM_LOAD_ERROR && !items[p].first_was_doc && !queue.empty()) { p_status[p] = AMH_E_MISSING_DEPS; results[p] = AMH_E_MISSING_DEPS; o.failed = 1; return; }
     new_queue[p] = queue; queue_dirty[p] = 1;
-    if (order.empty()) { p_status[p] = -1; continue; }
+    if (order.empty()) { p_status[p] = -1; return; }
     // actor table of S for this pair: the actors of the applied changes, bytewise sorted
     std::vector<Bytes> sact, tmp;
     for (u32 k : order) { chunk_actors(chunks[k].staged, tmp); sact.insert(sact.end(), tmp.begin(), tmp.end()); }
@@ -1689,15 +1732,42 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       ix.push_back(Ix{s_index(tmp[0]), (u32)hdr[u].start_op, u_cnt[u].n_rows, u_row_base[u]});
     }
     std::sort(ix.begin(), ix.end(), [](const Ix& x, const Ix& y) { return x.actor != y.actor ? x.actor < y.actor : x.start < y.start; });
-    for (auto& e : ix) { ap.ix_actor.push_back(e.actor); ap.ix_start.push_back(e.start); ap.ix_nops.push_back(e.nops); ap.ix_row.push_back(e.row); }
+    for (auto& e : ix) { o.ix_actor.push_back(e.actor); o.ix_start.push_back(e.start); o.ix_nops.push_back(e.nops); o.ix_row.push_back(e.row); }
     for (size_t c = first_c; c < mc_from.size(); c++)
       for (u32 k = 0; k < mc_ndeps[c]; k++) mc_is_dep[first_c + m_dep_idx[mc_dep_base[c] + k]] = 1;
     m_cnt[p].n_chg = nca + (u32)order.size();
-    m_desc[p].chunk_off = arena_len;
     m_desc[p].chunk_len = lenApad + lenB;
-    m_desc[p].n_actors = (u32)(m_actor_off.size() - m_actor_base[p]);
+    m_desc[p].n_actors = (u32)m_actor_off.size();
     m_desc[p].ocol[OC_MARK_NAME].len = mark_len;
-    arena_len += (lenApad + lenB + 15u) & ~15ull;
+    o.arena_need = (lenApad + lenB + 15u) & ~15ull;
+    };
+  host_parallel_for(P, [&](u32 p) { decide(p, outs[p]); });
+  for (u32 p = 0; p < P; p++) {
+    PairOut& o = outs[p];
+    mapa_base[p] = (u32)map_a.size(); mapb_base[p] = (u32)map_b.size();
+    m_actor_base[p] = (u32)m_actor_off.size(); m_chg_base[p] = (u32)mc_from.size();
+    ap.ix_base[p] = (u32)ap.ix_actor.size();
+    n_failed += o.failed;
+    u32 dep0 = (u32)m_dep_idx.size();
+    for (auto& v : o.mc_dep_base) v += dep0;
+    map_a.insert(map_a.end(), o.map_a.begin(), o.map_a.end());
+    map_b.insert(map_b.end(), o.map_b.begin(), o.map_b.end());
+    map_b2a.insert(map_b2a.end(), o.map_b2a.begin(), o.map_b2a.end());
+    m_actor_off.insert(m_actor_off.end(), o.m_actor_off.begin(), o.m_actor_off.end());
+    m_actor_len.insert(m_actor_len.end(), o.m_actor_len.begin(), o.m_actor_len.end());
+    m_actor_rank.insert(m_actor_rank.end(), o.m_actor_rank.begin(), o.m_actor_rank.end());
+    mc_from.insert(mc_from.end(), o.mc_from.begin(), o.mc_from.end());
+    mc_ndeps.insert(mc_ndeps.end(), o.mc_ndeps.begin(), o.mc_ndeps.end());
+    mc_dep_base.insert(mc_dep_base.end(), o.mc_dep_base.begin(), o.mc_dep_base.end());
+    m_dep_idx.insert(m_dep_idx.end(), o.m_dep_idx.begin(), o.m_dep_idx.end());
+    mc_doc.insert(mc_doc.end(), o.mc_doc.begin(), o.mc_doc.end());
+    mc_is_dep.insert(mc_is_dep.end(), o.mc_is_dep.begin(), o.mc_is_dep.end());
+    ap.ix_actor.insert(ap.ix_actor.end(), o.ix_actor.begin(), o.ix_actor.end());
+    ap.ix_start.insert(ap.ix_start.end(), o.ix_start.begin(), o.ix_start.end());
+    ap.ix_nops.insert(ap.ix_nops.end(), o.ix_nops.begin(), o.ix_nops.end());
+    ap.ix_row.insert(ap.ix_row.end(), o.ix_row.begin(), o.ix_row.end());
+    if (o.arena_need) { m_desc[p].chunk_off = arena_len; arena_len += o.arena_need; }
+    o = PairOut();
   }
   for (u32 u = 0; u < NCH; u++) {
     ap.amap_base[u] = (u32)ap.amap.size();
@@ -1832,9 +1902,16 @@ extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* con
     u32 a = dst_idx[p];
     if (a >= dst->B.n_docs || seen_doc[a]) { set_error(ctx, "amh_merge_many: document index out of range or used twice"); return AMH_ERR_INVALID_ARG; }
     seen_doc[a] = 1;
+    for (size_t s = 0; s < n_srcs; s++) {
+      u32 b = src_idx[s * n_pairs + p];
+      if (b != AMH_NULL32 && b >= srcs[s]->B.n_docs) { set_error(ctx, "amh_merge_many: source document index out of range"); return AMH_ERR_INVALID_ARG; }
+    }
+  }
+  host_parallel_for(P, [&](u32 p) {
+    u32 a = dst_idx[p];
     items[p].doc = a;
     items[p].mode = APM_STRICT;
-    if (dst->status[a]) continue;   // apply_core reports it
+    if (dst->status[a]) return;   // apply_core reports it
     u32 nca = ha.cnt[a].n_chg, cba = ha.chg_base[a];
     std::unordered_map<Hash32, u32, Hash32Hasher> known;
     known.reserve((size_t)nca * 2 + 16);
@@ -1843,7 +1920,6 @@ extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* con
       u32 b = src_idx[s * n_pairs + p];
       if (b == AMH_NULL32) continue;
       const amh_batch* sb = srcs[s];
-      if (b >= sb->B.n_docs) { set_error(ctx, "amh_merge_many: source document index out of range"); return AMH_ERR_INVALID_ARG; }
       if (sb->status[b]) { pre_fail[p] = sb->status[b]; break; }
       const HostView& hb = sb->hv;
       u32 ncb = hb.cnt[b].n_chg, cbb = hb.chg_base[b];
@@ -1877,7 +1953,7 @@ extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* con
     }
     if (pre_fail[p]) owned[p].clear();
     for (auto& buf : owned[p]) items[p].bufs.push_back({buf.data(), buf.size()});
-  }
+    });
   pt.mark("added changes (host)");
   std::vector<i32> results;
   int rc = apply_core(ctx, dst, items, results, "amh_merge_many");

@@ -234,3 +234,14 @@ def test_load_with_change_chunks_and_incremental(emu):
 def test_edit_trace(emu, golden_dir):
     import edit_trace_case as et
     et.check_engine(emu, golden_dir)
+
+
+def test_many_documents_take_the_threaded_host_path(emu):
+    """the host bookkeeping of apply / merge_many runs on several threads from 128 documents up"""
+    from merge_cases import check_merge_many
+    n = 150
+    blob, offs = emu.gen_map_docs(77, n, 2, 2, 6, 8, 2)
+    docs = [bytes(blob[offs[i]:offs[i + 1]]) for i in range(n)]
+    ac.check_apply_tail(emu, docs, lambda k: k // 2)
+    blob, offs = emu.gen_text_docs(0x7E57, n, 3, 10, 30, 10, 2)
+    check_merge_many(emu, [[bytes(blob[offs[i * 3 + r]:offs[i * 3 + r + 1]]) for i in range(n)] for r in range(3)])
