@@ -110,8 +110,20 @@ struct amh_staged {
   std::vector<uint8_t> h_arena;   // normalised input bytes (kept for string / actor access on the host)
   std::vector<u64> h_doc_off;
   DevAlloc d_arena, d_doc_off;
+  size_t arena_bytes = 0;         // bytes of the arena (host and device copies alike)
+  bool host_ok = true;            // h_arena is filled (arenas assembled on the device fetch it on first use)
+  bool single_chunk = false;      // every input is exactly one document chunk (arenas assembled by merge / apply)
   int refs = 1;
 };
+// host copy of an arena that was assembled on the device (merge / apply results): fetched when an accessor needs bytes
+static bool ensure_host_arena(const amh_staged* sc) {
+  amh_staged* s = const_cast<amh_staged*>(sc);
+  if (s->host_ok) return true;
+  s->h_arena.resize(s->arena_bytes);
+  if (!rt_d2h(s->h_arena.data(), s->d_arena.p, s->arena_bytes, s->ctx->stream) || !rt_sync(s->ctx->stream)) return false;
+  s->host_ok = true;
+  return true;
+}
 static void staged_unref(amh_staged* s) {
   if (!s) return;
   if (--s->refs > 0) return;
@@ -258,6 +270,7 @@ extern "C" amh_staged* amh_stage_batch(amh_ctx* ctx, const uint8_t* const* docs,
     se[2 * i] = st->h_doc_off[i];
     se[2 * i + 1] = st->h_doc_off[i] + (changed[i] ? rewritten[i].size() : lens[i]);
   }
+  st->arena_bytes = st->h_arena.size();
   st->d_arena.p = ctx->pool.alloc(st->h_arena.size(), &st->d_arena.cap);
   st->d_doc_off.p = ctx->pool.alloc(se.size() * sizeof(u64), &st->d_doc_off.cap);
   if (!st->d_arena.p || !st->d_doc_off.p) { set_error(ctx, "device out of memory while staging"); staged_unref(st); return nullptr; }
@@ -609,6 +622,7 @@ extern "C" int amh_changes(const amh_batch* b, uint32_t doc, amh_change_view* ou
   size_t cap = *n;
   *n = nc;
   if (!out || cap < nc) return cap == 0 ? AMH_SUCCESS : AMH_ERR_INVALID_ARG;
+  if (!ensure_host_arena(b->staged)) return AMH_ERR_DEVICE;
   const uint8_t* chunk = b->staged->h_arena.data() + b->staged->h_doc_off[2 * (size_t)doc];
   u32 ab = hv.actor_base[doc];
   for (u32 i = 0; i < nc; i++) {
@@ -769,6 +783,7 @@ extern "C" int amh_hydrate_json(const amh_batch* b, uint32_t doc, amh_bytes_out*
             fetch(b, R.visible, B.r_visible + rb, R.n) && fetch(b, R.vmeta, B.r_vmeta + rb, R.n) &&
             fetch(b, R.inc_sum, B.r_inc_sum + rb, R.n);
   if (!ok) return AMH_ERR_DEVICE;
+  if (!ensure_host_arena(b->staged)) return AMH_ERR_DEVICE;
   R.chunk = b->staged->h_arena.data() + b->staged->h_doc_off[2 * (size_t)doc];
   R.D = &hv.desc[doc];
   u32 ab = hv.actor_base[doc];
@@ -1145,36 +1160,63 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
   launch(ctx, AK_SAVE_STORE, M, P * 25);
   launch(ctx, AK_SAVE_FINISH, M, P);
-  std::vector<u8> merged((size_t)sv_total);
+  pt.mark("exec: save kernels", &ctx->stream);
   std::vector<u32> sv_off(P + 1), sv_body(P);
   std::vector<i32> sv_st(P);
-  if (!rt_d2h(merged.data(), M.sv_out, sv_total, ctx->stream) || !rt_d2h(sv_off.data(), M.sv_off, (P + 1) * 4, ctx->stream) ||
-      !rt_d2h(sv_body.data(), M.sv_body_len, P * 4, ctx->stream) || !rt_d2h(sv_st.data(), M.sv_status, P * 4, ctx->stream))
+  if (!rt_d2h(sv_off.data(), M.sv_off, (P + 1) * 4, ctx->stream) || !rt_d2h(sv_body.data(), M.sv_body_len, P * 4, ctx->stream) ||
+      !rt_d2h(sv_st.data(), M.sv_status, P * 4, ctx->stream))
     return failm("D2H copy failed");
   collect_profile(ctx);
-  pt.mark("exec: save kernels + D2H", &ctx->stream);
-  // ---- reload: every document of dst, merged ones from their new bytes ---------------------------
+  pt.mark("exec: save D2H", &ctx->stream);
+  // ---- reload: every document of dst, merged ones from their new bytes.  The arena of the new batch is put
+  //      together in device memory (merged chunks from the save buffer, the others from the old arena): the
+  //      bytes do not visit the host; its host copy is fetched only when an accessor asks for bytes. ---------
   u32 nd = DB.n_docs;
-  std::vector<const uint8_t*> ptrs(nd);
-  std::vector<size_t> lens(nd);
+  amh_staged* old_st = dst->staged;
   amh_batch* nb = nullptr;
   int rc = AMH_SUCCESS;
   for (int attempt = 0; attempt < 2; attempt++) {
+  std::vector<u64> seg_src(nd), seg_dst(nd), se(2 * (size_t)nd + 2, 0);
+  std::vector<u32> seg_len(nd);
+  u64 off = 0;
   for (u32 d = 0; d < nd; d++) {
-    ptrs[d] = dst->staged->h_arena.data() + dst->staged->h_doc_off[2 * (size_t)d];
-    lens[d] = first_doc_chunk_len(ptrs[d], dst->staged->h_doc_off[2 * (size_t)d + 1] - dst->staged->h_doc_off[2 * (size_t)d]);
+    u64 o0 = old_st->h_doc_off[2 * (size_t)d], o1 = old_st->h_doc_off[2 * (size_t)d + 1];
+    size_t len = (size_t)(o1 - o0);
+    if (!old_st->single_chunk) len = first_doc_chunk_len(old_st->h_arena.data() + o0, len);
+    seg_src[d] = (u64)(uintptr_t)((const u8*)old_st->d_arena.p + o0);
     u32 p = d_pair[d];
-    if (p == AMH_NULL32 || p_status[p] != 0) continue;
-    if (sv_st[p] != 0) { p_status[p] = sv_st[p]; continue; }
-    u32 bl = sv_body[p];
-    ptrs[d] = merged.data() + sv_off[p];
-    lens[d] = 9 + bl + (bl < 0x80 ? 1 : bl < 0x4000 ? 2 : bl < 0x200000 ? 3 : bl < 0x10000000 ? 4 : 5);
+    if (p != AMH_NULL32 && p_status[p] == 0) {
+      if (sv_st[p] != 0) p_status[p] = sv_st[p];
+      else {
+        u32 bl = sv_body[p];
+        seg_src[d] = (u64)(uintptr_t)(M.sv_out + sv_off[p]);
+        len = 9 + bl + (bl < 0x80 ? 1 : bl < 0x4000 ? 2 : bl < 0x200000 ? 3 : bl < 0x10000000 ? 4 : 5);
+      }
+    }
+    seg_len[d] = (u32)len;
+    seg_dst[d] = off;
+    se[2 * (size_t)d] = off; se[2 * (size_t)d + 1] = off + len;
+    off = (off + len + 15) & ~(u64)15;
   }
   amh_load_opts lo;
   lo.verify_heads = 1; lo.on_partial_load = 0;
   {
-    amh_staged* st = amh_stage_batch(ctx, ptrs.data(), lens.data(), nd);
-    if (!st) return AMH_ERR_DEVICE;
+    auto* st = new amh_staged();
+    st->ctx = ctx; st->n_docs = nd; st->host_ok = false; st->single_chunk = true;
+    st->arena_bytes = (size_t)off + 256;
+    st->h_doc_off = se;
+    st->d_arena.p = ctx->pool.alloc(st->arena_bytes, &st->d_arena.cap);
+    st->d_doc_off.p = ctx->pool.alloc(se.size() * sizeof(u64), &st->d_doc_off.cap);
+    u64* d_src = balloc<u64>(mb, nd + 1, &ok); u64* d_dst = balloc<u64>(mb, nd + 1, &ok); u32* d_len = balloc<u32>(mb, nd + 1, &ok);
+    if (!st->d_arena.p || !st->d_doc_off.p || !ok) { staged_unref(st); set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+    // padding between and behind the chunks must read as zero only where the windowed decoders look past a column:
+    // clearing the tail is enough, the gaps are below 16 bytes and belong to no column
+    rt_memset((u8*)st->d_arena.p + off, 0, 256, ctx->stream);
+    bool cok = rt_h2d(st->d_doc_off.p, se.data(), se.size() * sizeof(u64), ctx->stream) && rt_h2d(d_src, seg_src.data(), nd * sizeof(u64), ctx->stream) &&
+               rt_h2d(d_dst, seg_dst.data(), nd * sizeof(u64), ctx->stream) && rt_h2d(d_len, seg_len.data(), nd * sizeof(u32), ctx->stream);
+    if (!cok) { staged_unref(st); return failm("H2D copy failed"); }
+    amh_copy_segments(d_src, d_len, d_dst, (u8*)st->d_arena.p, nd, (void*)ctx->stream);
+    pt.mark("exec: reload arena (device)", &ctx->stream);
     nb = load_staged_impl(ctx, st, &lo, false);
     staged_unref(st);
   }
@@ -1198,7 +1240,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   nb = nullptr;
   }
   for (u32 p = 0; p < P; p++) if (p_status[p] > 0) rc = AMH_ERR_DOC_FAILED;
-  pt.mark("exec: reload", &ctx->stream);
+  pt.mark("exec: reload pipeline", &ctx->stream);
   // documents of dst that failed earlier keep their status (a reload of their first chunk alone may succeed)
   bool st_dirty = false;
   for (u32 d = 0; d < nd; d++)
@@ -1214,7 +1256,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
 extern "C" int amh_merge_batch(amh_ctx* ctx, amh_batch* dst, const amh_batch* src, const uint32_t* dst_idx, const uint32_t* src_idx, size_t n_pairs) {
   if (!ctx || !dst || !src || dst == src || (n_pairs && (!dst_idx || !src_idx)) || n_pairs >= 0x7FFFFFFFull) { set_error(ctx, "amh_merge_batch: invalid argument"); return AMH_ERR_INVALID_ARG; }
   if (n_pairs == 0) return AMH_SUCCESS;
-  if (!ensure_chg(dst) || !ensure_chg(src)) { set_error(ctx, "amh_merge_batch: D2H copy failed"); return AMH_ERR_DEVICE; }
+  if (!ensure_chg(dst) || !ensure_chg(src) || !ensure_host_arena(dst->staged) || !ensure_host_arena(src->staged)) { set_error(ctx, "amh_merge_batch: D2H copy failed"); return AMH_ERR_DEVICE; }
   const HostView &ha = dst->hv, &hb = src->hv;
   const BatchDev &DB = dst->B, &SB = src->B;
   u32 P = (u32)n_pairs;
@@ -1423,7 +1465,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   results.assign(P, 0);
   if (P == 0) return AMH_SUCCESS;
   PhaseTimer pt(who);
-  if (!ensure_chg(dst)) { set_error(ctx, std::string(who) + ": D2H copy failed"); return AMH_ERR_DEVICE; }
+  if (!ensure_chg(dst) || !ensure_host_arena(dst->staged)) { set_error(ctx, std::string(who) + ": D2H copy failed"); return AMH_ERR_DEVICE; }
   const HostView& ha = dst->hv;
   const BatchDev& DB = dst->B;
   // ---- chunks of every pair: the new ones, then the document's queue -------------------------------

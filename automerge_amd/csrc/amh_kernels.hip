@@ -866,3 +866,16 @@ void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream) {
   }
 #undef M
 }
+
+// one block per segment, 16-byte copies (segments are 16-byte aligned and padded on both sides)
+__global__ void __launch_bounds__(AMH_BLOCK) g_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst) {
+  u32 i = blockIdx.x;
+  const uint4* s = (const uint4*)(uintptr_t)src[i];
+  uint4* d = (uint4*)(dst + dst_off[i]);
+  u32 n = (len[i] + 15) / 16;
+  for (u32 k = threadIdx.x; k < n; k += AMH_BLOCK) d[k] = s[k];
+}
+void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void* stream) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(g_copy_segments, dim3(n), dim3(AMH_BLOCK), 0, (hipStream_t)stream, src, len, dst_off, dst);
+}

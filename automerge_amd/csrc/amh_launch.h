@@ -32,3 +32,6 @@ enum MgKernel {
   MK_AP_SUCC_FILL_U, MK_AP_SUCC_SORT_U, MK_AP_SUCC_FILL_D, MK_NUM
 };
 void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream);
+// copy n byte segments inside device memory: segment i = len[i] bytes from address src[i] to dst + dst_off[i]
+// (16-byte aligned on both sides).  The three tables live in device memory.
+void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void* stream);
