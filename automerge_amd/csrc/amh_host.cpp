@@ -423,7 +423,9 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   launch(ctx, AK_PRED_SORT, B, T);
   launch(ctx, AK_ACTOR_MARK, B, T);
   launch(ctx, AK_ACTOR_RANK, B, B.tot_chg);
-  for (int k = 0; k < 12; k++) B.cv[k] = balloc<u32>(b, (size_t)tot_ops + 1, &ok);
+  for (int k = 0; k < 12; k++) B.cv[k] = nullptr;   // one interleaved array per column group: obj (2 fields), key (4), misc (2), value (4)
+  B.cv[0] = balloc<u32>(b, 2 * ((size_t)tot_ops + 1), &ok); B.cv[2] = balloc<u32>(b, 4 * ((size_t)tot_ops + 1), &ok);
+  B.cv[6] = balloc<u32>(b, 2 * ((size_t)tot_ops + 1), &ok); B.cv[8] = balloc<u32>(b, 4 * ((size_t)tot_ops + 1), &ok);
   if (!ok) return fail("device out of memory");
   rt_memset(B.c_wide, 0, NC * 4, ctx->stream);
   launch(ctx, AK_CHANGE_VIEW, B, tot_ops);
@@ -849,10 +851,8 @@ extern "C" int amh_debug_array(const amh_batch* b, const char* name, void* out, 
     {"s_target", B.s_target, NS * 4}, {"t_pred_cnt", B.t_pred_cnt, T * 4}, {"t_pred_base", B.t_pred_base, (T + 1) * 4},
     {"t_chg", B.t_chg, T * 4}, {"j_pred_base", B.j_pred_base, ((size_t)B.tot_ops + 1) * 4}, {"pred_ids", B.pred_ids, NS * 8}, {"ops_sorted", B.ops_sorted, (size_t)B.tot_ops * 4},
     {"out_arena", B.out_arena, (size_t)b->tot_out},
-    {"cv0", B.cv[0], (size_t)B.tot_ops * 4}, {"cv1", B.cv[1], (size_t)B.tot_ops * 4}, {"cv2", B.cv[2], (size_t)B.tot_ops * 4},
-    {"cv3", B.cv[3], (size_t)B.tot_ops * 4}, {"cv4", B.cv[4], (size_t)B.tot_ops * 4}, {"cv5", B.cv[5], (size_t)B.tot_ops * 4},
-    {"cv6", B.cv[6], (size_t)B.tot_ops * 4}, {"cv7", B.cv[7], (size_t)B.tot_ops * 4}, {"cv8", B.cv[8], (size_t)B.tot_ops * 4},
-    {"cv9", B.cv[9], (size_t)B.tot_ops * 4}, {"cv10", B.cv[10], (size_t)B.tot_ops * 4}, {"cv11", B.cv[11], (size_t)B.tot_ops * 4},
+    {"cv_obj", B.cv[0], (size_t)B.tot_ops * 8}, {"cv_key", B.cv[2], (size_t)B.tot_ops * 16}, {"cv_misc", B.cv[6], (size_t)B.tot_ops * 8},
+    {"cv_val", B.cv[8], (size_t)B.tot_ops * 16},
   };
   for (const Ent& e : tab) {
     if (strcmp(e.name, name) != 0) continue;

@@ -418,8 +418,8 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
         u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
-        S.t0[o] = B.cv[0][j];
-        S.t1[o] = B.cv[1][j];
+        uint2 g = ((const uint2*)B.cv[0])[j];
+        S.t0[o] = g.x; S.t1[o] = g.y;
       });
       __syncthreads();
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
@@ -443,10 +443,8 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
         u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
-        S.t0[o] = B.cv[2][j];
-        S.t1[o] = B.cv[3][j];
-        S.t2[o] = B.cv[4][j];
-        S.t3[o] = B.cv[5][j];
+        uint4 g = ((const uint4*)B.cv[2])[j];
+        S.t0[o] = g.x; S.t1[o] = g.y; S.t2[o] = g.z; S.t3[o] = g.w;
       });
       __syncthreads();
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
@@ -472,8 +470,8 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
         u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
-        S.t0[o] = B.cv[6][j];
-        S.t1[o] = B.cv[7][j];
+        uint2 g = ((const uint2*)B.cv[6])[j];
+        S.t0[o] = g.x; S.t1[o] = g.y;
       });
       __syncthreads();
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
@@ -501,10 +499,8 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
         u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
-        S.t0[o] = B.cv[8][j];
-        S.t1[o] = B.cv[9][j];
-        S.t2[o] = B.cv[10][j];
-        S.t3[o] = B.cv[11][j];
+        uint4 g = ((const uint4*)B.cv[8])[j];
+        S.t0[o] = g.x; S.t1[o] = g.y; S.t2[o] = g.z; S.t3[o] = g.w;
       });
       __syncthreads();
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;

@@ -153,7 +153,9 @@ struct BatchDev {
   u64* pred_ids;                 // [tot_succ] (ctr << 32 | actor)
   u32* ops_sorted;               // [tot_ops] ops grouped by change in id order
   u32* j_pred_base;              // [tot_ops + 1] base of each slot's pred list in pred_ids (change order)
-  // change view: per-op fields in change (slot) order, gathered once for the re-encode kernels [tot_ops] each:
+  // change view: per-op fields in change (slot) order, gathered once for the re-encode kernels.  The fields of a
+  // column group are interleaved per op: cv[0] = {0, 1} x tot_ops, cv[2] = {2..5}, cv[6] = {6, 7}, cv[8] = {8..11}
+  // (the other entries of cv are unused):
   // 0 obj actor (change-local, NULL32 = root)  1 obj ctr  2 key actor (NULL32 unless elem)  3 key ctr (NULL32 = prop)
   // 4 key str off  5 key str len (NULL32 unless prop)  6 insert | expand << 1 | action << 8  7 pred count
   // 8 value meta lo  9 value meta hi | kind << 8  10, 11 raw offset + length, or the i64 of a re-encoded increment
