@@ -1409,6 +1409,7 @@ struct HostChunk {
   std::vector<u8> owned;
   i32 bad = 0;                 // host-level failure of this position of the stream (nothing staged)
   bool from_queue = false;
+  bool is_doc = false;         // a document chunk: replaced by the changes it holds before staging
   u32 buf = 0;                 // which of the item's buffers it came from (one buffer = one apply_changes call)
   u32 staged = AMH_NULL32;     // index in U
 };
@@ -1442,10 +1443,11 @@ static void split_chunks(u32 pair, const u8* p, size_t len, std::vector<HostChun
       return;
     }
     size_t total = pos + (size_t)dlen;
-    if (q[8] == 0) {   // a document chunk inside a change stream (load.rs:84-100): not on this path yet
-      hc.bad = AMH_E_UNSUPPORTED;
+    if (q[8] == 0) {   // a document chunk inside a change stream stands for its changes (load.rs:84-100): expanded by apply_core
+      hc.p = q; hc.len = total; hc.is_doc = true;
       out.push_back(std::move(hc));
-      return;
+      off += total;
+      continue;
     }
     if (q[8] == 2) {
       if (!amh_ingest_inflate_change(q, total, hc.owned)) { hc.bad = AMH_E_PARSE; out.push_back(std::move(hc)); return; }
@@ -1497,6 +1499,59 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     for (u32 p = 0; p < P; p++) {
       pc_base[p] = (u32)chunks.size();
       for (auto& hc : per_pair[p]) chunks.push_back(std::move(hc));
+    }
+  }
+  // document chunks inside the streams (load_incremental of a whole saved document): loaded as a batch of their own
+  // without the heads check (load.rs:90-93), each then stands for its re-derived changes
+  {
+    std::vector<u32> docs_at;
+    for (u32 k = 0; k < chunks.size(); k++) if (chunks[k].is_doc) docs_at.push_back(k);
+    if (!docs_at.empty()) {
+      std::vector<const uint8_t*> dp;
+      std::vector<size_t> dl;
+      for (u32 k : docs_at) { dp.push_back(chunks[k].p); dl.push_back(chunks[k].len); }
+      amh_load_opts lo;
+      lo.verify_heads = 0; lo.on_partial_load = 0;
+      amh_staged* est = amh_stage_batch(ctx, dp.data(), dl.data(), dp.size());
+      if (!est) return AMH_ERR_DEVICE;
+      amh_batch* eb = load_staged_impl(ctx, est, &lo, false);
+      staged_unref(est);
+      if (!eb) return AMH_ERR_DEVICE;
+      std::unique_ptr<amh_batch, void (*)(amh_batch*)> ebh(eb, amh_batch_free);
+      if (!ensure_chg(eb)) return AMH_ERR_DEVICE;
+      HostView& ev = eb->hv;
+      if (!ev.out_ok) { if (!fetch(eb, ev.out_arena, eb->B.out_arena, (size_t)eb->tot_out) || !rt_sync(ctx->stream)) return AMH_ERR_DEVICE; ev.out_ok = true; }
+      std::vector<HostChunk> expanded;
+      expanded.reserve(chunks.size());
+      u32 di = 0;
+      for (u32 k = 0; k < chunks.size(); k++) {
+        HostChunk& hc = chunks[k];
+        if (!hc.is_doc) { expanded.push_back(std::move(hc)); continue; }
+        u32 e = di++;
+        if (eb->status[e]) {   // the stream stops here with this document's error (load.rs:94-99)
+          HostChunk bad;
+          bad.pair = hc.pair; bad.buf = hc.buf; bad.bad = eb->status[e] == AMH_E_BAD_CHECKSUM || eb->status[e] == AMH_E_PARSE ? eb->status[e] : AMH_E_INVALID_CHANGE_COLUMNS;
+          expanded.push_back(std::move(bad));
+          // everything of the same buffer behind it is dropped, as split_chunks does at a bad position
+          u32 k2 = k + 1;
+          while (k2 < chunks.size() && chunks[k2].pair == hc.pair && !chunks[k2].from_queue) k2++;
+          k = k2 - 1;
+          continue;
+        }
+        u32 cb = ev.chg_base[e], nc = ev.cnt[e].n_chg;
+        for (u32 i = 0; i < nc; i++) {
+          HostChunk c;
+          c.pair = hc.pair; c.buf = hc.buf;
+          const u8* q = ev.out_arena.data() + ev.c_out_off[cb + i];
+          c.owned.assign(q, q + ev.c_out_len[cb + i]);
+          c.len = c.owned.size();
+          expanded.push_back(std::move(c));
+        }
+      }
+      chunks.swap(expanded);
+      std::fill(pc_base.begin(), pc_base.end(), 0);
+      for (auto& hc : chunks) pc_base[hc.pair + 1]++;
+      for (u32 p = 0; p < P; p++) pc_base[p + 1] += pc_base[p];
     }
   }
   pc_base[P] = (u32)chunks.size();

@@ -181,3 +181,31 @@ def check_incremental_and_errors(engine, data):
         b3.apply_changes(0, pre + [comp])
         ref3.apply_changes(pre + [big[0]])
         check_doc(b3, 0, ref3)
+
+
+def check_incremental_with_documents(engine, replicas):
+    """load_incremental accepts whole saved documents too (automerge.rs:723-727; a document chunk in a change stream
+    stands for its changes, storage/load.rs:84-100): replica 0 takes in the saved form of every other replica, and a
+    stream that mixes a document chunk with change chunks"""
+    base = bytes(replicas[0])
+    b = engine.load_batch([base, base])
+    ref = o.Doc.load(base)
+    for r in replicas[1:]:
+        assert b.apply_batch([(0, bytes(r))], incremental=True) == [0]
+        ref.load_incremental(bytes(r))
+        check_doc(b, 0, ref)
+    assert b.save_all(deflate=False)[0] == ref.save(deflate=False)
+    ref2 = o.Doc.load(base)
+    extra = changes_of(replicas[2])[-1]
+    stream = bytes(replicas[1]) + extra + bytes(replicas[2])
+    assert b.apply_batch([(1, stream)], incremental=True) == [0]
+    ref2.load_incremental(stream)
+    check_doc(b, 1, ref2)
+    # a damaged document chunk stops the stream there
+    bad = bytearray(replicas[1]); bad[len(bad) // 2] ^= 0x41
+    stream = extra + bytes(bad) + bytes(replicas[2])
+    b3 = engine.load_batch([base])
+    ref3 = o.Doc.load(base)
+    assert b3.apply_batch([(0, stream)], incremental=True) == [0]
+    ref3.load_incremental(stream)
+    check_doc(b3, 0, ref3)

@@ -218,6 +218,7 @@ def test_apply_changes_text_replicas(emu):
     ac.check_apply_tail(emu, docs[:4], lambda n: 1)
     ac.check_apply_replicas(emu, docs, 4)
     ac.check_queue_across_calls(emu, docs[0], docs[1])
+    ac.check_incremental_with_documents(emu, docs[4:8])
 
 
 def test_load_with_change_chunks_and_incremental(emu):

@@ -250,6 +250,7 @@ def test_apply_changes_text_replicas(engine):
     ac.check_apply_tail(engine, docs[:4], lambda n: 1)
     ac.check_apply_replicas(engine, docs, 4)
     ac.check_queue_across_calls(engine, docs[0], docs[1])
+    ac.check_incremental_with_documents(engine, docs[4:8])
 
 
 def test_load_with_change_chunks_and_incremental(engine):
