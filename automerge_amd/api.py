@@ -40,7 +40,7 @@ EXPORTS = [
     "amh_load_batch", "amh_batch_free", "amh_bytes_free", "amh_doc_status", "amh_batch_get_stats", "amh_heads",
     "amh_changes", "amh_hydrate_json", "amh_doc_max_op", "amh_merge_batch", "amh_apply_changes", "amh_save_batch",
     "amh_sync_summaries", "amh_ctx_set_profiling", "amh_ctx_num_kernels", "amh_ctx_kernel_name", "amh_ctx_kernel_time",
-    "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free", "amh_apply_batch", "amh_doc_queue_len", "amh_merge_many",
+    "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free", "amh_apply_batch", "amh_doc_queue_len", "amh_merge_many", "amh_save_after",
 ]
 
 DOC_ERRORS = {
@@ -93,6 +93,7 @@ def bind(lib):
     lib.amh_apply_batch.argtypes = [vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int,
                                     C.POINTER(C.c_int)]
     lib.amh_doc_queue_len.argtypes = [vp, C.c_uint32, C.POINTER(C.c_size_t)]
+    lib.amh_save_after.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t, C.POINTER(BytesOut)]
     lib.amh_merge_many.argtypes = [vp, vp, C.POINTER(vp), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]
     return lib
 
@@ -261,6 +262,17 @@ class Batch:
         if rc not in (0, -7):
             raise EngineError(f"amh_apply_batch failed: {rc} {self.engine._err()}")
         return list(res)
+
+    def save_after(self, i, heads):
+        """== self[i].save_after(heads) (automerge.rs:993): the changes `heads` has not seen, as change chunks."""
+        self.check(i)
+        o = BytesOut()
+        rc = self.engine.lib.amh_save_after(self.h, i, b"".join(heads), len(heads), C.byref(o))
+        if rc != 0:
+            raise EngineError(f"amh_save_after failed: {rc}")
+        raw = C.string_at(o.data, o.len) if o.len else b""
+        self.engine.lib.amh_bytes_free(C.byref(o))
+        return raw
 
     def queue_len(self, i):
         n = C.c_size_t()

@@ -2059,6 +2059,44 @@ extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* con
   if (rc == AMH_ERR_DOC_FAILED) set_error(ctx, "amh_merge_many: some documents were left unmerged (failed documents, duplicate seq numbers or unsupported shapes)");
   return rc;
 }
+// == Automerge::save_after (automerge.rs:993-1000) = get_changes(heads) (:1306, get_changes_clock :1022-1047) as raw
+// change chunks back to back.  O(changes) graph walk over the batch's host mirrors; the chunks are the re-derived ones.
+extern "C" int amh_save_after(const amh_batch* b, uint32_t doc, const uint8_t* heads32, size_t n_heads, amh_bytes_out* out) {
+  if (!b || !out || doc >= b->B.n_docs || (n_heads && !heads32)) return AMH_ERR_INVALID_ARG;
+  out->data = nullptr; out->len = 0;
+  if (b->status[doc]) return AMH_ERR_DOC_FAILED;
+  if (!ensure_chg(b)) return AMH_ERR_DEVICE;
+  HostView& hv = b->hv;
+  if (!hv.out_ok) {
+    if (!fetch(b, hv.out_arena, b->B.out_arena, (size_t)b->tot_out) || !rt_sync(b->ctx->stream)) return AMH_ERR_DEVICE;
+    hv.out_ok = true;
+  }
+  u32 cb = hv.chg_base[doc], nc = hv.cnt[doc].n_chg, na = hv.desc[doc].n_actors;
+  std::vector<u64> clock(na, 0);
+  std::vector<u8> visited(nc, 0);
+  std::vector<u32> to_visit;
+  for (size_t h = 0; h < n_heads; h++)
+    for (u32 i = 0; i < nc; i++)
+      if (memcmp(hv.c_hash.data() + (size_t)(cb + i) * 32, heads32 + 32 * h, 32) == 0) { to_visit.push_back(i); break; }
+  while (!to_visit.empty()) {
+    u32 i = to_visit.back();
+    to_visit.pop_back();
+    if (visited[i]) continue;
+    visited[i] = 1;
+    u32 a = hv.c_actor[cb + i];
+    if (hv.c_seq[cb + i] > clock[a]) clock[a] = hv.c_seq[cb + i];
+    for (u32 k = 0; k < hv.c_ndeps[cb + i]; k++) to_visit.push_back(hv.dep_idx[hv.c_dep_base[cb + i] + k]);
+  }
+  size_t total = 0;
+  for (u32 i = 0; i < nc; i++) if (hv.c_seq[cb + i] > clock[hv.c_actor[cb + i]]) total += hv.c_out_len[cb + i];
+  out->data = (uint8_t*)malloc(total ? total : 1);
+  if (!out->data) return AMH_ERR_OOM;
+  size_t o = 0;
+  for (u32 i = 0; i < nc; i++)
+    if (hv.c_seq[cb + i] > clock[hv.c_actor[cb + i]]) { memcpy(out->data + o, hv.out_arena.data() + hv.c_out_off[cb + i], hv.c_out_len[cb + i]); o += hv.c_out_len[cb + i]; }
+  out->len = total;
+  return AMH_SUCCESS;
+}
 extern "C" int amh_doc_queue_len(const amh_batch* b, uint32_t doc, size_t* n) {
   if (!b || !n || doc >= b->B.n_docs) return AMH_ERR_INVALID_ARG;
   auto it = b->queue.find(doc);

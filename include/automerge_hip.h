@@ -185,6 +185,12 @@ int amh_doc_queue_len(const amh_batch*, uint32_t doc, size_t* n);
  * (same policy as the reference; compressed bytes are not flate2's: parity unpinned). */
 int amh_save_batch(amh_ctx*, const amh_batch*, const amh_save_opts*, amh_bytes_out* out);
 
+/* == Automerge::save_after(heads) (automerge.rs:993-1000): the changes that are not ancestors of `heads`
+ * (get_changes, :1306 / :1022-1047; heads the document does not know are ignored), as raw change chunks in
+ * history order — the counterpart of amh_apply_batch(incremental = 1) on the receiving side.  out is freed
+ * with amh_bytes_free. */
+int amh_save_after(const amh_batch*, uint32_t doc, const uint8_t* heads32, size_t n_heads, amh_bytes_out* out);
+
 /* ---- sync summaries ---------------------------------------------------------------------------
  * per document: sorted heads (get_heads) + Bloom filter over all change hashes
  * (sync.rs:243-250 make_bloom_filter with last_sync = [], sync/bloom.rs:38-47,69-90,125-146).

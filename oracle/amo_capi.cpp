@@ -92,6 +92,15 @@ int amo_change_compress(const uint8_t* data, size_t len, const uint8_t** out, si
   GUARD_END(-1)
 }
 
+// Automerge::save_after(heads) — automerge.rs:993-1000; heads = n x 32 bytes
+int amo_save_after(const amo_doc* d, const uint8_t* heads, size_t n, const uint8_t** out, size_t* len) {
+  GUARD_BEGIN
+  std::vector<Hash> hs(n);
+  for (size_t i = 0; i < n; i++) memcpy(hs[i].b.data(), heads + 32 * i, 32);
+  return give(save_after(d->doc, hs), out, len);
+  GUARD_END(-1)
+}
+
 // Automerge::load_incremental — automerge.rs:730
 long amo_load_incremental(amo_doc* d, const uint8_t* data, size_t len) {
   GUARD_BEGIN

@@ -685,6 +685,43 @@ inline size_t load_incremental(Doc& doc, const uint8_t* p, size_t n) {
   return opset_len(doc) - before;
 }
 
+// get_changes(have_deps) — automerge.rs:1306, 1022-1047 (get_changes_clock), change_graph.rs:128-182:
+// the clock of the given heads = per actor the highest seq among their ancestors (heads the document does not have
+// are skipped); result = every change whose seq is above its actor's clock entry, in history order.
+inline std::vector<size_t> get_changes_since(const Doc& doc, const std::vector<Hash>& have_deps) {
+  std::map<Bytes, uint64_t> clock;
+  std::vector<size_t> to_visit;
+  for (auto& h : have_deps) {
+    auto it = doc.history_index.find(h);
+    if (it != doc.history_index.end()) to_visit.push_back(it->second);
+  }
+  std::set<size_t> visited;
+  while (!to_visit.empty()) {
+    size_t i = to_visit.back();
+    to_visit.pop_back();
+    if (!visited.insert(i).second) continue;
+    const StoredChange& c = doc.history[i];
+    uint64_t& s = clock[c.actor];
+    if (c.seq > s) s = c.seq;
+    for (auto& d : c.deps) {
+      auto it = doc.history_index.find(d);
+      if (it != doc.history_index.end()) to_visit.push_back(it->second);
+    }
+  }
+  std::vector<size_t> out;
+  for (size_t i = 0; i < doc.history.size(); i++) {
+    auto it = clock.find(doc.history[i].actor);
+    if (it == clock.end() || doc.history[i].seq > it->second) out.push_back(i);
+  }
+  return out;
+}
+// save_after — automerge.rs:993-1000: the raw bytes of those changes, one after the other
+inline Bytes save_after(const Doc& doc, const std::vector<Hash>& heads) {
+  Bytes out;
+  for (size_t i : get_changes_since(doc, heads)) out.insert(out.end(), doc.history[i].bytes.begin(), doc.history[i].bytes.end());
+  return out;
+}
+
 // merge — automerge.rs:917-940, get_changes_added :1311-1334
 inline std::vector<Hash> merge(Doc& dst, const Doc& src) {
   std::vector<Hash> stack = src.get_heads();

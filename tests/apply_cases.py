@@ -209,3 +209,18 @@ def check_incremental_with_documents(engine, replicas):
     assert b3.apply_batch([(0, stream)], incremental=True) == [0]
     ref3.load_incremental(stream)
     check_doc(b3, 0, ref3)
+
+
+def check_save_after_roundtrip(engine, replicas):
+    """save_after(heads) on one side, load_incremental on the other (automerge.rs:993-1000, 730-769): replica 1 sends
+    what replica 0's heads have not seen; unknown heads are ignored; save_after([]) is the whole history"""
+    b = engine.load_batch([bytes(replicas[0]), bytes(replicas[1])])
+    r0, r1 = o.Doc.load(bytes(replicas[0])), o.Doc.load(bytes(replicas[1]))
+    h0 = r0.get_heads()
+    for heads in (h0, [], h0 + [b"\x07" * 32], r1.get_heads()):
+        assert b.save_after(1, heads) == r1.save_after(heads)
+    delta = b.save_after(1, h0)
+    assert b.apply_batch([(0, delta)], incremental=True) == [0]
+    r0.load_incremental(r1.save_after(h0))
+    check_doc(b, 0, r0)
+    assert b.save_all(deflate=False)[0] == r0.save(deflate=False)

@@ -28,6 +28,7 @@ lib.amo_load.argtypes = [C.c_char_p, C.c_size_t, C.c_int]
 lib.amo_load_opts.restype = C.c_void_p
 lib.amo_load_opts.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int]
 lib.amo_change_compress.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+lib.amo_save_after.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
 lib.amo_load_incremental.restype = C.c_long
 lib.amo_load_incremental.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
 lib.amo_apply_changes.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
@@ -111,6 +112,9 @@ class Doc:
 
     def save(self, deflate=True) -> bytes:
         return _out(lib.amo_save, self.h, 1 if deflate else 0)
+
+    def save_after(self, heads) -> bytes:
+        return _out(lib.amo_save_after, self.h, b"".join(heads), len(heads))
 
     def save_nocompress(self) -> bytes:
         return self.save(False)

@@ -219,6 +219,7 @@ def test_apply_changes_text_replicas(emu):
     ac.check_apply_replicas(emu, docs, 4)
     ac.check_queue_across_calls(emu, docs[0], docs[1])
     ac.check_incremental_with_documents(emu, docs[4:8])
+    ac.check_save_after_roundtrip(emu, docs[8:12])
 
 
 def test_load_with_change_chunks_and_incremental(emu):

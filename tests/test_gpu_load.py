@@ -251,6 +251,7 @@ def test_apply_changes_text_replicas(engine):
     ac.check_apply_replicas(engine, docs, 4)
     ac.check_queue_across_calls(engine, docs[0], docs[1])
     ac.check_incremental_with_documents(engine, docs[4:8])
+    ac.check_save_after_roundtrip(engine, docs[8:12])
 
 
 def test_load_with_change_chunks_and_incremental(engine):
