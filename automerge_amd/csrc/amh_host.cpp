@@ -1147,7 +1147,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   if (!rt_h2d(M.status, p_status.data(), P * sizeof(i32), ctx->stream)) return failm("H2D copy failed");
   pt.mark("exec: rows + succ + chunks", &ctx->stream);
   // ---- merged rows -> document chunks (the save kernels over M) ---------------------------------
-  M.sv_status = balloc<i32>(mb, P + 1, &ok); M.sv_col_len = balloc<u32>(mb, (size_t)P * 25 + 1, &ok);
+  M.sv_status = balloc<i32>(mb, P + 1, &ok); M.sv_col_len = balloc<u32>(mb, (size_t)P * 25 + 1, &ok); M.sv_wide = balloc<u32>(mb, P + 1, &ok);
   M.sv_body_len = balloc<u32>(mb, P + 1, &ok); M.sv_off = balloc<u32>(mb, P + 2, &ok);
   if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
   launch(ctx, AK_SAVE_CHECK, M, P);
@@ -2113,6 +2113,7 @@ extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch* bc, const amh_save_
   bool ok = true;
   B.sv_status = balloc<i32>(b, n + 1, &ok);
   B.sv_col_len = balloc<u32>(b, (size_t)n * 25 + 1, &ok);
+  B.sv_wide = balloc<u32>(b, n + 1, &ok);
   B.sv_body_len = balloc<u32>(b, n + 1, &ok);
   B.sv_off = balloc<u32>(b, n + 2, &ok);
   if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }

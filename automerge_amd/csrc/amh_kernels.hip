@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
   const u32 n_max = wave_max_u32(n);
   // output cursors of the store pass: columns back to back at c_cols_off (storage/change.rs:486-488).
   // Columns the size pass flagged as "wide literal" are left to k_encode_store (in-place header widening).
-  const u32 wide_in = (STORE && live) ? B.c_wide[c] : 0;
+  const u32 wide_in = 0;   // the register writer widens long literal headers itself (cw_lit_close)
   u32 wide = 0;
   u8* col_out[AMH_NCOLS];
   {
@@ -576,6 +576,244 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
   (void)raw_col;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Document save, LDS-staged (device form of k_save_size / k_save_store; those remain the host-emulation form and
+// the writer of "wide literal" columns).  Same scheme as g_encode_lds with lane = document: the rows of 64 documents
+// are gathered ENC_K at a time into LDS tiles with coalesced loads (the actor rank lookups and the value conversion
+// are done by the gathering threads, one row each), then every lane runs the reference's column encoders over its
+// own document out of LDS and writes through the 16-byte register writer.  Columns 0..8 (change metadata: a handful
+// of rows per document) are encoded by the lane straight from the change arrays.
+// ------------------------------------------------------------------------------------------
+template <bool STORE>
+__global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
+  typedef typename EncW<STORE>::T W;
+  __shared__ EncShared S;
+  const u32 lane = threadIdx.x;
+  const u32 d = blockIdx.x * 64 + lane;
+  const bool live = d < B.n_docs && B.status[d] == 0 && B.sv_status[d] == 0;
+  const u32 dd = d < B.n_docs ? d : 0;
+  const u32 n = live ? B.cnt[dd].n_rows : 0, ns = live ? B.cnt[dd].n_succ : 0;
+  const u8* chunk = B.arena + B.desc[dd].chunk_off;
+  u32* cl = B.sv_col_len + (u64)dd * AMH_SV_NCOLS;
+  S.n[lane] = n;
+  S.base[lane] = B.row_base[dd];
+  S.mapb[lane] = B.actor_base[dd];
+  S.pbase[lane] = B.succ_base[dd];
+  S.pn[lane] = ns;
+  __syncthreads();
+  const u32 n_max = wave_max_u32(n);
+  const u32 wide_in = 0;   // the register writer widens long literal headers itself (cw_lit_close)
+  u32 wide = 0;
+  const u64 data0 = (STORE && live) ? (u64)B.sv_off[dd] + sv_data_start(B, dd) : 0;
+  auto out_ptr = [&](u32 k) -> u8* {   // where column k goes (store pass), null = not written here
+    if (!STORE || !live || cl[k] == 0 || ((wide_in >> k) & 1)) return (u8*)0;
+    u64 off = data0;
+    for (u32 q = 0; q < k; q++) off += cl[q];
+    return B.sv_out + off;
+  };
+  auto done = [&](W& w, u32 k) { wide |= w_done(w) << k; if (!STORE && live) cl[k] = w.pos; };
+  const u32 row = lane * ENC_STRIDE;
+  RleVal x; x.v = 0; x.s = 0; x.n = 0;
+
+  // ---- change metadata, columns 0..8 ------------------------------------------------------------
+  for (u32 k = 0; k < AMH_SV_CHG_COLS; k++) {
+    W w; w_init(w, out_ptr(k));
+    if (live) save_encode_chg_col(B, dd, k, w);
+    done(w, k);
+  }
+  // ---- object id (columns 9, 10) ---------------------------------------------------------------------
+  {
+    RleEnc<0> ea, ec; re_init(ea); re_init(ec);
+    W wa, wc; w_init(wa, out_ptr(9)); w_init(wc, out_ptr(10));
+    for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
+      enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
+        u32 r = S.base[l] + i, o = l * ENC_STRIDE + k;
+        u32 oc = B.r_obj_ctr[r];
+        S.t1[o] = oc;
+        S.t0[o] = oc ? B.actor_rank[S.mapb[l] + B.r_obj_actor[r]] : 0;
+      });
+      __syncthreads();
+      u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
+      for (u32 i = 0; i < cnt; i++) {
+        u32 oc = S.t1[row + i];
+        if (oc == 0) { re_null(wa, ea); re_null(wc, ec); }
+        else { x.v = S.t0[row + i]; re_value(wa, ea, x); x.v = oc; re_value(wc, ec, x); }
+      }
+      __syncthreads();
+    }
+    re_finish(wa, ea); re_finish(wc, ec);
+    done(wa, 9); done(wc, 10);
+  }
+  // ---- key (columns 11, 12, 13; key.rs:236-257) --------------------------------------------------------
+  {
+    RleEnc<0> ea; re_init(ea);
+    DeltaEnc ec; re_init(ec.r); ec.abs = 0;
+    RleEnc<2> es; re_init(es);
+    W wa, wc, ws; w_init(wa, out_ptr(11)); w_init(wc, out_ptr(12)); w_init(ws, out_ptr(13));
+    for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
+      enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
+        u32 r = S.base[l] + i, o = l * ENC_STRIDE + k;
+        u32 kl = B.r_key_len[r], kc = B.r_key_ctr[r];
+        bool prop = kl != AMH_NULL32;
+        S.t3[o] = kl;
+        S.t2[o] = prop ? B.r_key_off[r] : 0;
+        S.t1[o] = prop ? AMH_NULL32 : kc;
+        S.t0[o] = (!prop && kc != 0) ? B.actor_rank[S.mapb[l] + B.r_key_actor[r]] : AMH_NULL32;
+      });
+      __syncthreads();
+      u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
+      for (u32 i = 0; i < cnt; i++) {
+        u32 ka = S.t0[row + i], kc = S.t1[row + i], kl = S.t3[row + i];
+        if (ka == AMH_NULL32) re_null(wa, ea); else { x.v = ka; re_value(wa, ea, x); }
+        if (kc == AMH_NULL32) re_null(wc, ec.r); else de_value(wc, ec, (i64)kc);
+        if (kl == AMH_NULL32) re_null(ws, es);
+        else { RleVal sv; sv.v = 0; sv.s = chunk + S.t2[row + i]; sv.n = kl; re_value(ws, es, sv); }
+      }
+      __syncthreads();
+    }
+    re_finish(wa, ea); re_finish(wc, ec.r); re_finish(ws, es);
+    done(wa, 11); done(wc, 12); done(ws, 13);
+  }
+  // ---- op id (columns 14, 15) --------------------------------------------------------------------------
+  {
+    RleEnc<0> ea; re_init(ea);
+    DeltaEnc ec; re_init(ec.r); ec.abs = 0;
+    W wa, wc; w_init(wa, out_ptr(14)); w_init(wc, out_ptr(15));
+    for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
+      enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
+        u32 r = S.base[l] + i, o = l * ENC_STRIDE + k;
+        S.t0[o] = B.actor_rank[S.mapb[l] + B.r_id_actor[r]];
+        S.t1[o] = B.r_id_ctr[r];
+      });
+      __syncthreads();
+      u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
+      for (u32 i = 0; i < cnt; i++) {
+        x.v = S.t0[row + i]; re_value(wa, ea, x);
+        de_value(wc, ec, (i64)S.t1[row + i]);
+      }
+      __syncthreads();
+    }
+    re_finish(wa, ea); re_finish(wc, ec.r);
+    done(wa, 14); done(wc, 15);
+  }
+  // ---- insert, action, succ count, expand (columns 16, 17, 20, 23) -------------------------------------
+  {
+    bool ins_last = false, exp_last = false, exp_any = false;
+    u64 ins_cnt = 0, exp_cnt = 0;
+    RleEnc<0> eact, esn; re_init(eact); re_init(esn);
+    W wi, wact, wsn, wex; w_init(wi, out_ptr(16)); w_init(wact, out_ptr(17)); w_init(wsn, out_ptr(20)); w_init(wex, out_ptr(23));
+    for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
+      enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
+        u32 r = S.base[l] + i, o = l * ENC_STRIDE + k;
+        u32 action = B.r_action[r];
+        S.t0[o] = (B.r_insert[r] ? 1u : 0u) | ((action == 7 && B.r_expand[r]) ? 2u : 0u) | (action << 8);
+        S.t1[o] = B.r_succ_cnt[r];
+      });
+      __syncthreads();
+      u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
+      for (u32 i = 0; i < cnt; i++) {
+        u32 f = S.t0[row + i];
+        bool_feed(wi, ins_last, ins_cnt, (f & 1) != 0);
+        x.v = f >> 8; re_value(wact, eact, x);
+        x.v = S.t1[row + i]; re_value(wsn, esn, x);
+        bool ex = (f & 2) != 0;
+        exp_any = exp_any || ex;
+        bool_feed(wex, exp_last, exp_cnt, ex);
+      }
+      __syncthreads();
+    }
+    if (ins_cnt > 0) cw_uleb(wi, ins_cnt);
+    re_finish(wact, eact); re_finish(wsn, esn);
+    if (exp_any && exp_cnt > 0) cw_uleb(wex, exp_cnt);   // MaybeBoolean (boolean.rs:131-137)
+    if (!exp_any) wex.pos = 0;
+    done(wi, 16); done(wact, 17); done(wsn, 20); done(wex, 23);
+  }
+  // ---- value (columns 18, 19; op_as_docop.rs, value.rs:320-369) ------------------------------------------
+  {
+    RleEnc<0> em; re_init(em);
+    W wm, wr; w_init(wm, out_ptr(18)); w_init(wr, out_ptr(19));
+    for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
+      enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
+        u32 r = S.base[l] + i, o = l * ENC_STRIDE + k;
+        OpVal v = op_val(B, r);
+        S.t0[o] = (u32)v.meta;
+        S.t1[o] = (u32)(v.meta >> 32) | ((u32)v.kind << 8);
+        if (v.kind == 2) { S.t2[o] = (u32)(u64)v.i; S.t3[o] = (u32)((u64)v.i >> 32); }
+        else {
+          S.t2[o] = (v.kind == 1 && v.raw_len) ? B.desc[B.r_doc[r]].ocol[OC_VAL_RAW].off + B.r_vraw_off[r] : 0;
+          S.t3[o] = v.raw_len;
+        }
+      });
+      __syncthreads();
+      u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
+      for (u32 i = 0; i < cnt; i++) {
+        u32 hi = S.t1[row + i], kind = hi >> 8;
+        x.v = (u64)S.t0[row + i] | ((u64)(hi & 0xFF) << 32);
+        re_value(wm, em, x);
+        if (kind == 1) cw_bytes(wr, chunk + S.t2[row + i], S.t3[row + i]);
+        else if (kind == 2) cw_sleb(wr, (i64)((u64)S.t2[row + i] | ((u64)S.t3[row + i] << 32)));
+      }
+      __syncthreads();
+    }
+    re_finish(wm, em);
+    done(wm, 18); done(wr, 19);
+  }
+  // ---- flattened succ lists (columns 21, 22; opid_list.rs:52-78) -----------------------------------------
+  {
+    RleEnc<0> ea; re_init(ea);
+    DeltaEnc ec; re_init(ec.r); ec.abs = 0;
+    W wa, wc; w_init(wa, out_ptr(21)); w_init(wc, out_ptr(22));
+    const u32 s_max = wave_max_u32(ns);
+    for (u32 t0 = 0; t0 < s_max; t0 += ENC_K) {
+      enc_load_tile(S.pn, t0, [&](u32 l, u32 k, u32 i) {
+        u32 e = S.pbase[l] + i, o = l * ENC_STRIDE + k;
+        S.t0[o] = B.actor_rank[S.mapb[l] + B.s_actor[e]];
+        S.t1[o] = B.s_ctr[e];
+      });
+      __syncthreads();
+      u32 cnt = ns > t0 ? (ns - t0 < ENC_K ? ns - t0 : ENC_K) : 0;
+      for (u32 i = 0; i < cnt; i++) {
+        x.v = S.t0[row + i]; re_value(wa, ea, x);
+        de_value(wc, ec, (i64)S.t1[row + i]);
+      }
+      __syncthreads();
+    }
+    re_finish(wa, ea); re_finish(wc, ec.r);
+    done(wa, 21); done(wc, 22);
+  }
+  // ---- mark names (column 24) — only when a document of this wave has marks ----------------------------------
+  {
+    bool has_marks = live && B.desc[dd].ocol[OC_MARK_NAME].len != 0;
+    if (__ballot(has_marks)) {
+      RleEnc<2> es; re_init(es);
+      W ws; w_init(ws, out_ptr(24));
+      for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
+        enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
+          u32 r = S.base[l] + i, o = l * ENC_STRIDE + k;
+          bool m = B.r_action[r] == 7 && B.r_mark_len[r] != AMH_NULL32;
+          S.t0[o] = m ? B.r_mark_off[r] : 0;
+          S.t1[o] = m ? B.r_mark_len[r] : AMH_NULL32;
+        });
+        __syncthreads();
+        u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
+        for (u32 i = 0; i < cnt; i++) {
+          u32 ml = S.t1[row + i];
+          if (ml == AMH_NULL32) re_null(ws, es);
+          else { RleVal sv; sv.v = 0; sv.s = chunk + S.t0[row + i]; sv.n = ml; re_value(ws, es, sv); }
+        }
+        __syncthreads();
+      }
+      re_finish(ws, es);
+      done(ws, 24);
+    } else if (!STORE && live) cl[24] = 0;
+  }
+  if (!STORE && d < B.n_docs) {
+    if (!live) for (u32 k = 0; k < AMH_SV_NCOLS; k++) cl[k] = 0;
+    B.sv_wide[d] = live ? wide : 0;
+  }
+}
+
 void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
   if (n == 0) return;
   hipStream_t s = (hipStream_t)stream;
@@ -584,11 +822,14 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
     hipLaunchKernelGGL(g_decode_cols, dim3((B.n_docs + 63) / 64, OC_COUNT), dim3(64), 0, s, B);
     return;
   }
+  if (k == AK_SAVE_SIZE) { hipLaunchKernelGGL((g_save_lds<false>), dim3((B.n_docs + 63) / 64), dim3(64), 0, s, B); return; }
+  if (k == AK_SAVE_STORE) {
+    hipLaunchKernelGGL((g_save_lds<true>), dim3((B.n_docs + 63) / 64), dim3(64), 0, s, B);
+    return;
+  }
   if (k == AK_ENCODE_SIZE) { hipLaunchKernelGGL((g_encode_lds<false>), dim3((B.tot_chg + 63) / 64), dim3(64), 0, s, B); return; }
   if (k == AK_ENCODE_STORE) {
     hipLaunchKernelGGL((g_encode_lds<true>), dim3((B.tot_chg + 63) / 64), dim3(64), 0, s, B);
-    // columns with a literal run of more than 64 values (flagged in c_wide): byte-wise writer that can widen the header
-    if (!getenv("AMH_SKIP_WIDE")) hipLaunchKernelGGL(g_k_encode_store, dim3((n + AMH_BLOCK - 1) / AMH_BLOCK), dim3(AMH_BLOCK), 0, s, B, n);
     return;
   }
   dim3 grid((n + AMH_BLOCK - 1) / AMH_BLOCK), block(AMH_BLOCK);

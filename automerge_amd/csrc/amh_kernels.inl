@@ -1102,16 +1102,30 @@ AMH_DEV void cw_lit_close(SizeWriter& w, u32, u64 cnt) {
   u32 h = sleb_size_fast(-(i64)cnt);
   if (h > 1) { w.pos += h - 1; w.wide = 1; }
 }
-AMH_DEV void cw_lit_close(FastWriter& w, u32 at, u64 cnt) {   // cnt <= 64 here: wide columns never reach a FastWriter with out != null
-  if (!w.out) { u32 h = sleb_size_fast(-(i64)cnt); if (h > 1) w.pos += h - 1; return; }
-  u64 hdr = (u64)(-(i64)cnt) & 0x7f;
-  u32 first = w.pos - w.na;   // oldest byte still in the registers
-  if (at >= first) {
-    u32 k = at - first;
-    if (k < 8) w.a0 |= hdr << (8 * k); else w.a1 |= hdr << (8 * (k - 8));
-  } else {
-    w.out[at] = (u8)hdr;
+AMH_DEV void cw_lit_close(FastWriter& w, u32 at, u64 cnt) {
+  u32 h = sleb_size_fast(-(i64)cnt);
+  if (!w.out) { if (h > 1) w.pos += h - 1; return; }
+  if (h == 1) {
+    u64 hdr = (u64)(-(i64)cnt) & 0x7f;
+    u32 first = w.pos - w.na;   // oldest byte still in the registers
+    if (at >= first) {
+      u32 k = at - first;
+      if (k < 8) w.a0 |= hdr << (8 * k); else w.a1 |= hdr << (8 * (k - 8));
+    } else {
+      w.out[at] = (u8)hdr;
+    }
+    return;
   }
+  // more than 64 values: the header is wider than the byte reserved for it.  The run's bytes are already in place
+  // behind that byte: drain the registers, move the run up by h - 1 (highest bytes first, 8 at a time) and write
+  // the header in front of it — once per long run, instead of sending the whole column through the byte-wise writer.
+  fw_finish(w);
+  u32 delta = h - 1, lo = at + 1, i = w.pos;
+  struct __attribute__((packed)) P8 { u64 v; };
+  while (i - lo >= 8) { u64 v = ((const P8*)(w.out + i - 8))->v; ((P8*)(w.out + i - 8 + delta))->v = v; i -= 8; }
+  while (i > lo) { w.out[i - 1 + delta] = w.out[i - 1]; i--; }
+  wr_sleb(w.out + at, -(i64)cnt);
+  w.pos += delta;
 }
 
 // RLE state machine restated with O(1) state: a literal run's values are streamed behind a
@@ -1706,6 +1720,40 @@ AMH_DEV u32 sv_dep_sorted(const BatchDev& B, u32 c, u32 cb, u32 k) {
   }
   return 0;
 }
+// change-metadata columns 0..8 of a document (doc_change_columns.rs:87-162), any writer
+template <class W>
+AMH_DEV void save_encode_chg_col(const BatchDev& B, u32 d, u32 col, W& w) {
+  const DocDesc& D = B.desc[d];
+  const u8* chunk = B.arena + D.chunk_off;
+  const u32* rank = B.actor_rank + B.actor_base[d];
+  RleVal x; x.v = 0; x.s = 0; x.n = 0;
+  u32 cb = B.chg_base[d], n = B.cnt[d].n_chg;
+  switch (col) {
+    case 0: { RleEnc<0> e; re_init(e); for (u32 i = 0; i < n; i++) { x.v = rank[B.c_actor[cb + i]]; re_value(w, e, x); } re_finish(w, e); break; }
+    case 1: { DeltaEnc e; re_init(e.r); e.abs = 0; for (u32 i = 0; i < n; i++) de_value(w, e, (i64)B.c_seq[cb + i]); re_finish(w, e.r); break; }
+    case 2: { DeltaEnc e; re_init(e.r); e.abs = 0; for (u32 i = 0; i < n; i++) de_value(w, e, (i64)B.c_max_op[cb + i]); re_finish(w, e.r); break; }
+    case 3: { DeltaEnc e; re_init(e.r); e.abs = 0; for (u32 i = 0; i < n; i++) de_value(w, e, B.c_time[cb + i]); re_finish(w, e.r); break; }
+    case 4: {
+      RleEnc<2> e; re_init(e);
+      for (u32 i = 0; i < n; i++) {
+        u32 ml = B.c_msg_len[cb + i];
+        if (ml == AMH_NULL32 || ml == 0) re_null(w, e);
+        else { RleVal sv; sv.v = 0; sv.s = chunk + B.c_msg_off[cb + i]; sv.n = ml; re_value(w, e, sv); }
+      }
+      re_finish(w, e);
+      break;
+    }
+    case 5: { RleEnc<0> e; re_init(e); for (u32 i = 0; i < n; i++) { x.v = B.c_ndeps[cb + i]; re_value(w, e, x); } re_finish(w, e); break; }
+    case 6: {
+      DeltaEnc e; re_init(e.r); e.abs = 0;
+      for (u32 i = 0; i < n; i++) { u32 nd = B.c_ndeps[cb + i]; for (u32 k = 0; k < nd; k++) de_value(w, e, (i64)sv_dep_sorted(B, cb + i, cb, k)); }
+      re_finish(w, e.r);
+      break;
+    }
+    case 7: { RleEnc<0> e; re_init(e); for (u32 i = 0; i < n; i++) { x.v = ((u64)B.c_extra_len[cb + i] << 4) | 7; re_value(w, e, x); } re_finish(w, e); break; }
+    case 8: { for (u32 i = 0; i < n; i++) cw_bytes(w, chunk + B.c_extra_off[cb + i], B.c_extra_len[cb + i]); break; }
+  }
+}
 AMH_DEV u32 save_encode_col(const BatchDev& B, u32 d, u32 col, u8* out) {
   const DocDesc& D = B.desc[d];
   const u8* chunk = B.arena + D.chunk_off;
@@ -1713,32 +1761,7 @@ AMH_DEV u32 save_encode_col(const BatchDev& B, u32 d, u32 col, u8* out) {
   ColWriter w; w.out = out; w.pos = 0;
   RleVal x; x.v = 0; x.s = 0; x.n = 0;
   if (col < AMH_SV_CHG_COLS) {
-    u32 cb = B.chg_base[d], n = B.cnt[d].n_chg;
-    switch (col) {
-      case 0: { RleEnc<0> e; re_init(e); for (u32 i = 0; i < n; i++) { x.v = rank[B.c_actor[cb + i]]; re_value(w, e, x); } re_finish(w, e); break; }
-      case 1: { DeltaEnc e; re_init(e.r); e.abs = 0; for (u32 i = 0; i < n; i++) de_value(w, e, (i64)B.c_seq[cb + i]); re_finish(w, e.r); break; }
-      case 2: { DeltaEnc e; re_init(e.r); e.abs = 0; for (u32 i = 0; i < n; i++) de_value(w, e, (i64)B.c_max_op[cb + i]); re_finish(w, e.r); break; }
-      case 3: { DeltaEnc e; re_init(e.r); e.abs = 0; for (u32 i = 0; i < n; i++) de_value(w, e, B.c_time[cb + i]); re_finish(w, e.r); break; }
-      case 4: {
-        RleEnc<2> e; re_init(e);
-        for (u32 i = 0; i < n; i++) {
-          u32 ml = B.c_msg_len[cb + i];
-          if (ml == AMH_NULL32 || ml == 0) re_null(w, e);
-          else { RleVal sv; sv.v = 0; sv.s = chunk + B.c_msg_off[cb + i]; sv.n = ml; re_value(w, e, sv); }
-        }
-        re_finish(w, e);
-        break;
-      }
-      case 5: { RleEnc<0> e; re_init(e); for (u32 i = 0; i < n; i++) { x.v = B.c_ndeps[cb + i]; re_value(w, e, x); } re_finish(w, e); break; }
-      case 6: {
-        DeltaEnc e; re_init(e.r); e.abs = 0;
-        for (u32 i = 0; i < n; i++) { u32 nd = B.c_ndeps[cb + i]; for (u32 k = 0; k < nd; k++) de_value(w, e, (i64)sv_dep_sorted(B, cb + i, cb, k)); }
-        re_finish(w, e.r);
-        break;
-      }
-      case 7: { RleEnc<0> e; re_init(e); for (u32 i = 0; i < n; i++) { x.v = ((u64)B.c_extra_len[cb + i] << 4) | 7; re_value(w, e, x); } re_finish(w, e); break; }
-      case 8: { for (u32 i = 0; i < n; i++) cw_bytes(w, chunk + B.c_extra_off[cb + i], B.c_extra_len[cb + i]); break; }
-    }
+    save_encode_chg_col(B, d, col, w);
     return w.pos;
   }
   u32 rb = B.row_base[d], n = B.cnt[d].n_rows;
@@ -1887,6 +1910,9 @@ AMH_DEV void k_save_store(const BatchDev& B, u32 gid) {
   if (col >= AMH_SV_NCOLS || !sv_doc_ok(B, d)) return;
   const u32* cl = B.sv_col_len + (u64)d * AMH_SV_NCOLS;
   if (cl[col] == 0) return;
+#ifndef AMH_EMU
+  if (!((B.sv_wide[d] >> col) & 1)) return;   // written by g_save_lds
+#endif
   u64 off = (u64)B.sv_off[d] + sv_data_start(B, d);
   for (u32 k = 0; k < col; k++) off += cl[k];
   save_encode_col(B, d, col, B.sv_out + off);

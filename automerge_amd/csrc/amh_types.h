@@ -163,6 +163,7 @@ struct BatchDev {
   u8* out_arena;                 // re-derived change chunks
   i32* sv_status;                // [n_docs] save: 0 ok, else why the document has no saved form
   u32* sv_col_len;               // [n_docs * 25]
+  u32* sv_wide;                  // [n_docs] bit k: column k holds a literal run of more than 64 values (left to k_save_store)
   u32* sv_body_len;              // [n_docs]
   u32* sv_off;                   // [n_docs + 1] chunk offsets in sv_out
   u8* sv_out;

@@ -55,3 +55,27 @@ void amh_launch_mg(int k, const MergeDev* G, u32 n, void*) {
 void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void*) {
   for (u32 i = 0; i < n; i++) memcpy(dst + dst_off[i], (const u8*)(uintptr_t)src[i], len[i]);
 }
+
+// Test hook: the register writer (FastWriter: 16-byte stores, in-place widening of long literal headers) against the
+// byte-wise writer (ColWriter) over the same value sequence, for the three encoder kinds.  Returns 0 when the bytes
+// agree.  vals[i] < 0 = null; `mod` folds the values so that runs and literal stretches of all lengths show up.
+extern "C" int amh_emu_test_writers(const long long* vals, unsigned n, int kind, unsigned char* scratch_a, unsigned char* scratch_b, unsigned cap, unsigned* len_out) {
+  ColWriter cw; cw.out = scratch_a; cw.pos = 0;
+  FastWriter fw; fw_init(fw, scratch_b);
+  SizeWriter sw; sw_init(sw);
+  static const char* strs[8] = {"", "a", "bc", "k012", "hello", "some longer key", "\xc3\xa9", "zzzzzzzzzzzzzzzzzzzzzzzz"};
+  auto run = [&](auto& w) {
+    RleVal x; x.v = 0; x.s = 0; x.n = 0;
+    if (kind == 0) { RleEnc<0> e; re_init(e); for (unsigned i = 0; i < n; i++) { if (vals[i] < 0) re_null(w, e); else { x.v = (u64)vals[i]; re_value(w, e, x); } } re_finish(w, e); }
+    else if (kind == 1) { DeltaEnc e; re_init(e.r); e.abs = 0; for (unsigned i = 0; i < n; i++) { if (vals[i] < 0) re_null(w, e.r); else de_value(w, e, (i64)vals[i]); } re_finish(w, e.r); }
+    else { RleEnc<2> e; re_init(e); for (unsigned i = 0; i < n; i++) { if (vals[i] < 0) re_null(w, e); else { RleVal sv; sv.v = 0; sv.s = (const u8*)strs[vals[i] & 7]; sv.n = (u32)strlen(strs[vals[i] & 7]); re_value(w, e, sv); } } re_finish(w, e); }
+  };
+  run(cw);
+  run(sw);
+  if (cw.pos > cap) return -1;
+  run(fw);
+  fw_finish(fw);
+  *len_out = cw.pos;
+  if (cw.pos != fw.pos || cw.pos != sw.pos) return 1;
+  return memcmp(scratch_a, scratch_b, cw.pos) == 0 ? 0 : 2;
+}
