@@ -612,18 +612,21 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
     for (u32 q = 0; q < k; q++) off += cl[q];
     return B.sv_out + off;
   };
-  auto done = [&](W& w, u32 k) { wide |= w_done(w) << k; if (!STORE && live) cl[k] = w.pos; };
+  auto done = [&](W& w, u32 k) { wide |= w_done(w) << k; if (!STORE && d < B.n_docs) cl[k] = live ? w.pos : 0; };
   const u32 row = lane * ENC_STRIDE;
   RleVal x; x.v = 0; x.s = 0; x.n = 0;
 
+  // blockIdx.y = column group: the groups of a document are independent (each finds its columns' places from the
+  // column lengths), so a batch of few, large documents still fills the device
+  const u32 grp = blockIdx.y;
   // ---- change metadata, columns 0..8 ------------------------------------------------------------
-  for (u32 k = 0; k < AMH_SV_CHG_COLS; k++) {
+  if (grp == 0) for (u32 k = 0; k < AMH_SV_CHG_COLS; k++) {
     W w; w_init(w, out_ptr(k));
     if (live) save_encode_chg_col(B, dd, k, w);
     done(w, k);
   }
   // ---- object id (columns 9, 10) ---------------------------------------------------------------------
-  {
+  if (grp == 1) {
     RleEnc<0> ea, ec; re_init(ea); re_init(ec);
     W wa, wc; w_init(wa, out_ptr(9)); w_init(wc, out_ptr(10));
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
@@ -646,7 +649,7 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
     done(wa, 9); done(wc, 10);
   }
   // ---- key (columns 11, 12, 13; key.rs:236-257) --------------------------------------------------------
-  {
+  if (grp == 2) {
     RleEnc<0> ea; re_init(ea);
     DeltaEnc ec; re_init(ec.r); ec.abs = 0;
     RleEnc<2> es; re_init(es);
@@ -676,7 +679,7 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
     done(wa, 11); done(wc, 12); done(ws, 13);
   }
   // ---- op id (columns 14, 15) --------------------------------------------------------------------------
-  {
+  if (grp == 3) {
     RleEnc<0> ea; re_init(ea);
     DeltaEnc ec; re_init(ec.r); ec.abs = 0;
     W wa, wc; w_init(wa, out_ptr(14)); w_init(wc, out_ptr(15));
@@ -698,7 +701,7 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
     done(wa, 14); done(wc, 15);
   }
   // ---- insert, action, succ count, expand (columns 16, 17, 20, 23) -------------------------------------
-  {
+  if (grp == 4) {
     bool ins_last = false, exp_last = false, exp_any = false;
     u64 ins_cnt = 0, exp_cnt = 0;
     RleEnc<0> eact, esn; re_init(eact); re_init(esn);
@@ -730,7 +733,7 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
     done(wi, 16); done(wact, 17); done(wsn, 20); done(wex, 23);
   }
   // ---- value (columns 18, 19; op_as_docop.rs, value.rs:320-369) ------------------------------------------
-  {
+  if (grp == 5) {
     RleEnc<0> em; re_init(em);
     W wm, wr; w_init(wm, out_ptr(18)); w_init(wr, out_ptr(19));
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
@@ -760,7 +763,7 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
     done(wm, 18); done(wr, 19);
   }
   // ---- flattened succ lists (columns 21, 22; opid_list.rs:52-78) -----------------------------------------
-  {
+  if (grp == 6) {
     RleEnc<0> ea; re_init(ea);
     DeltaEnc ec; re_init(ec.r); ec.abs = 0;
     W wa, wc; w_init(wa, out_ptr(21)); w_init(wc, out_ptr(22));
@@ -783,7 +786,7 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
     done(wa, 21); done(wc, 22);
   }
   // ---- mark names (column 24) — only when a document of this wave has marks ----------------------------------
-  {
+  if (grp == 7) {
     bool has_marks = live && B.desc[dd].ocol[OC_MARK_NAME].len != 0;
     if (__ballot(has_marks)) {
       RleEnc<2> es; re_init(es);
@@ -806,12 +809,10 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
       }
       re_finish(ws, es);
       done(ws, 24);
-    } else if (!STORE && live) cl[24] = 0;
+    } else if (!STORE && d < B.n_docs) cl[24] = 0;
   }
-  if (!STORE && d < B.n_docs) {
-    if (!live) for (u32 k = 0; k < AMH_SV_NCOLS; k++) cl[k] = 0;
-    B.sv_wide[d] = live ? wide : 0;
-  }
+  if (!STORE && d < B.n_docs && grp == 0) B.sv_wide[d] = 0;   // nothing is left to the byte-wise writer
+  (void)wide;
 }
 
 void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
@@ -822,9 +823,9 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
     hipLaunchKernelGGL(g_decode_cols, dim3((B.n_docs + 63) / 64, OC_COUNT), dim3(64), 0, s, B);
     return;
   }
-  if (k == AK_SAVE_SIZE) { hipLaunchKernelGGL((g_save_lds<false>), dim3((B.n_docs + 63) / 64), dim3(64), 0, s, B); return; }
+  if (k == AK_SAVE_SIZE) { hipLaunchKernelGGL((g_save_lds<false>), dim3((B.n_docs + 63) / 64, 8), dim3(64), 0, s, B); return; }
   if (k == AK_SAVE_STORE) {
-    hipLaunchKernelGGL((g_save_lds<true>), dim3((B.n_docs + 63) / 64), dim3(64), 0, s, B);
+    hipLaunchKernelGGL((g_save_lds<true>), dim3((B.n_docs + 63) / 64, 8), dim3(64), 0, s, B);
     return;
   }
   if (k == AK_ENCODE_SIZE) { hipLaunchKernelGGL((g_encode_lds<false>), dim3((B.tot_chg + 63) / 64), dim3(64), 0, s, B); return; }
