@@ -164,7 +164,8 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
                 n_ops += d.num_ops()
             secs = time.perf_counter() - t0
             out["cpu_baseline"] = {"value": n_ops / secs, "unit": "ops/s", "cores": 1, "kind": "port",
-                                   "sample": f"first {ns} documents, load {R} + merge {R - 1} on one thread (CPU restatement in oracle/, not the Rust reference)"}
+                                   "sample": f"first {ns} documents, load {R} + merge {R - 1} on one thread (CPU restatement in oracle/ with a plain O(n) "
+                                             f"sequence insert per op: a correctness oracle, not the Rust reference and not indicative of its speed)"}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
@@ -349,7 +350,7 @@ def main():
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))["kernels"]
-        names = {"encode_store": ["void g_encode_lds<true>(BatchDev)", "g_k_encode_store(BatchDev, unsigned int)"],
+        names = {"encode_store": ["void g_encode_lds<true>(BatchDev)"],
                  "encode_size": ["void g_encode_lds<false>(BatchDev)"], "decode_ops": ["g_decode_cols(BatchDev)", "g_k_decode_ops(BatchDev, unsigned int)"],
                  "count": ["g_count_lds(BatchDev)"]}.get(dom, [f"g_k_{dom}(BatchDev, unsigned int)"])
         vals = [tj[nm]["traffic"] for nm in names if nm in tj]
