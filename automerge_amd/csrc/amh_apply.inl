@@ -487,6 +487,7 @@ AMH_DEV void k_ap_succ_fill_u(const MergeDev& G, u32 e) {
   u32 tgt = G.A.p_tgt[e];
   if (tgt == AMH_NULL32 || (tgt & 0x80000000u)) return;
   u32 r = G.U.s_row[e];
+  if (!mg_pair_ok(G, G.S.r_doc[r])) return;
   u32 o = G.S.r_succ_base[tgt] + amh_atomic_add(&G.A.u_fill[tgt], 1);
   G.S.s_actor[o] = G.S.r_id_actor[r];
   G.S.s_ctr[o] = G.S.r_id_ctr[r];
@@ -514,6 +515,7 @@ AMH_DEV void k_ap_succ_fill_d(const MergeDev& G, u32 e) {
   u32 drow = tgt & 0x7FFFFFFFu;
   u32 r = G.U.s_row[e];
   u32 p = G.S.r_doc[r];
+  if (!mg_pair_ok(G, p)) return;
   u32 m = G.d_to_m[drow];
   u32 o = G.M.r_succ_base[m] + G.D.r_succ_cnt[drow] + amh_atomic_add(&G.x_fill[drow], 1);
   G.M.s_actor[o] = G.map_b[G.mapb_base[p] + G.S.r_id_actor[r]];

@@ -440,7 +440,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   if (!scan_inplace(b, B.c_out_off, B.tot_chg, &tot_out)) return fail("scan failed");
   if (tot_out == 0xFFFFFFFFu) return fail("batch too large: re-derived changes exceed 4 GiB");
   b->tot_out = tot_out;
-  B.out_arena = balloc<u8>(b, (size_t)tot_out + 64, &ok);
+  B.out_arena = balloc<u8>(b, (size_t)tot_out + 256, &ok);
   if (!ok) return fail("device out of memory");
   launch(ctx, AK_ENCODE_STORE, B, B.tot_chg * AMH_NCOLS);
   launch(ctx, AK_CHG_HEADER, B, B.tot_chg);
@@ -1078,6 +1078,8 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   M.r_vmeta = balloc<u64>(mb, NR, &ok);
   if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
   rt_memset(G.gap_cnt, 0, ((size_t)gap_tot + 2) * 4, ctx->stream);
+  rt_memset(G.new_src, 0xFF, ((size_t)tot_new + 1) * 4, ctx->stream);   // pairs given up by a kernel leave their slots empty
+  rt_memset(G.new_gap, 0xFF, ((size_t)tot_new + 1) * 4, ctx->stream);
   rt_memset(M.r_succ_cnt, 0, NR * 4, ctx->stream);
   mg(MK_SUBTREE, P);
   pt.mark("exec: setup + subtree", &ctx->stream);

@@ -248,6 +248,7 @@ AMH_DEV void k_mg_rows_dst(const MergeDev& G, u32 r) {
 AMH_DEV void k_mg_rows_new(const MergeDev& G, u32 k) {
   const BatchDev& S = G.S;
   u32 r = G.new_src[k];
+  if (r == AMH_NULL32) return;   // the pair was given up before its new rows were placed
   u32 b = S.r_doc[r], p = G.s_pair[b];
   if (!mg_pair_ok(G, p)) return;
   u32 k0 = G.new_idx[S.row_base[b]];
@@ -270,6 +271,7 @@ AMH_DEV void k_mg_succ_dst(const MergeDev& G, u32 r) {
 AMH_DEV void k_mg_succ_new(const MergeDev& G, u32 k) {
   const BatchDev& S = G.S;
   u32 r = G.new_src[k];
+  if (r == AMH_NULL32) return;
   u32 p = G.s_pair[S.r_doc[r]];
   if (!mg_pair_ok(G, p)) return;
   u32 m = G.new_gap[k], o = G.M.r_succ_base[m], sb = S.r_succ_base[r], n = S.r_succ_cnt[r];

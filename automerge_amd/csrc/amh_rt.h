@@ -19,9 +19,9 @@ inline void* rt_malloc(size_t n) { return malloc(n ? n : 1); }
 inline void rt_free(void* p) { free(p); }
 inline void* rt_host_alloc(size_t n) { return malloc(n ? n : 1); }
 inline void rt_host_free(void* p) { free(p); }
-inline bool rt_h2d(void* d, const void* h, size_t n, rt_stream) { memcpy(d, h, n); return true; }
-inline bool rt_d2h(void* h, const void* d, size_t n, rt_stream) { memcpy(h, d, n); return true; }
-inline bool rt_memset(void* d, int v, size_t n, rt_stream) { memset(d, v, n); return true; }
+inline bool rt_h2d(void* d, const void* h, size_t n, rt_stream) { if (n) memcpy(d, h, n); return true; }
+inline bool rt_d2h(void* h, const void* d, size_t n, rt_stream) { if (n) memcpy(h, d, n); return true; }
+inline bool rt_memset(void* d, int v, size_t n, rt_stream) { if (n) memset(d, v, n); return true; }
 inline bool rt_sync(rt_stream) { return true; }
 inline void rt_event_create(rt_event*) {}
 inline void rt_event_destroy(rt_event*) {}
