@@ -327,6 +327,8 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   for (auto pb : bases) *pb = balloc<u32>(b, n + 2, &ok);
   B.doc_hash = balloc<u8>(b, (size_t)n * 32 + 32, &ok);
   B.doc_max_op = balloc<u32>(b, n + 1, &ok);
+  B.dn_base = balloc<u32>(b, n + 2, &ok); B.dn_stride = balloc<u32>(b, n + 2, &ok);
+  B.ht_mode = getenv("AMH_HT_HASH") ? 1 : 0;
   B.heads_ok = balloc<u32>(b, n + 1, &ok);
   B.doc_level = balloc<u32>(b, n + 1, &ok);
   B.max_level = balloc<u32>(b, 4, &ok);
@@ -370,13 +372,11 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   B.r_vmeta = balloc<u64>(b, NR, &ok); B.r_inc_sum = balloc<i64>(b, NR, &ok);
   B.s_actor = balloc<u32>(b, NS, &ok); B.s_ctr = balloc<u32>(b, NS, &ok); B.s_row = balloc<u32>(b, NS, &ok);
   B.s_target = balloc<u32>(b, NS, &ok); B.pred_ids = balloc<u64>(b, NS, &ok);
-  B.ht_key = balloc<u64>(b, (size_t)b->tot_ht + 1, &ok); B.ht_val = balloc<u32>(b, (size_t)b->tot_ht + 1, &ok);
   B.dt_key = balloc<u64>(b, (size_t)B.tot_dt + 1, &ok); B.d_doc = balloc<u32>(b, (size_t)B.tot_dt + 1, &ok);
   B.d_first_pred_row = balloc<u32>(b, (size_t)B.tot_dt + 1, &ok);
   B.t_pred_cnt = balloc<u32>(b, (size_t)T + 2, &ok); B.t_pred_base = balloc<u32>(b, (size_t)T + 2, &ok);
   B.t_pred_fill = balloc<u32>(b, (size_t)T + 2, &ok); B.t_chg = balloc<u32>(b, (size_t)T + 2, &ok);
   if (!ok) return fail("device out of memory");
-  rt_memset(B.ht_key, 0, ((size_t)b->tot_ht + 1) * 8, ctx->stream);
   rt_memset(B.dt_key, 0, ((size_t)B.tot_dt + 1) * 8, ctx->stream);
   rt_memset(B.d_first_pred_row, 0xFF, ((size_t)B.tot_dt + 1) * 4, ctx->stream);
   rt_memset(B.s_row, 0xFF, NS * 4, ctx->stream);
@@ -394,6 +394,18 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   launch(ctx, AK_CHG_INIT, B, B.tot_chg);
   launch(ctx, AK_DECODE_CHG, B, n);
   launch(ctx, AK_DECODE_OPS, B, n * OC_COUNT);
+  {   // id -> row tables, sized now that the highest counter of every document is known
+    launch(ctx, AK_HT_SIZE, B, n);
+    u32 tot_ht = 0, tot_dn = 0;
+    if (!scan_inplace(b, B.ht_base, n, &tot_ht) || !scan_inplace(b, B.dn_base, n, &tot_dn)) return fail("scan failed");
+    if (tot_ht == 0xFFFFFFFFu || tot_dn == 0xFFFFFFFFu) return fail("batch too large: id tables exceed 2^32-1 slots");
+    b->tot_ht = tot_ht;
+    B.ht_key = balloc<u64>(b, (size_t)tot_ht + 1, &ok); B.ht_val = balloc<u32>(b, (size_t)tot_ht + 1, &ok);
+    B.dn_val = balloc<u32>(b, (size_t)tot_dn + 1, &ok);
+    if (!ok) return fail("device out of memory");
+    rt_memset(B.ht_key, 0, ((size_t)tot_ht + 1) * 8, ctx->stream);
+    rt_memset(B.dn_val, 0xFF, ((size_t)tot_dn + 1) * 4, ctx->stream);
+  }
   launch(ctx, AK_ROWS, B, B.tot_rows);
   launch(ctx, AK_OBJ_ORDER, B, B.tot_rows);
   launch(ctx, AK_SUCC, B, B.tot_succ);

@@ -18,8 +18,14 @@ AMH_DEV u64 amh_mix64(u64 x) {
 }
 AMH_DEV u64 pack_id(u32 ctr, u32 actor) { return ((u64)ctr << 32) | actor; }
 
-// id -> row lookup in the document's region of the open-addressing table. AMH_EMPTY32 = absent.
+// id -> row lookup in the document's table region (direct or open addressing). AMH_EMPTY32 = absent.
 AMH_DEV u32 ht_find(const BatchDev& B, u32 d, u64 id) {
+  u32 stride = B.dn_stride[d];
+  if (stride) {
+    u32 ctr = (u32)(id >> 32), actor = (u32)id;
+    if (ctr >= stride || actor >= B.desc[d].n_actors) return AMH_EMPTY32;
+    return B.dn_val[B.dn_base[d] + actor * stride + ctr];
+  }
   u64 base = B.ht_base[d], size = B.ht_base[d + 1] - base;
   if (size == 0) return AMH_EMPTY32;
   u64 key = id + 1, mask = size - 1, h = amh_mix64(key) & mask;
@@ -740,6 +746,12 @@ AMH_DEV void k_rows(const BatchDev& B, u32 r) {
   u8 action = B.r_action[r];
   if (action == 5 && vt != 3 && vt != 4) { amh_fail(B, d, AMH_E_INVALID_OP); return; }
   // id -> row
+  u32 stride = B.dn_stride[d];
+  if (stride) {
+    if (ic >= stride) { amh_fail(B, d, AMH_E_UNSUPPORTED); return; }   // cannot happen: stride covers doc_max_op
+    if (amh_atomic_cas(&B.dn_val[B.dn_base[d] + ia * stride + ic], AMH_NULL32, r) != AMH_NULL32) amh_fail(B, d, AMH_E_UNSUPPORTED);   // duplicate op id in one document
+    return;
+  }
   u64 base = B.ht_base[d], size = B.ht_base[d + 1] - base, mask = size - 1;
   u64 key = pack_id(ic, ia) + 1, h = amh_mix64(key) & mask;
   for (u64 i = 0; i < size; i++) {
@@ -1975,6 +1987,19 @@ AMH_DEV void k_save_finish(const BatchDev& B, u32 d) {
 // small glue kernels
 // ------------------------------------------------------------------------------------------
 AMH_DEV u32 amh_pow2_at_least(u32 v) { u32 p = 1; while (p < v) p <<= 1; return p; }
+// id table of a document: direct when actors x (highest counter + 1) stays within 8 slots per row, else a hash
+// region of at least twice the rows.  doc_max_op is final here (op ids and succ ids, k_decode_ops).  Thread per document.
+AMH_DEV void k_ht_size(const BatchDev& B, u32 d) {
+  B.ht_base[d] = 0; B.dn_base[d] = 0; B.dn_stride[d] = 0;
+  if (B.status[d]) return;
+  u32 rows = B.cnt[d].n_rows, na = B.desc[d].n_actors;
+  if (rows == 0) return;
+  u64 stride = (u64)B.doc_max_op[d] + 1;
+  u64 dense = stride * na;
+  if (B.ht_mode == 0 && dense <= 8ull * rows + 64 && stride < 0xFFFFFFFFull) { B.dn_base[d] = (u32)dense; B.dn_stride[d] = (u32)stride; }
+  else B.ht_base[d] = amh_pow2_at_least(2 * rows);
+}
+
 // per-document sizes, written into the *_base arrays and scanned in place afterwards
 AMH_DEV void k_extract(const BatchDev& B, u32 d) {
   bool ok = B.status[d] == 0;
@@ -1986,7 +2011,7 @@ AMH_DEV void k_extract(const BatchDev& B, u32 d) {
   B.chg_base[d] = chg;
   B.dep_base[d] = deps;
   B.actor_base[d] = na;
-  B.ht_base[d] = rows ? amh_pow2_at_least(2 * rows) : 0;
+  B.ht_base[d] = 0;   // the id tables are sized after the decode, when the highest counter is known (k_ht_size)
   B.dt_base[d] = succ ? amh_pow2_at_least(2 * succ) : 0;
   u64 m = (u64)chg * na;
   B.map_base[d] = m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)m;

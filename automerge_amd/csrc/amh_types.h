@@ -142,7 +142,12 @@ struct BatchDev {
   u32 *s_actor, *s_ctr;
   u32* s_row;                    // owning row (global)
   u32* s_target;                 // op index t of the op this entry names
-  // id -> row hash tables (one power-of-two region per document) [tot_ht]
+  // id -> row tables, one region per document, sized after the decode (k_ht_size).  Documents whose ids are dense
+  // (actors x highest counter within a few times the row count: what writers produce) get a direct table
+  // dn_val[dn_base[d] + actor * dn_stride[d] + ctr]; the others an open-addressing hash region [tot_ht]
+  u32 ht_mode;                   // 0 = choose per document, 1 = hash tables only (tests)
+  u32 *dn_base, *dn_stride;      // [n_docs + 1] / [n_docs]: stride = highest counter + 1, 0 = the document uses the hash region
+  u32* dn_val;                   // row, AMH_NULL32 = empty
   u64* ht_key;                   // (ctr << 32 | actor) + 1, 0 = empty
   u32* ht_val;
   // synthesized deletes live in the slots of a second table [tot_dt]

@@ -58,6 +58,7 @@ def algorithmic_bytes(st, cols):
         "chg_hash": Eout + 32 * C + 4 * C * 5,
         "chg_hash_seq": Eout,
         "heads": 64 * C + 40 * D,
+        "ht_size": 24 * D,
         "visible": 12 * R + 2 * R,
         "scan": 8 * (9 * D + 2 * C + T),
     }
@@ -358,7 +359,7 @@ def main():
     except Exception:
         traffic = None
     kernels = {k: {"ms": round(v[0] / max(1, v[1]), 4), "launches": v[1],
-                   "GBps": round(model[k] / v[1] / (v[0] / v[1] * 1e-3) / 1e9, 2) if v[0] > 0 and v[1] > 0 else None}
+                   "GBps": round(model.get(k, 0) / v[1] / (v[0] / v[1] * 1e-3) / 1e9, 2) if v[0] > 0 and v[1] > 0 else None}
                for k, v in kt.items() if v[1] > 0}
     out = {
         "metric": "ops loaded+merged/sec (node)", "value": ops_all * args.steps / elapsed_max, "unit": "ops/s",

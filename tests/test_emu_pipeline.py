@@ -247,3 +247,17 @@ def test_many_documents_take_the_threaded_host_path(emu):
     ac.check_apply_tail(emu, docs, lambda k: k // 2)
     blob, offs = emu.gen_text_docs(0x7E57, n, 3, 10, 30, 10, 2)
     check_merge_many(emu, [[bytes(blob[offs[i * 3 + r]:offs[i * 3 + r + 1]]) for i in range(n)] for r in range(3)])
+
+
+def test_hash_id_tables(emu, golden_dir, monkeypatch):
+    """documents whose op ids are sparse use an open-addressing id table instead of the direct one: force that form"""
+    monkeypatch.setenv("AMH_HT_HASH", "1")
+    files = sorted(glob.glob(os.path.join(golden_dir, "docs", "*.automerge")))[:20]
+    docs = [open(f, "rb").read() for f in files]
+    blob, offs = emu.gen_text_docs(0xE070, 2, 3, 60, 240, 40, 2)
+    docs += [bytes(blob[offs[i]:offs[i + 1]]) for i in range(6)]
+    batch = emu.load_batch(docs)
+    for i, d in enumerate(docs):
+        compare(batch, i, d)
+    from merge_cases import check_merge_many
+    check_merge_many(emu, [[docs[20 + 3 * i + r] for i in range(2)] for r in range(3)])

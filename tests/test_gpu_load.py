@@ -278,3 +278,17 @@ def test_edit_trace(engine, golden_dir):
     """BASELINE.json configs[0] on the device: one document, one change of 259,779 ops"""
     import edit_trace_case as et
     et.check_engine(engine, golden_dir)
+
+
+def test_hash_id_tables(engine, golden_dir, monkeypatch):
+    """documents whose op ids are sparse use an open-addressing id table instead of the direct one: force that form"""
+    monkeypatch.setenv("AMH_HT_HASH", "1")
+    files = sorted(glob.glob(os.path.join(golden_dir, "docs", "*.automerge")))[:20]
+    docs = [open(f, "rb").read() for f in files]
+    blob, offs = engine.gen_text_docs(0xE070, 2, 3, 60, 240, 40, 2)
+    docs += [bytes(blob[offs[i]:offs[i + 1]]) for i in range(6)]
+    batch = engine.load_batch(docs)
+    for i, d in enumerate(docs):
+        _compare(batch, i, d)
+    from merge_cases import check_merge_many
+    check_merge_many(engine, [[docs[20 + 3 * i + r] for i in range(2)] for r in range(3)])
