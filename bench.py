@@ -244,6 +244,71 @@ def bench_sync(args, eng, rank, world, dist, torch, red_dev):
         dist.destroy_process_group()
 
 
+def bench_apply(args, eng, rank, world, dist, torch, red_dev):
+    """Sync-server round: `--docs` map documents per GPU (default 100k, configs[1]'s shape after 4 of its 5 rounds: 800 ops
+    each) receive the 4 changes of the last round (200 ops) through one amh_apply_batch call.  The deltas are what
+    save_after(base heads) of the full documents yields.  One step = load the base batch + apply; the apply share is
+    reported separately.  ops = ops of the resulting documents, counted once."""
+    threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), 32))
+    seed = 0xA070 + rank * args.docs
+    t0 = time.time()
+    base_arena = eng.gen_map_arena(seed, args.docs, 4, 4, 50, 128, threads)
+    full_arena = eng.gen_map_arena(seed, args.docs, 4, 5, 50, 128, threads)
+    base_staged = eng.stage_arena(base_arena)
+    bb = eng.load_staged(base_staged)
+    fb = eng.load_staged(eng.stage_arena(full_arena))
+    items = [(i, fb.save_after(i, bb.get_heads(i))) for i in range(args.docs)]
+    delta_bytes = sum(len(x[1]) for x in items)
+    fb.close()
+    bb.close()
+    t_prep = time.time() - t0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        b = eng.load_staged(base_staged)
+        t1 = time.perf_counter()
+        res = b.apply_batch(items, incremental=True)
+        return b, time.perf_counter() - t1, res
+
+    for _ in range(args.warmup):
+        step()[0].close()
+    barrier()
+    t0 = time.perf_counter()
+    apply_s = 0.0
+    for k in range(args.steps):
+        b, dt, res = step()
+        apply_s += dt
+        if k + 1 < args.steps:
+            b.close()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert not any(res)
+    st = b.stats()
+    assert st["n_ok"] == args.docs
+    tot = torch.tensor([float(elapsed), float(st["ops_loaded"])], dtype=torch.float64, device=red_dev)
+    if dist is not None:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed_max, ops_all = float(tmax[0]), float(tot[1])
+    else:
+        elapsed_max, ops_all = elapsed, float(st["ops_loaded"])
+    if rank == 0:
+        print(json.dumps({"metric": "ops loaded+merged/sec (node)", "value": ops_all * args.steps / elapsed_max, "unit": "ops/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64", "data": "synthetic",
+                          "config": {"workload": "sync-server round: load 800-op map documents, apply 4 received changes (200 ops) to each with one amh_apply_batch call",
+                                     "docs_per_gpu": args.docs, "delta_bytes_per_gpu": delta_bytes, "apply_ms_per_step": apply_s / args.steps * 1e3,
+                                     "docs_applied_per_s": world * args.docs / (apply_s / args.steps), "prep_s": round(t_prep, 1),
+                                     "note": "the call's Python marshalling of one buffer per document is inside apply_ms; the batch is re-verified (reloaded) after the apply"}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,13 +319,13 @@ def main():
                     "do not fit one GPU's HBM together)")
     ap.add_argument("--cpu-sample", type=int, default=4000, help="documents of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", default="load", choices=["load", "merge", "sync"],
+    ap.add_argument("--workload", default="load", choices=["load", "merge", "sync", "apply"],
                     help="load = configs[1] (the headline line); merge = configs[2]: text documents x 8 divergent replicas, load 8 + merge 7")
     ap.add_argument("--replicas", type=int, default=8)
     ap.add_argument("--sequential-merges", action="store_true", help="merge workload: R-1 amh_merge_batch calls instead of one amh_merge_many")
     args = ap.parse_args()
     if args.docs is None:
-        args.docs = {"load": 100000, "merge": 4000, "sync": 125000}[args.workload]
+        args.docs = {"load": 100000, "merge": 4000, "sync": 125000, "apply": 100000}[args.workload]
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -288,6 +353,8 @@ def main():
         return bench_merge(args, eng, rank, world, dist, torch, red_dev)
     if args.workload == "sync":
         return bench_sync(args, eng, rank, world, dist, torch, red_dev)
+    if args.workload == "apply":
+        return bench_apply(args, eng, rank, world, dist, torch, red_dev)
     omp = int(os.environ.get("OMP_NUM_THREADS", "16"))
     threads = max(1, min(omp if world == 1 else max(4, omp // world), 32))   # host threads of the (untimed) generator
     seed = 0xA070 + rank * args.docs
