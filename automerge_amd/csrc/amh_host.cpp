@@ -898,6 +898,19 @@ struct Hash32 {
 };
 struct Hash32Hasher { size_t operator()(const Hash32& h) const { size_t v; memcpy(&v, h.b, sizeof v); return v; } };
 
+// byte buffer that is not zero-filled on allocation (staging arenas of several hundred MB are written in full anyway)
+struct RawBuf {
+  u8* p = nullptr;
+  size_t n = 0;
+  RawBuf() {}
+  RawBuf(const RawBuf&) = delete;
+  RawBuf& operator=(const RawBuf&) = delete;
+  ~RawBuf() { free(p); }
+  bool alloc(size_t bytes) { free(p); p = (u8*)malloc(bytes ? bytes : 1); n = p ? bytes : 0; return p != nullptr; }
+  u8* data() const { return p; }
+  size_t size() const { return n; }
+};
+
 // per-document host bookkeeping of a batch call on a few threads (documents are independent)
 template <class F>
 static void host_parallel_for(u32 n, F f) {
@@ -1576,7 +1589,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   hb->ctx = ctx;
   ApplyRun ap;
   std::vector<u64> doc_off;
-  std::vector<u8> h_arena;
+  RawBuf h_arena;
   ap.s_desc.resize(P); ap.s_cnt.resize(P); ap.s_row_base.assign(P + 1, 0);
   std::vector<u32> staged_of;   // U index -> chunks index
   {
@@ -1599,8 +1612,13 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       if (off - region >= 0xFFFFFFF0ull) { set_error(ctx, std::string(who) + ": changes of one document exceed 4 GiB"); return AMH_ERR_BATCH_TOO_LARGE; }
       ap.s_desc[p].chunk_len = (u32)(off - region);
     }
-    h_arena.assign(off + 256, 0);
-    host_parallel_for((u32)staged_of.size(), [&](u32 u) { memcpy(h_arena.data() + doc_off[2 * (size_t)u], chunks[staged_of[u]].p, chunks[staged_of[u]].len); });
+    if (!h_arena.alloc((size_t)off + 256)) { set_error(ctx, std::string(who) + ": out of host memory"); return AMH_ERR_OOM; }
+    memset(h_arena.data() + off, 0, 256);
+    host_parallel_for((u32)staged_of.size(), [&](u32 u) {   // chunk bytes + the alignment gap behind them
+      u64 o0 = doc_off[2 * (size_t)u], o1 = doc_off[2 * (size_t)u + 1], next = (o1 + 15) & ~(u64)15;
+      memcpy(h_arena.data() + o0, chunks[staged_of[u]].p, chunks[staged_of[u]].len);
+      memset(h_arena.data() + o1, 0, (size_t)(next - o1));
+    });
   }
   u32 NCH = (u32)staged_of.size();
   ap.n_chunks = NCH;

@@ -317,7 +317,7 @@ def main():
     ap.add_argument("--docs", type=int, default=None, help="documents per GPU (default: 100k for load = configs[1]; 4000 for merge, "
                     "a 40 % share of configs[2]'s 10k documents: the 8 source batches, the merged rows and the reloaded batch of all 10k "
                     "do not fit one GPU's HBM together)")
-    ap.add_argument("--cpu-sample", type=int, default=4000, help="documents of the same workload timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=16000, help="documents of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--workload", default="load", choices=["load", "merge", "sync", "apply"],
                     help="load = configs[1] (the headline line); merge = configs[2]: text documents x 8 divergent replicas, load 8 + merge 7")
