@@ -347,8 +347,6 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
     if (totals[i] == 0xFFFFFFFFu) return fail("batch too large: a derived count exceeds 2^32-1");
   B.tot_rows = totals[0]; B.tot_succ = totals[1]; B.tot_chg = totals[2]; B.tot_deps = totals[3];
   B.tot_actors = totals[4]; b->tot_ht = totals[5]; B.tot_dt = totals[6]; b->tot_map = totals[7];
-  if ((u64)B.tot_rows + B.tot_dt >= 0x7FFFFFFFull) return fail("batch too large: more than 2^31 ops");
-  u32 T = B.tot_rows + B.tot_dt;
   size_t NA = B.tot_actors + 1, NC = B.tot_chg + 2, NR = B.tot_rows + 1, NS = B.tot_succ + 1;
   B.actor_off = balloc<u32>(b, NA, &ok); B.actor_len = balloc<u32>(b, NA, &ok);
   B.actor_rank = balloc<u32>(b, NA, &ok); B.actor_by_rank = balloc<u32>(b, NA, &ok);
@@ -372,13 +370,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   B.r_vmeta = balloc<u64>(b, NR, &ok); B.r_inc_sum = balloc<i64>(b, NR, &ok);
   B.s_actor = balloc<u32>(b, NS, &ok); B.s_ctr = balloc<u32>(b, NS, &ok); B.s_row = balloc<u32>(b, NS, &ok);
   B.s_target = balloc<u32>(b, NS, &ok); B.pred_ids = balloc<u64>(b, NS, &ok);
-  B.dt_key = balloc<u64>(b, (size_t)B.tot_dt + 1, &ok); B.d_doc = balloc<u32>(b, (size_t)B.tot_dt + 1, &ok);
-  B.d_first_pred_row = balloc<u32>(b, (size_t)B.tot_dt + 1, &ok);
-  B.t_pred_cnt = balloc<u32>(b, (size_t)T + 2, &ok); B.t_pred_base = balloc<u32>(b, (size_t)T + 2, &ok);
-  B.t_pred_fill = balloc<u32>(b, (size_t)T + 2, &ok); B.t_chg = balloc<u32>(b, (size_t)T + 2, &ok);
   if (!ok) return fail("device out of memory");
-  rt_memset(B.dt_key, 0, ((size_t)B.tot_dt + 1) * 8, ctx->stream);
-  rt_memset(B.d_first_pred_row, 0xFF, ((size_t)B.tot_dt + 1) * 4, ctx->stream);
   rt_memset(B.s_row, 0xFF, NS * 4, ctx->stream);
   rt_memset(B.r_doc, 0xFF, NR * 4, ctx->stream);
   // "absent column" defaults of the nullable op columns (the staged decoders skip columns no document of a wave has)
@@ -387,8 +379,6 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   rt_memset(B.r_key_off, 0, NR * 4, ctx->stream); rt_memset(B.r_key_len, 0xFF, NR * 4, ctx->stream);
   rt_memset(B.r_mark_off, 0, NR * 4, ctx->stream); rt_memset(B.r_mark_len, 0xFF, NR * 4, ctx->stream);
   rt_memset(B.r_expand, 0, NR, ctx->stream);
-  rt_memset(B.t_pred_cnt, 0, ((size_t)T + 2) * 4, ctx->stream);
-  rt_memset(B.t_pred_fill, 0, ((size_t)T + 2) * 4, ctx->stream);
   rt_memset(B.chg_actor_map, 0, ((size_t)b->tot_map + 1) * 4, ctx->stream);
   launch(ctx, AK_ACTORS, B, n);
   launch(ctx, AK_CHG_INIT, B, B.tot_chg);
@@ -409,6 +399,21 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   launch(ctx, AK_ROWS, B, B.tot_rows);
   launch(ctx, AK_OBJ_ORDER, B, B.tot_rows);
   launch(ctx, AK_SUCC, B, B.tot_succ);
+  // the delete table and the op space [0, tot_rows + tot_dt), sized for the succ entries that point at deletes
+  launch(ctx, AK_DT_SIZE, B, n);
+  if (!scan_inplace(b, B.dt_base, n, &B.tot_dt)) return fail("scan failed");
+  if (B.tot_dt == 0xFFFFFFFFu || (u64)B.tot_rows + B.tot_dt >= 0x7FFFFFFFull) return fail("batch too large: more than 2^31 ops");
+  const u32 T = B.tot_rows + B.tot_dt;
+  B.dt_key = balloc<u64>(b, (size_t)B.tot_dt + 1, &ok); B.d_doc = balloc<u32>(b, (size_t)B.tot_dt + 1, &ok);
+  B.d_first_pred_row = balloc<u32>(b, (size_t)B.tot_dt + 1, &ok);
+  B.t_pred_cnt = balloc<u32>(b, (size_t)T + 2, &ok); B.t_pred_base = balloc<u32>(b, (size_t)T + 2, &ok);
+  B.t_pred_fill = balloc<u32>(b, (size_t)T + 2, &ok); B.t_chg = balloc<u32>(b, (size_t)T + 2, &ok);
+  if (!ok) return fail("device out of memory");
+  rt_memset(B.dt_key, 0, ((size_t)B.tot_dt + 1) * 8, ctx->stream);
+  rt_memset(B.d_first_pred_row, 0xFF, ((size_t)B.tot_dt + 1) * 4, ctx->stream);
+  rt_memset(B.t_pred_cnt, 0, ((size_t)T + 2) * 4, ctx->stream);
+  rt_memset(B.t_pred_fill, 0, ((size_t)T + 2) * 4, ctx->stream);
+  launch(ctx, AK_SUCC_LINK, B, B.tot_succ);
   launch(ctx, AK_BUCKET, B, T);
   launch(ctx, AK_CHG_FINISH, B, B.tot_chg);
   // ops grouped by change

@@ -53,6 +53,8 @@ AMH_GLOBAL(k_save_store)
 AMH_GLOBAL(k_save_finish)
 AMH_GLOBAL(k_visible)
 AMH_GLOBAL(k_ht_size)
+AMH_GLOBAL(k_dt_size)
+AMH_GLOBAL(k_succ_link)
 
 // ------------------------------------------------------------------------------------------
 // Op-column decode, LDS-staged (device form of k_decode_ops; the stream decoders are the same
@@ -346,8 +348,8 @@ __global__ void __launch_bounds__(64) g_count_lds(BatchDev B) {
 #define ENC_STRIDE (ENC_K + 1)
 #define ENC_TILE (64 * ENC_STRIDE)
 
-struct EncShared {
-  u32 t0[ENC_TILE], t1[ENC_TILE], t2[ENC_TILE], t3[ENC_TILE];
+template <int NT> struct EncShared {
+  u32 t[NT][ENC_TILE];
   u32 n[64], base[64], mapb[64], pbase[64], pn[64];
 };
 
@@ -368,119 +370,123 @@ template <bool STORE> struct EncW { typedef SizeWriter T; };
 template <> struct EncW<true> { typedef FastWriter T; };
 __device__ __forceinline__ void w_init(SizeWriter& w, u8*) { sw_init(w); }
 __device__ __forceinline__ void w_init(FastWriter& w, u8* o) { fw_init(w, o); }
-__device__ __forceinline__ u32 w_done(SizeWriter& w) { return w.wide; }
-__device__ __forceinline__ u32 w_done(FastWriter& w) { fw_finish(w); return 0; }
+__device__ __forceinline__ void w_done(SizeWriter&) {}
+__device__ __forceinline__ void w_done(FastWriter& w) { fw_finish(w); }
 
-template <bool STORE>
-__global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
+// One kernel per column group G (1 object id, 2 key, 3 insert/action/predNum/expand, 4 value, 5 pred lists, 6 mark
+// names): a group's state machines and tiles alone need about half the registers and LDS of all six together, so
+// twice as many waves are resident to hide the latency of these serial per-lane loops.
+template <int G> struct EncTiles { enum { N = (G == 2 || G == 4) ? 4 : 2 }; };
+template <bool STORE, int G>
+__global__ void __launch_bounds__(64) g_encode_grp(BatchDev B) {
   typedef typename EncW<STORE>::T W;
-  __shared__ EncShared S;
+  __shared__ EncShared<EncTiles<G>::N> S;
   const u32 lane = threadIdx.x;
   const u32 c = blockIdx.x * 64 + lane;
   const bool live = c < B.tot_chg && B.status[B.c_doc[c]] == 0;
+  const u32 d = live ? B.c_doc[c] : 0;
+  if (G == 6) {   // only when a document of this wave has a mark column
+    bool has_marks = live && B.desc[d].ocol[OC_MARK_NAME].len != 0;
+    if (!__ballot(has_marks)) {
+      if (!STORE && c < B.tot_chg) B.c_col_len[(u64)c * AMH_NCOLS + 13] = 0;
+      return;
+    }
+  }
   const u32 n = live ? B.c_nops[c] : 0;
   const u32 base = live ? B.c_op_base[c] : 0;
-  const u32 d = live ? B.c_doc[c] : 0;
   const u8* chunk = B.arena + B.desc[d].chunk_off;
-  const u32 raw_col = B.desc[d].ocol[OC_VAL_RAW].off;
   u32* cl = B.c_col_len + (u64)(c < B.tot_chg ? c : 0) * AMH_NCOLS;
   S.n[lane] = n;
   S.base[lane] = base;
-  S.mapb[lane] = live ? B.c_map_base[c] : 0;
-  u32 pb = 0, pn = 0;
-  if (live && n) { pb = B.j_pred_base[base]; pn = B.j_pred_base[base + n] - pb; }
-  S.pbase[lane] = pb;
-  S.pn[lane] = pn;
+  u32 pn = 0;
+  if (G == 5) {
+    S.mapb[lane] = live ? B.c_map_base[c] : 0;
+    u32 pb = 0;
+    if (live && n) { pb = B.j_pred_base[base]; pn = B.j_pred_base[base + n] - pb; }
+    S.pbase[lane] = pb;
+    S.pn[lane] = pn;
+  }
   __syncthreads();
   const u32 n_max = wave_max_u32(n);
-  // output cursors of the store pass: columns back to back at c_cols_off (storage/change.rs:486-488).
-  // Columns the size pass flagged as "wide literal" are left to k_encode_store (in-place header widening).
-  const u32 wide_in = 0;   // the register writer widens long literal headers itself (cw_lit_close)
-  u32 wide = 0;
-  u8* col_out[AMH_NCOLS];
-  {
-    u64 off = live ? (u64)B.c_out_off[c] + B.c_cols_off[c] : 0;
-#pragma unroll
-    for (int k = 0; k < AMH_NCOLS; k++) {
-      col_out[k] = (STORE && live && cl[k] && !((wide_in >> k) & 1)) ? B.out_arena + off : (u8*)0;
-      if (STORE && live) off += cl[k];
-    }
-  }
-  u32 len_out[AMH_NCOLS];
-#pragma unroll
-  for (int k = 0; k < AMH_NCOLS; k++) len_out[k] = 0;
+  // output cursor of column k in the store pass: columns back to back at c_cols_off (storage/change.rs:486-488);
+  // long literal runs are widened in place by the register writer (cw_lit_close)
+  auto col_out = [&](int k) -> u8* {
+    if (!STORE || !live || cl[k] == 0) return (u8*)0;
+    u64 off = (u64)B.c_out_off[c] + B.c_cols_off[c];
+    for (int j = 0; j < k; j++) off += cl[j];
+    return B.out_arena + off;
+  };
+  auto put_len = [&](int k, u32 v) { if (!STORE && c < B.tot_chg) cl[k] = live ? v : 0; };
   const u32 row = lane * ENC_STRIDE;
   RleVal x; x.v = 0; x.s = 0; x.n = 0;
 
-  // ---- group 1: object id (columns 0, 1; obj_id.rs:158-172) -----------------------------------
-  {
+  if constexpr (G == 1) {   // object id (columns 0, 1; obj_id.rs:158-172)
     RleEnc<0> ea, ec; re_init(ea); re_init(ec);
-    W wa, wc; w_init(wa, col_out[0]); w_init(wc, col_out[1]);
+    W wa, wc; w_init(wa, col_out(0)); w_init(wc, col_out(1));
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
         u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
         uint2 g = ((const uint2*)B.cv[0])[j];
-        S.t0[o] = g.x; S.t1[o] = g.y;
+        S.t[0][o] = g.x; S.t[1][o] = g.y;
       });
       __syncthreads();
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
       for (u32 i = 0; i < cnt; i++) {
-        u32 oc = S.t1[row + i];
-        if (oc == 0) { re_null(wa, ea); re_null(wc, ec); }
-        else { x.v = S.t0[row + i]; re_value(wa, ea, x); x.v = oc; re_value(wc, ec, x); }
+        u32 oc = S.t[1][row + i];
+        const int m = oc == 0 ? RE_NULL : RE_VALUE;
+        x.v = S.t[0][row + i]; re_step(wa, ea, x, m);
+        x.v = oc; re_step(wc, ec, x, m);
       }
       __syncthreads();
     }
     re_finish(wa, ea); re_finish(wc, ec);
-    wide |= w_done(wa) << 0 | w_done(wc) << 1;
-    len_out[0] = wa.pos; len_out[1] = wc.pos;
+    w_done(wa); w_done(wc);
+    put_len(0, wa.pos); put_len(1, wc.pos);
   }
-  // ---- group 2: key (columns 2, 3, 4; key.rs:236-257) -----------------------------------------
-  {
+  if constexpr (G == 2) {   // key (columns 2, 3, 4; key.rs:236-257)
     RleEnc<0> ea; re_init(ea);
     DeltaEnc ec; re_init(ec.r); ec.abs = 0;
     RleEnc<2> es; re_init(es);
-    W wa, wc, ws; w_init(wa, col_out[2]); w_init(wc, col_out[3]); w_init(ws, col_out[4]);
+    W wa, wc, ws; w_init(wa, col_out(2)); w_init(wc, col_out(3)); w_init(ws, col_out(4));
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
         u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
         uint4 g = ((const uint4*)B.cv[2])[j];
-        S.t0[o] = g.x; S.t1[o] = g.y; S.t2[o] = g.z; S.t3[o] = g.w;
+        S.t[0][o] = g.x; S.t[1][o] = g.y; S.t[2][o] = g.z; S.t[3][o] = g.w;
       });
       __syncthreads();
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
       for (u32 i = 0; i < cnt; i++) {
-        u32 ka = S.t0[row + i], kc = S.t1[row + i], kl = S.t3[row + i];
-        if (ka == AMH_NULL32) re_null(wa, ea); else { x.v = ka; re_value(wa, ea, x); }
-        if (kc == AMH_NULL32) re_null(wc, ec.r); else de_value(wc, ec, (i64)kc);
-        if (kl == AMH_NULL32) re_null(ws, es);
-        else { RleVal sv; sv.v = 0; sv.s = chunk + S.t2[row + i]; sv.n = kl; re_value(ws, es, sv); }
+        u32 ka = S.t[0][row + i], kc = S.t[1][row + i], kl = S.t[3][row + i];
+        x.v = ka; re_step(wa, ea, x, ka == AMH_NULL32 ? RE_NULL : RE_VALUE);
+        de_step(wc, ec, (i64)kc, kc == AMH_NULL32);
+        RleVal sv; sv.v = 0; sv.s = chunk + S.t[2][row + i]; sv.n = kl;
+        re_step(ws, es, sv, kl == AMH_NULL32 ? RE_NULL : RE_VALUE);
       }
       __syncthreads();
     }
     re_finish(wa, ea); re_finish(wc, ec.r); re_finish(ws, es);
-    wide |= w_done(wa) << 2 | w_done(wc) << 3 | w_done(ws) << 4;
-    len_out[2] = wa.pos; len_out[3] = wc.pos; len_out[4] = ws.pos;
+    w_done(wa); w_done(wc); w_done(ws);
+    put_len(2, wa.pos); put_len(3, wc.pos); put_len(4, ws.pos);
   }
-  // ---- group 3: insert, action, predNum, expand (columns 5, 6, 9, 12) -------------------------
-  {
+  if constexpr (G == 3) {   // insert, action, predNum, expand (columns 5, 6, 9, 12)
     bool ins_last = false, exp_last = false, exp_any = false;
     u64 ins_cnt = 0, exp_cnt = 0;
     RleEnc<0> eact, epn; re_init(eact); re_init(epn);
-    W wi, wact, wpn, wex; w_init(wi, col_out[5]); w_init(wact, col_out[6]); w_init(wpn, col_out[9]); w_init(wex, col_out[12]);
+    W wi, wact, wpn, wex; w_init(wi, col_out(5)); w_init(wact, col_out(6)); w_init(wpn, col_out(9)); w_init(wex, col_out(12));
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
         u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
         uint2 g = ((const uint2*)B.cv[6])[j];
-        S.t0[o] = g.x; S.t1[o] = g.y;
+        S.t[0][o] = g.x; S.t[1][o] = g.y;
       });
       __syncthreads();
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
       for (u32 i = 0; i < cnt; i++) {
-        u32 f = S.t0[row + i];
+        u32 f = S.t[0][row + i];
         bool_feed(wi, ins_last, ins_cnt, (f & 1) != 0);
         x.v = f >> 8; re_value(wact, eact, x);
-        x.v = S.t1[row + i]; re_value(wpn, epn, x);
+        x.v = S.t[1][row + i]; re_value(wpn, epn, x);
         bool ex = (f & 2) != 0;
         exp_any = exp_any || ex;
         bool_feed(wex, exp_last, exp_cnt, ex);
@@ -490,106 +496,109 @@ __global__ void __launch_bounds__(64) g_encode_lds(BatchDev B) {
     if (ins_cnt > 0) cw_uleb(wi, ins_cnt);
     re_finish(wact, eact); re_finish(wpn, epn);
     if (exp_any && exp_cnt > 0) cw_uleb(wex, exp_cnt);   // MaybeBoolean: nothing unless a true was appended (boolean.rs:131-137)
-    wide |= w_done(wi) << 5 | w_done(wact) << 6 | w_done(wpn) << 9 | w_done(wex) << 12;
-    len_out[5] = wi.pos; len_out[6] = wact.pos; len_out[9] = wpn.pos; len_out[12] = exp_any ? wex.pos : 0;
+    w_done(wi); w_done(wact); w_done(wpn); w_done(wex);
+    put_len(5, wi.pos); put_len(6, wact.pos); put_len(9, wpn.pos); put_len(12, exp_any ? wex.pos : 0);
   }
-  // ---- group 4: value (columns 7, 8; value.rs:320-369, op_as_changeop.rs:94-103) --------------
-  {
+  if constexpr (G == 4) {   // value (columns 7, 8; value.rs:320-369, op_as_changeop.rs:94-103)
     RleEnc<0> em; re_init(em);
-    W wm, wr; w_init(wm, col_out[7]); w_init(wr, col_out[8]);
+    W wm, wr; w_init(wm, col_out(7)); w_init(wr, col_out(8));
     for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
       enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
         u32 j = S.base[l] + i, o = l * ENC_STRIDE + k;
         uint4 g = ((const uint4*)B.cv[8])[j];
-        S.t0[o] = g.x; S.t1[o] = g.y; S.t2[o] = g.z; S.t3[o] = g.w;
+        S.t[0][o] = g.x; S.t[1][o] = g.y; S.t[2][o] = g.z; S.t[3][o] = g.w;
       });
       __syncthreads();
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
       for (u32 i = 0; i < cnt; i++) {
-        u32 hi = S.t1[row + i], kind = hi >> 8;
-        x.v = (u64)S.t0[row + i] | ((u64)(hi & 0xFF) << 32);
+        u32 hi = S.t[1][row + i], kind = hi >> 8;
+        x.v = (u64)S.t[0][row + i] | ((u64)(hi & 0xFF) << 32);
         re_value(wm, em, x);
-        if (kind == 1) cw_bytes(wr, chunk + S.t2[row + i], S.t3[row + i]);
-        else if (kind == 2) cw_sleb(wr, (i64)((u64)S.t2[row + i] | ((u64)S.t3[row + i] << 32)));
+        if (kind == 1) cw_bytes(wr, chunk + S.t[2][row + i], S.t[3][row + i]);
+        else if (kind == 2) cw_sleb(wr, (i64)((u64)S.t[2][row + i] | ((u64)S.t[3][row + i] << 32)));
       }
       __syncthreads();
     }
     re_finish(wm, em);
-    wide |= w_done(wm) << 7 | w_done(wr) << 8;
-    len_out[7] = wm.pos; len_out[8] = wr.pos;
+    w_done(wm); w_done(wr);
+    put_len(7, wm.pos); put_len(8, wr.pos);
   }
-  // ---- group 5: flattened pred lists (columns 10, 11; opid_list.rs:52-78) ---------------------
-  {
+  if constexpr (G == 5) {   // flattened pred lists (columns 10, 11; opid_list.rs:52-78)
     RleEnc<0> ea; re_init(ea);
     DeltaEnc ec; re_init(ec.r); ec.abs = 0;
-    W wa, wc; w_init(wa, col_out[10]); w_init(wc, col_out[11]);
+    W wa, wc; w_init(wa, col_out(10)); w_init(wc, col_out(11));
     const u32 p_max = wave_max_u32(pn);
     for (u32 t0 = 0; t0 < p_max; t0 += ENC_K) {
       enc_load_tile(S.pn, t0, [&](u32 l, u32 k, u32 i) {
         u64 id = B.pred_ids[S.pbase[l] + i];
-        S.t0[l * ENC_STRIDE + k] = B.chg_actor_map[S.mapb[l] + (u32)id];
-        S.t1[l * ENC_STRIDE + k] = (u32)(id >> 32);
+        S.t[0][l * ENC_STRIDE + k] = B.chg_actor_map[S.mapb[l] + (u32)id];
+        S.t[1][l * ENC_STRIDE + k] = (u32)(id >> 32);
       });
       __syncthreads();
       u32 cnt = pn > t0 ? (pn - t0 < ENC_K ? pn - t0 : ENC_K) : 0;
       for (u32 i = 0; i < cnt; i++) {
-        x.v = S.t0[row + i]; re_value(wa, ea, x);
-        de_value(wc, ec, (i64)S.t1[row + i]);
+        x.v = S.t[0][row + i]; re_value(wa, ea, x);
+        de_value(wc, ec, (i64)S.t[1][row + i]);
       }
       __syncthreads();
     }
     re_finish(wa, ea); re_finish(wc, ec.r);
-    wide |= w_done(wa) << 10 | w_done(wc) << 11;
-    len_out[10] = wa.pos; len_out[11] = wc.pos;
+    w_done(wa); w_done(wc);
+    put_len(10, wa.pos); put_len(11, wc.pos);
   }
-  // ---- group 6: mark names (column 13) — only when a document of this wave has a mark column ---
-  {
-    bool has_marks = live && B.desc[d].ocol[OC_MARK_NAME].len != 0;
-    if (__ballot(has_marks)) {
-      RleEnc<2> es; re_init(es);
-      W ws; w_init(ws, col_out[13]);
-      for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
-        enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
-          u32 t = B.ops_sorted[S.base[l] + i];
-          bool m = !op_is_del(B, t) && B.r_action[t] == 7 && B.r_mark_len[t] != AMH_NULL32;
-          S.t0[l * ENC_STRIDE + k] = m ? B.r_mark_off[t] : 0;
-          S.t1[l * ENC_STRIDE + k] = m ? B.r_mark_len[t] : AMH_NULL32;
-        });
-        __syncthreads();
-        u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
-        for (u32 i = 0; i < cnt; i++) {
-          u32 ml = S.t1[row + i];
-          if (ml == AMH_NULL32) re_null(ws, es);
-          else { RleVal sv; sv.v = 0; sv.s = chunk + S.t0[row + i]; sv.n = ml; re_value(ws, es, sv); }
-        }
-        __syncthreads();
+  if constexpr (G == 6) {   // mark names (column 13)
+    RleEnc<2> es; re_init(es);
+    W ws; w_init(ws, col_out(13));
+    for (u32 t0 = 0; t0 < n_max; t0 += ENC_K) {
+      enc_load_tile(S.n, t0, [&](u32 l, u32 k, u32 i) {
+        u32 t = B.ops_sorted[S.base[l] + i];
+        bool m = !op_is_del(B, t) && B.r_action[t] == 7 && B.r_mark_len[t] != AMH_NULL32;
+        S.t[0][l * ENC_STRIDE + k] = m ? B.r_mark_off[t] : 0;
+        S.t[1][l * ENC_STRIDE + k] = m ? B.r_mark_len[t] : AMH_NULL32;
+      });
+      __syncthreads();
+      u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
+      for (u32 i = 0; i < cnt; i++) {
+        u32 ml = S.t[1][row + i];
+        RleVal sv; sv.v = 0; sv.s = chunk + S.t[0][row + i]; sv.n = ml;
+        re_step(ws, es, sv, ml == AMH_NULL32 ? RE_NULL : RE_VALUE);
       }
-      re_finish(ws, es);
-      wide |= w_done(ws) << 13;
-      len_out[13] = ws.pos;
+      __syncthreads();
     }
+    re_finish(ws, es);
+    w_done(ws);
+    put_len(13, ws.pos);
   }
-  if (!STORE && c < B.tot_chg) {
-#pragma unroll
-    for (int k = 0; k < AMH_NCOLS; k++) cl[k] = live ? len_out[k] : 0;
-    B.c_wide[c] = live ? wide : 0;
-  }
-  (void)raw_col;
+  (void)chunk; (void)pn;
+}
+template <bool STORE>
+static void launch_encode(const BatchDev& B, hipStream_t s) {
+  const dim3 g((B.tot_chg + 63) / 64), b(64);
+  hipLaunchKernelGGL((g_encode_grp<STORE, 1>), g, b, 0, s, B);
+  hipLaunchKernelGGL((g_encode_grp<STORE, 2>), g, b, 0, s, B);
+  hipLaunchKernelGGL((g_encode_grp<STORE, 3>), g, b, 0, s, B);
+  hipLaunchKernelGGL((g_encode_grp<STORE, 4>), g, b, 0, s, B);
+  hipLaunchKernelGGL((g_encode_grp<STORE, 5>), g, b, 0, s, B);
+  hipLaunchKernelGGL((g_encode_grp<STORE, 6>), g, b, 0, s, B);
 }
 
 
 // ------------------------------------------------------------------------------------------
 // Document save, LDS-staged (device form of k_save_size / k_save_store; those remain the host-emulation form and
-// the writer of "wide literal" columns).  Same scheme as g_encode_lds with lane = document: the rows of 64 documents
+// the writer of "wide literal" columns).  Same scheme as g_encode_grp with lane = document: the rows of 64 documents
 // are gathered ENC_K at a time into LDS tiles with coalesced loads (the actor rank lookups and the value conversion
 // are done by the gathering threads, one row each), then every lane runs the reference's column encoders over its
 // own document out of LDS and writes through the 16-byte register writer.  Columns 0..8 (change metadata: a handful
 // of rows per document) are encoded by the lane straight from the change arrays.
 // ------------------------------------------------------------------------------------------
+struct SaveShared {
+  u32 t0[ENC_TILE], t1[ENC_TILE], t2[ENC_TILE], t3[ENC_TILE];
+  u32 n[64], base[64], mapb[64], pbase[64], pn[64];
+};
 template <bool STORE>
 __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
   typedef typename EncW<STORE>::T W;
-  __shared__ EncShared S;
+  __shared__ SaveShared S;
   const u32 lane = threadIdx.x;
   const u32 d = blockIdx.x * 64 + lane;
   const bool live = d < B.n_docs && B.status[d] == 0 && B.sv_status[d] == 0;
@@ -613,7 +622,7 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
     for (u32 q = 0; q < k; q++) off += cl[q];
     return B.sv_out + off;
   };
-  auto done = [&](W& w, u32 k) { wide |= w_done(w) << k; if (!STORE && d < B.n_docs) cl[k] = live ? w.pos : 0; };
+  auto done = [&](W& w, u32 k) { w_done(w); if (!STORE && d < B.n_docs) cl[k] = live ? w.pos : 0; };
   const u32 row = lane * ENC_STRIDE;
   RleVal x; x.v = 0; x.s = 0; x.n = 0;
 
@@ -641,8 +650,9 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
       for (u32 i = 0; i < cnt; i++) {
         u32 oc = S.t1[row + i];
-        if (oc == 0) { re_null(wa, ea); re_null(wc, ec); }
-        else { x.v = S.t0[row + i]; re_value(wa, ea, x); x.v = oc; re_value(wc, ec, x); }
+        const int m = oc == 0 ? RE_NULL : RE_VALUE;
+        x.v = S.t0[row + i]; re_step(wa, ea, x, m);
+        x.v = oc; re_step(wc, ec, x, m);
       }
       __syncthreads();
     }
@@ -669,10 +679,10 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
       for (u32 i = 0; i < cnt; i++) {
         u32 ka = S.t0[row + i], kc = S.t1[row + i], kl = S.t3[row + i];
-        if (ka == AMH_NULL32) re_null(wa, ea); else { x.v = ka; re_value(wa, ea, x); }
-        if (kc == AMH_NULL32) re_null(wc, ec.r); else de_value(wc, ec, (i64)kc);
-        if (kl == AMH_NULL32) re_null(ws, es);
-        else { RleVal sv; sv.v = 0; sv.s = chunk + S.t2[row + i]; sv.n = kl; re_value(ws, es, sv); }
+        x.v = ka; re_step(wa, ea, x, ka == AMH_NULL32 ? RE_NULL : RE_VALUE);
+        de_step(wc, ec, (i64)kc, kc == AMH_NULL32);
+        RleVal sv; sv.v = 0; sv.s = chunk + S.t2[row + i]; sv.n = kl;
+        re_step(ws, es, sv, kl == AMH_NULL32 ? RE_NULL : RE_VALUE);
       }
       __syncthreads();
     }
@@ -803,8 +813,8 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
         u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
         for (u32 i = 0; i < cnt; i++) {
           u32 ml = S.t1[row + i];
-          if (ml == AMH_NULL32) re_null(ws, es);
-          else { RleVal sv; sv.v = 0; sv.s = chunk + S.t0[row + i]; sv.n = ml; re_value(ws, es, sv); }
+          RleVal sv; sv.v = 0; sv.s = chunk + S.t0[row + i]; sv.n = ml;
+          re_step(ws, es, sv, ml == AMH_NULL32 ? RE_NULL : RE_VALUE);
         }
         __syncthreads();
       }
@@ -829,9 +839,9 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
     hipLaunchKernelGGL((g_save_lds<true>), dim3((B.n_docs + 63) / 64, 8), dim3(64), 0, s, B);
     return;
   }
-  if (k == AK_ENCODE_SIZE) { hipLaunchKernelGGL((g_encode_lds<false>), dim3((B.tot_chg + 63) / 64), dim3(64), 0, s, B); return; }
+  if (k == AK_ENCODE_SIZE) { launch_encode<false>(B, s); return; }
   if (k == AK_ENCODE_STORE) {
-    hipLaunchKernelGGL((g_encode_lds<true>), dim3((B.tot_chg + 63) / 64), dim3(64), 0, s, B);
+    launch_encode<true>(B, s);
     return;
   }
   dim3 grid((n + AMH_BLOCK - 1) / AMH_BLOCK), block(AMH_BLOCK);
@@ -843,7 +853,7 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
     L(AK_BUCKET, k_bucket) L(AK_CHG_FINISH, k_chg_finish) L(AK_PLACE, k_place) L(AK_PRED_SLOT_CNT, k_pred_slot_cnt) L(AK_PRED_SLOT_BASE, k_pred_slot_base) L(AK_PRED_FILL, k_pred_fill)
     L(AK_PRED_SORT, k_pred_sort) L(AK_ACTOR_MARK, k_actor_mark) L(AK_ACTOR_RANK, k_actor_rank) L(AK_CHANGE_VIEW, k_change_view)
     L(AK_ENCODE_SIZE, k_encode_size) L(AK_CHG_LAYOUT, k_chg_layout) L(AK_ENCODE_STORE, k_encode_store)
-    L(AK_CHG_HEADER, k_chg_header) L(AK_CHG_HASH, k_chg_hash) L(AK_CHG_HASH_SEQ, k_chg_hash_seq) L(AK_HEADS, k_heads) L(AK_SYNC_SIZE, k_sync_size) L(AK_SYNC_FILL, k_sync_fill) L(AK_SAVE_CHECK, k_save_check) L(AK_SAVE_SIZE, k_save_size) L(AK_SAVE_LAYOUT, k_save_layout) L(AK_SAVE_STORE, k_save_store) L(AK_SAVE_FINISH, k_save_finish) L(AK_VISIBLE, k_visible) L(AK_HT_SIZE, k_ht_size)
+    L(AK_CHG_HEADER, k_chg_header) L(AK_CHG_HASH, k_chg_hash) L(AK_CHG_HASH_SEQ, k_chg_hash_seq) L(AK_HEADS, k_heads) L(AK_SYNC_SIZE, k_sync_size) L(AK_SYNC_FILL, k_sync_fill) L(AK_SAVE_CHECK, k_save_check) L(AK_SAVE_SIZE, k_save_size) L(AK_SAVE_LAYOUT, k_save_layout) L(AK_SAVE_STORE, k_save_store) L(AK_SAVE_FINISH, k_save_finish) L(AK_VISIBLE, k_visible) L(AK_HT_SIZE, k_ht_size) L(AK_DT_SIZE, k_dt_size) L(AK_SUCC_LINK, k_succ_link)
     default: break;
   }
 #undef L

@@ -696,7 +696,6 @@ AMH_DEV u32 find_doc(const u32* base, u32 n_docs, u32 idx) {  // largest d with 
 // ------------------------------------------------------------------------------------------
 AMH_DEV void k_rows(const BatchDev& B, u32 r) {
   u32 d = B.r_doc[r];   // written by the id-counter stream of k_decode_ops; AMH_NULL32 when that document failed earlier
-  B.t_pred_cnt[r] = 0;
   B.r_inc_cnt[r] = 0;
   B.r_inc_sum[r] = 0;
   if (d == AMH_NULL32) { B.r_doc[r] = find_doc(B.row_base, B.n_docs, r); return; }
@@ -802,8 +801,14 @@ AMH_DEV int lamport_cmp(const BatchDev& B, u32 d, u32 c1, u32 a1, u32 c2, u32 a2
 // ------------------------------------------------------------------------------------------
 // K8  succ entries: ordering check, pred = inverse of succ inside the object, counter folding,
 //     delete discovery — reconstruct_document.rs:141-143, 285-287, 299-310, 347-358.
-//     Thread per succ entry.
+//     Thread per succ entry, two passes.  k_succ finds the target row of every entry; an entry without one is
+//     the pred of a delete, and is only counted (per document, in dt_base).  The delete table is then sized
+//     for the entries that need it (k_dt_size) instead of for every succ entry of the batch, and with it the
+//     op space [0, tot_rows + tot_dt) that the per-op kernels and arrays run over.  k_succ_link counts the preds
+//     of the rows and claims the delete slots.
 // ------------------------------------------------------------------------------------------
+#define AMH_PENDING32 0xFFFFFFFEu
+AMH_DEV u32 amh_pow2_at_least(u32 v) { u32 p = 1; while (p < v) p <<= 1; return p; }
 AMH_DEV void k_succ(const BatchDev& B, u32 e) {
   B.s_target[e] = AMH_EMPTY32;
   u32 r = B.s_row[e];
@@ -820,7 +825,6 @@ AMH_DEV void k_succ(const BatchDev& B, u32 e) {
   u32 tr = ht_find(B, d, pack_id(sc, sa));
   if (tr != AMH_EMPTY32 && B.r_obj_ctr[tr] == B.r_obj_ctr[r] && B.r_obj_actor[tr] == B.r_obj_actor[r]) {
     B.s_target[e] = tr;
-    amh_atomic_add(&B.t_pred_cnt[tr], 1);
     if (B.r_action[r] == 1 && (B.r_vmeta[r] & 15) == 8 && B.r_action[tr] == 5) {
       i64 inc = 0;
       if (val_int(B, tr, inc)) {
@@ -829,14 +833,28 @@ AMH_DEV void k_succ(const BatchDev& B, u32 e) {
       }
     }
   } else {
-    u32 slot = dt_claim(B, d, pack_id(sc, sa));
-    if (slot == AMH_EMPTY32) { amh_fail(B, d, AMH_E_UNSUPPORTED); return; }
-    u32 t = B.tot_rows + slot;
-    B.d_doc[slot] = d;
-    amh_atomic_min(&B.d_first_pred_row[slot], r);
-    amh_atomic_add(&B.t_pred_cnt[t], 1);
-    B.s_target[e] = t;
+    B.s_target[e] = AMH_PENDING32;
+    amh_atomic_add(&B.dt_base[d], 1);   // zero after the scan of the (still empty) table sizes: used as the counter
   }
+}
+AMH_DEV void k_dt_size(const BatchDev& B, u32 d) {
+  u32 n = B.status[d] ? 0 : B.dt_base[d];
+  B.dt_base[d] = n ? amh_pow2_at_least(2 * n) : 0;
+}
+AMH_DEV void k_succ_link(const BatchDev& B, u32 e) {
+  u32 t = B.s_target[e];
+  if (t == AMH_EMPTY32) return;
+  u32 r = B.s_row[e];
+  u32 d = B.r_doc[r];
+  if (B.status[d]) { B.s_target[e] = AMH_EMPTY32; return; }
+  if (t != AMH_PENDING32) { amh_atomic_add(&B.t_pred_cnt[t], 1); return; }
+  u32 slot = dt_claim(B, d, pack_id(B.s_ctr[e], B.s_actor[e]));
+  if (slot == AMH_EMPTY32) { B.s_target[e] = AMH_EMPTY32; amh_fail(B, d, AMH_E_UNSUPPORTED); return; }
+  t = B.tot_rows + slot;
+  B.d_doc[slot] = d;
+  amh_atomic_min(&B.d_first_pred_row[slot], r);
+  amh_atomic_add(&B.t_pred_cnt[t], 1);
+  B.s_target[e] = t;
 }
 
 // accessors over the unified op index space -------------------------------------------------
@@ -1170,54 +1188,71 @@ template <int KIND> struct RleEnc {
 };
 template <int KIND> AMH_DEV void re_init(RleEnc<KIND>& e) { e.st = 0; e.n = 0; e.lit_pos = 0; e.lit_cnt = 0; e.val.v = 0; e.val.s = 0; e.val.n = 0; }
 template <int KIND, class W> AMH_DEV void re_lit_open(W& w, RleEnc<KIND>& e) { e.lit_pos = cw_lit_open(w); e.lit_cnt = 0; }
-template <int KIND, class W> AMH_DEV void re_lit_push(W& w, RleEnc<KIND>& e, const RleVal& x) { rv_write<KIND>(w, x); e.lit_cnt++; }
 template <int KIND, class W> AMH_DEV void re_lit_close(W& w, RleEnc<KIND>& e) { cw_lit_close(w, e.lit_pos, e.lit_cnt); }
-template <int KIND, class W> AMH_DEV void re_flush_run(W& w, const RleVal& v, u64 n) { cw_sleb(w, (i64)n); rv_write<KIND>(w, v); }
-template <class W> AMH_DEV void re_flush_nulls(W& w, u64 n) { cw_sleb(w, (i64)0); cw_uleb(w, n); }
-template <int KIND, class W> AMH_DEV void re_null(W& w, RleEnc<KIND>& e) {  // rle.rs:71-90
-  switch (e.st) {
-    case 0: e.st = 1; e.n = 1; break;
-    case 1: case 2: e.n++; break;
-    case 4: re_lit_open(w, e); re_lit_push(w, e, e.val); re_lit_close(w, e); e.st = 2; e.n = 1; break;
-    case 5: re_flush_run<KIND>(w, e.val, e.n); e.st = 2; e.n = 1; break;
-    case 3: re_lit_push(w, e, e.val); re_lit_close(w, e); e.st = 2; e.n = 1; break;
+// One step of the encoder (rle.rs:31-46 finish, 71-90 append_null, 92-126 append_value).  The state machine only
+// decides WHAT is written (a set of RE_* actions on the state before the step); the bytes are produced by one copy
+// of the writer code below it.  On the device that matters twice: lanes in different states run the writer together
+// instead of one state after the other, and the code is a fraction of the size it has with the writer inlined into
+// every transition.
+enum { RE_OPEN = 1, RE_PUSH = 2, RE_CLOSE = 4, RE_RUN = 8, RE_NULLS = 16 };
+enum { RE_VALUE = 0, RE_NULL = 1, RE_FINISH = 2 };
+template <int KIND, class W> AMH_DEV void re_step(W& w, RleEnc<KIND>& e, const RleVal& x, int mode) {
+  const int st = e.st;
+  u32 f = 0;
+  int nst = st;
+  u64 nn = e.n;
+  bool take = false;
+  if (mode == RE_VALUE) {
+    const bool eq = (st == 3 || st == 4 || st == 5) && rv_eq<KIND>(e.val, x);
+    switch (st) {
+      case 0: nst = 4; take = true; break;
+      case 4: if (eq) { nst = 5; nn = 2; } else { f = RE_OPEN | RE_PUSH; nst = 3; take = true; } break;
+      case 5: if (eq) nn++; else { f = RE_RUN; nst = 4; take = true; } break;
+      case 3: if (eq) { f = RE_CLOSE; nst = 5; nn = 2; } else { f = RE_PUSH; take = true; } break;
+      default: f = RE_NULLS; nst = 4; take = true; break;   // 1, 2
+    }
+  } else if (mode == RE_NULL) {
+    switch (st) {
+      case 0: nst = 1; nn = 1; break;
+      case 1: case 2: nn++; break;
+      case 4: f = RE_OPEN | RE_PUSH | RE_CLOSE; nst = 2; nn = 1; break;
+      case 5: f = RE_RUN; nst = 2; nn = 1; break;
+      default: f = RE_PUSH | RE_CLOSE; nst = 2; nn = 1; break;   // 3
+    }
+  } else {
+    switch (st) {
+      case 2: f = RE_NULLS; break;
+      case 4: f = RE_OPEN | RE_PUSH | RE_CLOSE; break;
+      case 5: f = RE_RUN; break;
+      case 3: f = RE_PUSH | RE_CLOSE; break;
+      default: break;   // Empty, InitialNullRun: nothing (rle.rs:33)
+    }
   }
-}
-template <int KIND, class W> AMH_DEV void re_value(W& w, RleEnc<KIND>& e, const RleVal& x) {  // rle.rs:92-126
-  switch (e.st) {
-    case 0: e.st = 4; e.val = x; break;
-    case 4:
-      if (rv_eq<KIND>(e.val, x)) { e.st = 5; e.n = 2; }
-      else { re_lit_open(w, e); re_lit_push(w, e, e.val); e.val = x; e.st = 3; }
-      break;
-    case 5:
-      if (rv_eq<KIND>(e.val, x)) e.n++;
-      else { re_flush_run<KIND>(w, e.val, e.n); e.st = 4; e.val = x; }
-      break;
-    case 3:
-      if (rv_eq<KIND>(e.val, x)) { re_lit_close(w, e); e.st = 5; e.n = 2; }
-      else { re_lit_push(w, e, e.val); e.val = x; }
-      break;
-    case 1: case 2: re_flush_nulls(w, e.n); e.st = 4; e.val = x; break;
+  if (f) {
+    if (f & RE_OPEN) re_lit_open(w, e);
+    if (f & RE_RUN) cw_sleb(w, (i64)e.n);
+    if (f & RE_NULLS) { cw_sleb(w, (i64)0); cw_uleb(w, e.n); }
+    if (f & (RE_PUSH | RE_RUN)) { rv_write<KIND>(w, e.val); if (f & RE_PUSH) e.lit_cnt++; }
+    if (f & RE_CLOSE) re_lit_close(w, e);
   }
+  e.st = nst;
+  e.n = nn;
+  if (take) e.val = x;
 }
-template <int KIND, class W> AMH_DEV void re_finish(W& w, RleEnc<KIND>& e) {  // rle.rs:31-46
-  switch (e.st) {
-    case 2: re_flush_nulls(w, e.n); break;
-    case 4: re_lit_open(w, e); re_lit_push(w, e, e.val); re_lit_close(w, e); break;
-    case 5: re_flush_run<KIND>(w, e.val, e.n); break;
-    case 3: re_lit_push(w, e, e.val); re_lit_close(w, e); break;
-    default: break;  // Empty, InitialNullRun: nothing (rle.rs:33)
-  }
-}
+template <int KIND, class W> AMH_DEV void re_null(W& w, RleEnc<KIND>& e) { RleVal x; x.v = 0; x.s = 0; x.n = 0; re_step(w, e, x, RE_NULL); }
+template <int KIND, class W> AMH_DEV void re_value(W& w, RleEnc<KIND>& e, const RleVal& x) { re_step(w, e, x, RE_VALUE); }
+template <int KIND, class W> AMH_DEV void re_finish(W& w, RleEnc<KIND>& e) { RleVal x; x.v = 0; x.s = 0; x.n = 0; re_step(w, e, x, RE_FINISH); }
 struct DeltaEnc { RleEnc<1> r; i64 abs; };
-template <class W> AMH_DEV void de_value(W& w, DeltaEnc& e, i64 v) {  // delta.rs:23-27
-  i64 dlt;
-  if (__builtin_sub_overflow(v, e.abs, &dlt)) dlt = v > e.abs ? INT64_MAX : INT64_MIN;
+template <class W> AMH_DEV void de_step(W& w, DeltaEnc& e, i64 v, bool isnull) {  // delta.rs:23-27, 30-32
+  i64 dlt = 0;
+  if (!isnull) {
+    if (__builtin_sub_overflow(v, e.abs, &dlt)) dlt = v > e.abs ? INT64_MAX : INT64_MIN;
+    e.abs = v;
+  }
   RleVal x; x.v = (u64)dlt; x.s = 0; x.n = 0;
-  re_value<1>(w, e.r, x);
-  e.abs = v;
+  re_step<1>(w, e.r, x, isnull ? RE_NULL : RE_VALUE);
 }
+template <class W> AMH_DEV void de_value(W& w, DeltaEnc& e, i64 v) { de_step(w, e, v, false); }
 
 // the value an op carries into a change (op_as_changeop.rs:94-103): kind 0 = null, 1 = stored
 // bytes as they are, 2 = integer re-encoded as Int (increments)
@@ -1986,7 +2021,6 @@ AMH_DEV void k_save_finish(const BatchDev& B, u32 d) {
 // ------------------------------------------------------------------------------------------
 // small glue kernels
 // ------------------------------------------------------------------------------------------
-AMH_DEV u32 amh_pow2_at_least(u32 v) { u32 p = 1; while (p < v) p <<= 1; return p; }
 // id table of a document: direct when actors x (highest counter + 1) stays within 8 slots per row, else a hash
 // region of at least twice the rows.  doc_max_op is final here (op ids and succ ids, k_decode_ops).  Thread per document.
 AMH_DEV void k_ht_size(const BatchDev& B, u32 d) {
@@ -2012,7 +2046,7 @@ AMH_DEV void k_extract(const BatchDev& B, u32 d) {
   B.dep_base[d] = deps;
   B.actor_base[d] = na;
   B.ht_base[d] = 0;   // the id tables are sized after the decode, when the highest counter is known (k_ht_size)
-  B.dt_base[d] = succ ? amh_pow2_at_least(2 * succ) : 0;
+  B.dt_base[d] = 0;   // the delete table is sized after k_succ, for the succ entries that point at deletes (k_dt_size)
   u64 m = (u64)chg * na;
   B.map_base[d] = m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)m;
   B.doc_max_op[d] = 0;

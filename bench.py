@@ -59,6 +59,8 @@ def algorithmic_bytes(st, cols):
         "chg_hash_seq": Eout,
         "heads": 64 * C + 40 * D,
         "ht_size": 24 * D,
+        "dt_size": 8 * D,
+        "succ_link": 8 * S + 4 * S,
         "visible": 12 * R + 2 * R,
         "scan": 8 * (9 * D + 2 * C + T),
     }
