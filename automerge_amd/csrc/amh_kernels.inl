@@ -1056,10 +1056,18 @@ AMH_DEV void fw_put(FastWriter& w, u64 x, u32 n) {
   }
   w.na = na;
 }
-AMH_DEV void fw_finish(FastWriter& w) {
+AMH_DEV void fw_finish(FastWriter& w) {   // the 0..15 bytes still in the registers: at most four stores (8, 4, 2, 1)
   if (!w.out) return;
   u8* o = w.out + (w.pos - w.na);
-  for (u32 i = 0; i < w.na; i++) o[i] = (u8)((i < 8 ? w.a0 >> (8 * i) : w.a1 >> (8 * (i - 8))) & 0xFF);
+  u32 na = w.na;
+  u64 a = w.a0;
+  struct __attribute__((packed)) P8 { u64 v; };
+  struct __attribute__((packed)) P4 { u32 v; };
+  struct __attribute__((packed)) P2 { unsigned short v; };
+  if (na & 8) { ((P8*)o)->v = a; o += 8; a = w.a1; }
+  if (na & 4) { ((P4*)o)->v = (u32)a; o += 4; a >>= 32; }
+  if (na & 2) { ((P2*)o)->v = (unsigned short)a; o += 2; a >>= 16; }
+  if (na & 1) *o = (u8)a;
   w.na = 0; w.a0 = 0; w.a1 = 0;
 }
 // spread the low 56 bits of v into eight 7-bit groups, one per byte
