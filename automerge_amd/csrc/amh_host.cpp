@@ -437,8 +437,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   if (!scan_inplace(b, B.j_pred_base, tot_ops, nullptr)) return fail("scan failed");
   launch(ctx, AK_PRED_SLOT_BASE, B, tot_ops);
   launch(ctx, AK_PRED_FILL, B, B.tot_succ);
-  launch(ctx, AK_PRED_SORT, B, T);
-  launch(ctx, AK_ACTOR_MARK, B, T);
+  launch(ctx, AK_PRED_SORT, B, T);   // + the actors each op refers to (k_actor_mark), in the same pass over the pred lists
   launch(ctx, AK_ACTOR_RANK, B, B.tot_chg);
   for (int k = 0; k < 12; k++) B.cv[k] = nullptr;   // one interleaved array per column group: obj (2 fields), key (4), misc (2), value (4)
   B.cv[0] = balloc<u32>(b, 2 * ((size_t)tot_ops + 1), &ok); B.cv[2] = balloc<u32>(b, 4 * ((size_t)tot_ops + 1), &ok);

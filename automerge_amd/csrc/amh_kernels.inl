@@ -944,18 +944,21 @@ AMH_DEV void k_pred_fill(const BatchDev& B, u32 e) {
   u32 pos = B.t_pred_base[t] + amh_atomic_add(&B.t_pred_fill[t], 1);
   B.pred_ids[pos] = pack_id(B.r_id_ctr[r], B.r_id_actor[r]);
 }
+AMH_DEV void k_actor_mark(const BatchDev& B, u32 t);
 AMH_DEV void k_pred_sort(const BatchDev& B, u32 t) {
   u32 n = B.t_pred_cnt[t];
-  if (n < 2) return;
-  u32 d = op_doc(B, t);
-  if (B.status[d]) return;
-  u64* v = B.pred_ids + B.t_pred_base[t];
-  for (u32 i = 1; i < n; i++) {
-    u64 x = v[i];
-    u32 j = i;
-    while (j > 0 && lamport_cmp(B, d, (u32)(v[j - 1] >> 32), (u32)v[j - 1], (u32)(x >> 32), (u32)x) > 0) { v[j] = v[j - 1]; j--; }
-    v[j] = x;
+  if (n >= 2) {
+    u32 d = op_doc(B, t);
+    if (B.status[d]) return;
+    u64* v = B.pred_ids + B.t_pred_base[t];
+    for (u32 i = 1; i < n; i++) {
+      u64 x = v[i];
+      u32 j = i;
+      while (j > 0 && lamport_cmp(B, d, (u32)(v[j - 1] >> 32), (u32)v[j - 1], (u32)(x >> 32), (u32)x) > 0) { v[j] = v[j - 1]; j--; }
+      v[j] = x;
+    }
   }
+  k_actor_mark(B, t);   // same thread, same pred list: the actors this op contributes to its change's table
 }
 
 // op views used by the actor table and the encoder -------------------------------------------
@@ -1541,38 +1544,68 @@ AMH_DEV void k_chg_header(const BatchDev& B, u32 c) {
   u8* out = B.out_arena + B.c_out_off[c];
   u32 body_len = B.c_body_len[c];
   u32 hdr = B.c_out_len[c] - body_len;
-  u32 pos = hdr;
   u32 nd = B.c_ndeps[c];
-  pos += wr_uleb(out + pos, nd);
-  pos += 32 * nd;   // filled in by k_chg_hash
+  // both runs of header bytes go through the 16-byte register writer: magic, checksum slot (k_chg_hash), type,
+  // length, dep count | (dep hashes: k_chg_hash) | actor .. column metadata
+  FastWriter w;
+  fw_init(w, out);
+  fw_put(w, 0x00000000834a6f85ull, 8);
+  fw_put(w, 1, 1);
+  cw_uleb(w, body_len);
+  cw_uleb(w, nd);
+  fw_finish(w);
+  u32 pos = w.pos + 32 * nd;
+  fw_init(w, out + pos);
   u32 a = ab + B.c_actor[c];
-  pos += wr_uleb(out + pos, B.actor_len[a]);
-  for (u32 b = 0; b < B.actor_len[a]; b++) out[pos++] = chunk[B.actor_off[a] + b];
-  pos += wr_uleb(out + pos, B.c_seq[c]);
-  pos += wr_uleb(out + pos, B.c_start_op[c]);
-  pos += wr_sleb(out + pos, B.c_time[c]);
+  cw_uleb(w, B.actor_len[a]);
+  cw_bytes(w, chunk + B.actor_off[a], B.actor_len[a]);
+  cw_uleb(w, B.c_seq[c]);
+  cw_uleb(w, B.c_start_op[c]);
+  cw_sleb(w, B.c_time[c]);
   u32 ml = B.c_msg_len[c] == AMH_NULL32 ? 0 : B.c_msg_len[c];
-  pos += wr_uleb(out + pos, ml);
-  for (u32 b = 0; b < ml; b++) out[pos++] = chunk[B.c_msg_off[c] + b];
-  pos += wr_uleb(out + pos, B.c_n_other[c]);
+  cw_uleb(w, ml);
+  cw_bytes(w, chunk + B.c_msg_off[c], ml);
+  cw_uleb(w, B.c_n_other[c]);
   const u32* amap = B.chg_actor_map + B.c_map_base[c];
   for (u32 k = 0; k < na; k++) {  // other actors in bytewise order
     u32 oa = B.actor_by_rank[ab + k];
     if (amap[oa] == AMH_EMPTY32 || amap[oa] == 0) continue;
-    pos += wr_uleb(out + pos, B.actor_len[ab + oa]);
-    for (u32 b = 0; b < B.actor_len[ab + oa]; b++) out[pos++] = chunk[B.actor_off[ab + oa] + b];
+    cw_uleb(w, B.actor_len[ab + oa]);
+    cw_bytes(w, chunk + B.actor_off[ab + oa], B.actor_len[ab + oa]);
   }
   const u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
   u32 ncols = 0, data = 0;
   for (u32 k = 0; k < AMH_NCOLS; k++) if (cl[k]) ncols++;
-  pos += wr_uleb(out + pos, ncols);
+  cw_uleb(w, ncols);
   for (u32 k = 0; k < AMH_NCOLS; k++)
-    if (cl[k]) { pos += wr_uleb(out + pos, chg_spec(k)); pos += wr_uleb(out + pos, cl[k]); data += cl[k]; }
-  pos += data;  // column data was written by the store pass at c_cols_off
-  for (u32 b = 0; b < B.c_extra_len[c]; b++) out[pos++] = chunk[B.c_extra_off[c] + b];
-  out[0] = 0x85; out[1] = 0x6f; out[2] = 0x4a; out[3] = 0x83;
-  out[8] = 1;
-  wr_uleb(out + 9, body_len);
+    if (cl[k]) { cw_uleb(w, chg_spec(k)); cw_uleb(w, cl[k]); data += cl[k]; }
+  fw_finish(w);
+  pos += w.pos + data;  // column data was written by the store pass at c_cols_off
+  u32 el = B.c_extra_len[c];
+  if (el) {
+    fw_init(w, out + pos);
+    cw_bytes(w, chunk + B.c_extra_off[c], el);
+    fw_finish(w);
+  }
+}
+// a 32-byte hash as four big-endian words: bytewise order = lexicographic order of the words
+struct Hash4 { u64 w[4]; };
+AMH_DEV Hash4 hash4_load(const u8* p) {   // any alignment
+  struct __attribute__((packed)) P8 { u64 v; };
+  Hash4 h;
+  for (int i = 0; i < 4; i++) h.w[i] = ((const P8*)p)[i].v;
+  return h;
+}
+AMH_DEV void hash4_store(u8* p, const Hash4& h) {
+  struct __attribute__((packed)) P8 { u64 v; };
+  for (int i = 0; i < 4; i++) ((P8*)p)[i].v = h.w[i];
+}
+AMH_DEV bool hash4_greater(const Hash4& a, const Hash4& b) {
+  for (int i = 0; i < 4; i++) {
+    u64 x = __builtin_bswap64(a.w[i]), y = __builtin_bswap64(b.w[i]);
+    if (x != y) return x > y;
+  }
+  return false;
 }
 AMH_DEV void chg_hash_one(const BatchDev& B, u32 c, u32 cb) {
   u8* out = B.out_arena + B.c_out_off[c];
@@ -1582,13 +1615,15 @@ AMH_DEV void chg_hash_one(const BatchDev& B, u32 c, u32 cb) {
   u8* deps = out + hdr + uleb_size(nd);
   // deps: hashes of earlier changes, sorted (change_collector.rs:178; change.rs:335-341)
   for (u32 k = 0; k < nd; k++) {
-    const u8* h = B.c_hash + (u64)(cb + B.dep_idx[B.c_dep_base[c] + k]) * 32;
+    Hash4 h = hash4_load(B.c_hash + (u64)(cb + B.dep_idx[B.c_dep_base[c] + k]) * 32);
     u32 j = k;
-    while (j > 0 && amh_memcmp(deps + 32 * (j - 1), 32, h, 32) > 0) {
-      for (int b = 0; b < 32; b++) deps[32 * j + b] = deps[32 * (j - 1) + b];
+    while (j > 0) {
+      Hash4 prev = hash4_load(deps + 32 * (j - 1));
+      if (!hash4_greater(prev, h)) break;
+      hash4_store(deps + 32 * j, prev);
       j--;
     }
-    for (int b = 0; b < 32; b++) deps[32 * j + b] = h[b];
+    hash4_store(deps + 32 * j, h);
   }
   u8* h = B.c_hash + (u64)c * 32;
   sha256_contig(out + 8, (u64)(hdr - 8) + body_len, h);
@@ -1655,8 +1690,12 @@ AMH_DEV bool same_group(const BatchDev& B, u32 a, u32 b) {  // same object and s
   bool ap = B.r_key_len[a] != AMH_NULL32 && !B.r_insert[a], bp = B.r_key_len[b] != AMH_NULL32 && !B.r_insert[b];
   if (ap != bp) return false;
   if (ap) {
+    if (B.r_key_len[a] != B.r_key_len[b]) return false;
     const u8* chunk = B.arena + B.desc[B.r_doc[a]].chunk_off;
-    return amh_memcmp(chunk + B.r_key_off[a], B.r_key_len[a], chunk + B.r_key_off[b], B.r_key_len[b]) == 0;
+    RleVal x, y;   // eight bytes per step (rv_eq), not one
+    x.v = 0; x.s = chunk + B.r_key_off[a]; x.n = B.r_key_len[a];
+    y.v = 0; y.s = chunk + B.r_key_off[b]; y.n = x.n;
+    return rv_eq<2>(x, y);
   }
   u32 aa = B.r_insert[a] ? B.r_id_actor[a] : B.r_key_actor[a], ac = B.r_insert[a] ? B.r_id_ctr[a] : B.r_key_ctr[a];
   u32 ba = B.r_insert[b] ? B.r_id_actor[b] : B.r_key_actor[b], bc = B.r_insert[b] ? B.r_id_ctr[b] : B.r_key_ctr[b];
