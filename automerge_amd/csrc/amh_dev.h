@@ -203,9 +203,27 @@ AMH_DEV u32 wr_sleb(u8* out, i64 v) {
   }
 }
 
+AMH_DEV u64 amh_peek8_any(const u8* p) {   // 8 bytes at any address; reads at most 11 bytes past p (the arena is padded)
+  u64 a = (u64)p;
+  const u32* w = (const u32*)(a & ~(u64)3);
+  u32 w0 = w[0], w1 = w[1], w2 = w[2];
+  u32 sh = (u32)(a & 3) * 8;
+  u64 lo = (u64)w0 | ((u64)w1 << 32);
+  return sh ? (lo >> sh) | ((u64)w2 << (64 - sh)) : lo;
+}
+
 // Rust str::from_utf8 acceptance
 AMH_DEV_NOINLINE bool amh_valid_utf8(const u8* s, u64 n) {
   u64 i = 0;
+  // ASCII, eight bytes per step (nearly every key and most values); the first byte with its high bit set starts the
+  // general loop at a character boundary
+  while (i < n) {
+    u64 w = amh_peek8_any(s + i);
+    u64 r = n - i;
+    if (r < 8) w &= ((u64)1 << (8 * r)) - 1;
+    if (w & 0x8080808080808080ull) break;
+    i += r < 8 ? r : 8;
+  }
   while (i < n) {
     u8 b = s[i];
     if (b < 0x80) { i++; continue; }

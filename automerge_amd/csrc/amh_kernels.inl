@@ -1103,14 +1103,6 @@ AMH_DEV void cw_sleb(FastWriter& w, i64 v) {
   u64 g8 = (u64)(v >> 56) & 0x7f, g9 = (u64)(v >> 63) & 0x7f;
   if (nb == 9) fw_put(w, g8, 1); else fw_put(w, (g8 | 0x80) | (g9 << 8), 2);
 }
-AMH_DEV u64 amh_peek8_any(const u8* p) {   // 8 bytes at any address; reads at most 11 bytes past p (the arena is padded)
-  u64 a = (u64)p;
-  const u32* w = (const u32*)(a & ~(u64)3);
-  u32 w0 = w[0], w1 = w[1], w2 = w[2];
-  u32 sh = (u32)(a & 3) * 8;
-  u64 lo = (u64)w0 | ((u64)w1 << 32);
-  return sh ? (lo >> sh) | ((u64)w2 << (64 - sh)) : lo;
-}
 AMH_DEV void cw_bytes(FastWriter& w, const u8* p, u32 n) {
   if (!w.out) { w.pos += n; return; }
   u32 i = 0;
