@@ -458,9 +458,14 @@ __global__ void __launch_bounds__(64) g_encode_grp(BatchDev B) {
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
       for (u32 i = 0; i < cnt; i++) {
         u32 ka = S.t[0][row + i], kc = S.t[1][row + i], kl = S.t[3][row + i];
+        const bool inl = kl != AMH_NULL32 && (kl & AMH_CV_INLINE);   // short map key: its bytes are in fields 0, 1
+        RleVal sv;
+        sv.v = inl ? (u64)ka | ((u64)kc << 32) : 0;
+        sv.s = inl ? (const u8*)0 : chunk + S.t[2][row + i];
+        sv.n = inl ? (kl & 0xFF) : kl;
+        if (inl) { ka = AMH_NULL32; kc = AMH_NULL32; }
         x.v = ka; re_step(wa, ea, x, ka == AMH_NULL32 ? RE_NULL : RE_VALUE);
         de_step(wc, ec, (i64)kc, kc == AMH_NULL32);
-        RleVal sv; sv.v = 0; sv.s = chunk + S.t[2][row + i]; sv.n = kl;
         re_step(ws, es, sv, kl == AMH_NULL32 ? RE_NULL : RE_VALUE);
       }
       __syncthreads();
@@ -511,10 +516,11 @@ __global__ void __launch_bounds__(64) g_encode_grp(BatchDev B) {
       __syncthreads();
       u32 cnt = n > t0 ? (n - t0 < ENC_K ? n - t0 : ENC_K) : 0;
       for (u32 i = 0; i < cnt; i++) {
-        u32 hi = S.t[1][row + i], kind = hi >> 8;
+        u32 hi = S.t[1][row + i], kind = (hi >> 8) & 0xFF;
         x.v = (u64)S.t[0][row + i] | ((u64)(hi & 0xFF) << 32);
         re_value(wm, em, x);
-        if (kind == 1) cw_bytes(wr, chunk + S.t[2][row + i], S.t[3][row + i]);
+        if (kind == 3) cw_inline(wr, (u64)S.t[2][row + i] | ((u64)S.t[3][row + i] << 32), (hi >> 16) & 0xF);
+        else if (kind == 1) cw_bytes(wr, chunk + S.t[2][row + i], S.t[3][row + i]);
         else if (kind == 2) cw_sleb(wr, (i64)((u64)S.t[2][row + i] | ((u64)S.t[3][row + i] << 32)));
       }
       __syncthreads();

@@ -1092,11 +1092,16 @@ AMH_DEV void cw_uleb(FastWriter& w, u64 v) {
   u32 rb = nb - 8;
   fw_put(w, amh_leb_spread(rest) | amh_cont_bits(rb), rb);
 }
+#define AMH_CV_INLINE 0x80000000u
+AMH_DEV u64 amh_low_bytes(u32 n) { return n >= 8 ? ~(u64)0 : (((u64)1 << (8 * n)) - 1); }   // mask of the low n bytes
+AMH_DEV u64 sleb_bytes8(i64 v, u32 nb) {   // the nb <= 8 bytes of sleb128(v), low byte first
+  u64 m = nb == 8 ? (u64)v & 0x00ffffffffffffffull : (u64)v & (((u64)1 << (7 * nb)) - 1);
+  return amh_leb_spread(m) | amh_cont_bits(nb);
+}
 AMH_DEV void cw_sleb(FastWriter& w, i64 v) {
   u32 nb = sleb_size_fast(v);
   if (nb <= 8) {
-    u64 m = nb == 8 ? (u64)v & 0x00ffffffffffffffull : (u64)v & (((u64)1 << (7 * nb)) - 1);
-    fw_put(w, amh_leb_spread(m) | amh_cont_bits(nb), nb);
+    fw_put(w, sleb_bytes8(v, nb), nb);
     return;
   }
   fw_put(w, amh_leb_spread((u64)v & 0x00ffffffffffffffull) | 0x8080808080808080ull, 8);
@@ -1109,6 +1114,8 @@ AMH_DEV void cw_bytes(FastWriter& w, const u8* p, u32 n) {
   for (; i + 8 <= n; i += 8) fw_put(w, amh_peek8_any(p + i), 8);
   if (i < n) { u32 r = n - i; fw_put(w, amh_peek8_any(p + i) & (((u64)1 << (8 * r)) - 1), r); }
 }
+AMH_DEV void cw_inline(FastWriter& w, u64 bytes, u32 n) { if (n) fw_put(w, bytes, n); }   // n <= 8 bytes held in a register
+AMH_DEV void cw_inline(SizeWriter& w, u64, u32 n) { w.pos += n; }
 AMH_DEV void cw_uleb(SizeWriter& w, u64 v) { w.pos += uleb_size_fast(v); }
 AMH_DEV void cw_sleb(SizeWriter& w, i64 v) { w.pos += sleb_size_fast(v); }
 AMH_DEV void cw_bytes(SizeWriter& w, const u8*, u32 n) { w.pos += n; }
@@ -1116,6 +1123,10 @@ AMH_DEV void cw_uleb(ColWriter& w, u64 v) { w.pos += wr_uleb(w.out ? w.out + w.p
 AMH_DEV void cw_sleb(ColWriter& w, i64 v) { w.pos += wr_sleb(w.out ? w.out + w.pos : (u8*)0, v); }
 AMH_DEV void cw_bytes(ColWriter& w, const u8* p, u32 n) {
   if (w.out) for (u32 i = 0; i < n; i++) w.out[w.pos + i] = p[i];
+  w.pos += n;
+}
+AMH_DEV void cw_inline(ColWriter& w, u64 bytes, u32 n) {
+  if (w.out) for (u32 i = 0; i < n; i++) w.out[w.pos + i] = (u8)(bytes >> (8 * i));
   w.pos += n;
 }
 // literal-run header: one byte reserved at open, written at close (rle.rs:112-119, 128-133)
@@ -1165,9 +1176,14 @@ AMH_DEV void cw_lit_close(FastWriter& w, u32 at, u64 cnt) {
 // one-byte header slot which is widened in place if the run turns out longer than 64 values.
 // KIND 0 = u64, 1 = i64, 2 = string (value = pointer + length)
 struct RleVal { u64 v; const u8* s; u32 n; };
+// KIND 2: s == null means the string's n <= 8 bytes are in v (change view, short keys)
 template <int KIND> AMH_DEV bool rv_eq(const RleVal& a, const RleVal& b) {
   if (KIND != 2) return a.v == b.v;
   if (a.n != b.n) return false;
+  if (!a.s || !b.s) {
+    u64 x = a.s ? amh_peek8_any(a.s) & amh_low_bytes(a.n) : a.v, y = b.s ? amh_peek8_any(b.s) & amh_low_bytes(b.n) : b.v;
+    return x == y;
+  }
   if (a.s == b.s) return true;
   for (u32 i = 0; i < a.n; i += 8) {
     u64 d = amh_peek8_any(a.s + i) ^ amh_peek8_any(b.s + i);
@@ -1180,7 +1196,7 @@ template <int KIND> AMH_DEV bool rv_eq(const RleVal& a, const RleVal& b) {
 template <int KIND, class W> AMH_DEV void rv_write(W& w, const RleVal& x) {
   if (KIND == 0) cw_uleb(w, x.v);
   else if (KIND == 1) cw_sleb(w, (i64)x.v);
-  else { cw_uleb(w, (u64)x.n); cw_bytes(w, x.s, x.n); }
+  else { cw_uleb(w, (u64)x.n); if (x.s) cw_bytes(w, x.s, x.n); else cw_inline(w, x.v, x.n); }
 }
 template <int KIND> struct RleEnc {
   int st;        // 0 Empty 1 InitialNullRun 2 NullRun 3 LiteralRun 4 LoneVal 5 Run
@@ -1432,11 +1448,21 @@ AMH_DEV void k_change_view(const BatchDev& B, u32 j) {
   u32* g_val = B.cv[8] + 4 * (u64)j;
   g_obj[0] = oc ? amap[B.r_obj_actor[kr]] : AMH_NULL32;
   g_obj[1] = oc;
+  const u8* chunk = B.arena + B.desc[B.c_doc[c]].chunk_off;
   OpKey ky = op_key(B, t);
-  g_key[0] = ky.kind == 2 ? amap[ky.actor] : AMH_NULL32;
-  g_key[1] = ky.kind == 0 ? AMH_NULL32 : (ky.kind == 1 ? 0 : ky.ctr);
-  g_key[2] = ky.str_off;
-  g_key[3] = ky.kind == 0 ? ky.str_len : AMH_NULL32;
+  if (ky.kind == 0 && ky.str_len <= 8) {
+    // a short map key travels in the view itself (bytes, AMH_CV_INLINE | length): the encoders, one lane per
+    // change, compare and write it out of registers instead of going back to the chunk for every op
+    u64 kb = ky.str_len ? amh_peek8_any(chunk + ky.str_off) & amh_low_bytes(ky.str_len) : 0;
+    g_key[0] = (u32)kb; g_key[1] = (u32)(kb >> 32);
+    g_key[2] = ky.str_off;
+    g_key[3] = AMH_CV_INLINE | ky.str_len;
+  } else {
+    g_key[0] = ky.kind == 2 ? amap[ky.actor] : AMH_NULL32;
+    g_key[1] = ky.kind == 0 ? AMH_NULL32 : (ky.kind == 1 ? 0 : ky.ctr);
+    g_key[2] = ky.str_off;
+    g_key[3] = ky.kind == 0 ? ky.str_len : AMH_NULL32;
+  }
   bool del = op_is_del(B, t);
   u32 action = del ? 3 : B.r_action[t];
   u32 ins = del ? 0 : (B.r_insert[t] != 0);
@@ -1446,8 +1472,20 @@ AMH_DEV void k_change_view(const BatchDev& B, u32 j) {
   OpVal v = op_val(B, t);
   g_val[0] = (u32)v.meta;
   g_val[1] = (u32)(v.meta >> 32) | ((u32)v.kind << 8);
-  if (v.kind == 2) { g_val[2] = (u32)(u64)v.i; g_val[3] = (u32)((u64)v.i >> 32); }
-  else {
+  // value bytes of up to eight bytes (every integer below 2^55 in its LEB128 form, short strings) are inlined as
+  // kind 3 with the length in bits 16..19; longer ones stay references into the chunk (kind 1) / integers (kind 2)
+  if (v.kind == 2) {
+    u32 nb = sleb_size_fast(v.i);
+    if (nb <= 8) {
+      u64 eb = sleb_bytes8(v.i, nb);
+      g_val[1] = (u32)(v.meta >> 32) | (3u << 8) | (nb << 16);
+      g_val[2] = (u32)eb; g_val[3] = (u32)(eb >> 32);
+    } else { g_val[2] = (u32)(u64)v.i; g_val[3] = (u32)((u64)v.i >> 32); }
+  } else if (v.kind == 1 && v.raw_len && v.raw_len <= 8) {
+    u64 eb = amh_peek8_any(v.raw) & amh_low_bytes(v.raw_len);
+    g_val[1] = (u32)(v.meta >> 32) | (3u << 8) | (v.raw_len << 16);
+    g_val[2] = (u32)eb; g_val[3] = (u32)(eb >> 32);
+  } else {
     g_val[2] = (v.kind == 1 && v.raw_len) ? B.desc[B.r_doc[t]].ocol[OC_VAL_RAW].off + B.r_vraw_off[t] : 0;
     g_val[3] = v.raw_len;
   }
