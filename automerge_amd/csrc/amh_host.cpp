@@ -85,6 +85,8 @@ struct DevPool {
 struct amh_ctx {
   int device = 0;
   rt_stream stream{};
+  rt_stream side{};          // second stream: kernels that are independent of the main chain run beside it (fork / join by events)
+  rt_event ev_fork{}, ev_fork2{}, ev_join{};
   DevPool pool;
   bool profiling = false;
   double kernel_ms[AK_NUM] = {0};
@@ -164,7 +166,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
 // launch helpers
 // ---------------------------------------------------------------------------------------------
 static int g_dbg_stop_after = -1;  // AMH_DEBUG_STOP_AFTER=<kernel id>: skip every kernel with a larger id (diagnostics)
-static void launch(amh_ctx* ctx, int k, const BatchDev& B, u32 n) {
+static void launch_on(amh_ctx* ctx, rt_stream st, int k, const BatchDev& B, u32 n) {
   if (n == 0) return;
   if (g_dbg_stop_after >= 0 && k > g_dbg_stop_after) return;
   if (ctx->profiling) {
@@ -172,14 +174,15 @@ static void launch(amh_ctx* ctx, int k, const BatchDev& B, u32 n) {
     p.k = k;
     rt_event_create(&p.a);
     rt_event_create(&p.b);
-    rt_event_record(&p.a, ctx->stream);
-    amh_launch(k, B, n, (void*)ctx->stream);
-    rt_event_record(&p.b, ctx->stream);
+    rt_event_record(&p.a, st);
+    amh_launch(k, B, n, (void*)st);
+    rt_event_record(&p.b, st);
     ctx->pending.push_back(p);
   } else {
-    amh_launch(k, B, n, (void*)ctx->stream);
+    amh_launch(k, B, n, (void*)st);
   }
 }
+static void launch(amh_ctx* ctx, int k, const BatchDev& B, u32 n) { launch_on(ctx, ctx->stream, k, B, n); }
 static void collect_profile(amh_ctx* ctx) {
   for (auto& p : ctx->pending) {
     ctx->kernel_ms[p.k] += rt_event_ms(&p.a, &p.b);
@@ -315,6 +318,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   bool ok = true;
   auto fail = [&](const std::string& m) -> amh_batch* {
     set_error(ctx, m);
+    rt_sync(ctx->side);   // nothing of this batch may still be running when its memory goes back to the pool
     collect_profile(ctx);
     amh_batch_free(b);
     return nullptr;
@@ -337,8 +341,24 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   rt_memset(B.fail_line, 0, (n + 1) * sizeof(u32), ctx->stream);
   rt_memset(B.max_level, 0, 16, ctx->stream);
   launch(ctx, AK_PARSE, B, n);
-  launch(ctx, AK_SHA_DOC, B, n);
+  {   // checksums on the side stream, beside the count pass (both are one long serial walk per lane: few waves each)
+    i32* gate = balloc<i32>(b, n + 1, &ok);
+    B.sha_bad = balloc<u8>(b, n + 1, &ok);
+    if (!ok) return fail("device out of memory");
+    B.sha_gate = gate;
+#ifdef AMH_EMU
+    memcpy(gate, B.status, (size_t)n * sizeof(i32));
+#else
+    (void)hipMemcpyAsync(gate, B.status, (size_t)n * sizeof(i32), hipMemcpyDeviceToDevice, ctx->stream);
+#endif
+    rt_memset(B.sha_bad, 0, n + 1, ctx->stream);
+    rt_event_record(&ctx->ev_fork, ctx->stream);
+    rt_stream_wait(ctx->side, &ctx->ev_fork);
+    launch_on(ctx, ctx->side, AK_SHA_DOC, B, n);
+    rt_event_record(&ctx->ev_join, ctx->side);
+  }
   launch(ctx, AK_COUNT, B, n);
+  rt_stream_wait(ctx->stream, &ctx->ev_join);   // k_extract applies the checksum verdicts
   launch(ctx, AK_EXTRACT, B, n);
   u32 totals[8] = {0};
   for (int i = 0; i < 8; i++)
@@ -445,6 +465,12 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   if (!ok) return fail("device out of memory");
   rt_memset(B.c_wide, 0, NC * 4, ctx->stream);
   launch(ctx, AK_CHANGE_VIEW, B, tot_ops);
+  // visibility only needs the linked rows: it runs on the side stream next to the change encode and hashing, whose
+  // per-lane state machines leave the memory system mostly idle (joined before the statuses are read)
+  rt_event_record(&ctx->ev_fork2, ctx->stream);
+  rt_stream_wait(ctx->side, &ctx->ev_fork2);
+  launch_on(ctx, ctx->side, AK_VISIBLE, B, B.tot_rows);
+  rt_event_record(&ctx->ev_join, ctx->side);
   launch(ctx, AK_ENCODE_SIZE, B, B.tot_chg * AMH_NCOLS);
   launch(ctx, AK_CHG_LAYOUT, B, B.tot_chg);
 #ifdef AMH_EMU
@@ -475,7 +501,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   }
   if (lvl_start[AMH_LEVEL_CAP_HOST + 1] > lvl_start[AMH_LEVEL_CAP_HOST]) launch(ctx, AK_CHG_HASH_SEQ, B, n);
   launch(ctx, AK_HEADS, B, n);
-  launch(ctx, AK_VISIBLE, B, B.tot_rows);
+  rt_stream_wait(ctx->stream, &ctx->ev_join);   // visibility is in
   b->status.resize(n);
   b->fail_line.resize(n);
   if (!rt_d2h(b->status.data(), B.status, n * sizeof(i32), ctx->stream) || !rt_d2h(b->fail_line.data(), B.fail_line, n * sizeof(u32), ctx->stream) || !rt_sync(ctx->stream))
@@ -2232,12 +2258,26 @@ extern "C" amh_ctx* amh_ctx_create(const int* gpu_ids, int n_gpus) {
     delete ctx;
     return nullptr;
   }
+  if (!rt_stream_create(&ctx->side)) {
+    set_error(nullptr, "stream creation failed");
+    rt_shutdown(ctx->stream);
+    delete ctx;
+    return nullptr;
+  }
+  rt_event_create(&ctx->ev_fork);
+  rt_event_create(&ctx->ev_fork2);
+  rt_event_create(&ctx->ev_join);
   return ctx;
 }
 extern "C" void amh_ctx_destroy(amh_ctx* ctx) {
   if (!ctx) return;
   rt_sync(ctx->stream);
+  rt_sync(ctx->side);
   ctx->pool.trim();
+  rt_event_destroy(&ctx->ev_fork);
+  rt_event_destroy(&ctx->ev_fork2);
+  rt_event_destroy(&ctx->ev_join);
+  rt_shutdown(ctx->side);
   rt_shutdown(ctx->stream);
   delete ctx;
 }

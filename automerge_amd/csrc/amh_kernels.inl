@@ -281,14 +281,16 @@ AMH_DEV void k_parse(const BatchDev& B, u32 d) {
 // K1b  SHA-256 of the document chunk and checksum check — chunk.rs:277-293.  Thread per document.
 // ------------------------------------------------------------------------------------------
 AMH_DEV void k_sha_doc(const BatchDev& B, u32 d) {
-  if (B.status[d]) return;
+  if (B.sha_gate ? B.sha_gate[d] : B.status[d]) return;
   const DocDesc& D = B.desc[d];
   if (D.chunk_len == 0) return;
   const u8* p = B.arena + D.chunk_off;
   // type byte + uleb(len) exactly as stored (strict parse => canonical) and the data: one contiguous range
   u8* h = B.doc_hash + (u64)d * 32;
   sha256_contig(p + 8, (u64)(D.data_off - 8) + D.data_len, h);
-  if (!B.no_checksum && (h[0] != p[4] || h[1] != p[5] || h[2] != p[6] || h[3] != p[7])) amh_fail(B, d, AMH_E_BAD_CHECKSUM);
+  if (!B.no_checksum && (h[0] != p[4] || h[1] != p[5] || h[2] != p[6] || h[3] != p[7])) {
+    if (B.sha_bad) B.sha_bad[d] = 1; else amh_fail(B, d, AMH_E_BAD_CHECKSUM);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2113,6 +2115,10 @@ AMH_DEV void k_ht_size(const BatchDev& B, u32 d) {
 
 // per-document sizes, written into the *_base arrays and scanned in place afterwards
 AMH_DEV void k_extract(const BatchDev& B, u32 d) {
+  if (B.sha_bad && B.sha_bad[d]) {   // the checksum is checked before the document is reconstructed: it outranks what the count made of the bytes
+    B.status[d] = AMH_E_BAD_CHECKSUM;
+    B.fail_line[d] = __LINE__;
+  }
   bool ok = B.status[d] == 0;
   const DocCounts& C = B.cnt[d];
   u32 rows = ok ? C.n_rows : 0, succ = ok ? C.n_succ : 0, chg = ok ? C.n_chg : 0, deps = ok ? C.n_deps : 0;

@@ -82,6 +82,13 @@ struct BatchDev {
   u32 tot_rows, tot_succ, tot_chg, tot_deps, tot_actors, tot_dt, tot_ops;
   u32 check_heads;         // VerificationMode::Check (reconstruct_document.rs:86-90)
   u32 no_checksum;         // the stored checksum is not compared (Change::try_from, change.rs:161-180, does not look at it)
+  // deferred checksum verdict (batch load): k_sha_doc runs beside the count pass on the side stream, looks at the
+  // statuses as k_parse left them (sha_gate) and only notes a mismatch (sha_bad); k_extract, behind the join, turns
+  // the note into the document's status, ahead of whatever the count made of the damaged bytes — the order the
+  // reference checks in — and before anything is sized or decoded.  Null = the kernel fails the document itself
+  // (apply's change chunks).
+  const i32* sha_gate;
+  u8* sha_bad;
   u32 cur_level;           // start, in lvl_order, of the dependency level hashed by the current k_chg_hash launch
   u32* lvl_order;          // [tot_chg] changes grouped by dependency level
   u32* lvl_start;          // [AMH_LEVEL_CAP + 2] start of each level in lvl_order
