@@ -423,8 +423,9 @@ def main():
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))["kernels"]
-        names = {"encode_store": ["void g_encode_lds<true>(BatchDev)"],
-                 "encode_size": ["void g_encode_lds<false>(BatchDev)"], "decode_ops": ["g_decode_cols(BatchDev)", "g_k_decode_ops(BatchDev, unsigned int)"],
+        names = {"encode_store": [f"void g_encode_grp<true, {g}>(BatchDev)" for g in range(1, 7)],
+                 "encode_size": [f"void g_encode_grp<false, {g}>(BatchDev)" for g in range(1, 7)],
+                 "decode_ops": ["g_decode_cols(BatchDev)"],
                  "count": ["g_count_lds(BatchDev)"]}.get(dom, [f"g_k_{dom}(BatchDev, unsigned int)"])
         vals = [tj[nm]["traffic"] for nm in names if nm in tj]
         traffic = sum(vals) if vals else None
