@@ -224,3 +224,25 @@ def check_save_after_roundtrip(engine, replicas):
     r0.load_incremental(r1.save_after(h0))
     check_doc(b, 0, r0)
     assert b.save_all(deflate=False)[0] == r0.save(deflate=False)
+
+
+def check_error_precedence(engine, data):
+    """chunk parse errors come first, then the checksum, then whatever reconstruction finds (storage/load.rs:56-114,
+    automerge.rs:601-656): a damaged document reports BadChecksum even when its damaged bytes no longer decode"""
+    n = len(data)
+    flip = bytearray(data); flip[n // 2] ^= 0x01                        # one bit of column data
+    smash = bytearray(data); smash[n // 3:n // 3 + 96] = b"\xff" * 96    # columns that cannot be decoded any more
+    tail = bytearray(data); tail[-1] ^= 0x80
+    magic = bytearray(data); magic[1] ^= 0x10                            # not a chunk at all
+    cases = [bytes(data), bytes(flip), bytes(smash), bytes(tail), bytes(magic)]
+    b = engine.load_batch(cases)
+    for i, c in enumerate(cases):
+        try:
+            o.Doc.load(c)
+            want = 0
+        except o.OracleError as e:
+            want = e.kind
+        kind, _ = b.status(i)
+        got = 4 if 20 <= kind < 40 else kind     # the oracle reports every reconstruction error as kind 4
+        assert got == want, (i, kind, want)
+    assert b.status(0)[0] == 0 and b.status(1)[0] == 2 and b.status(2)[0] == 2 and b.status(4)[0] == 1

@@ -261,3 +261,9 @@ def test_hash_id_tables(emu, golden_dir, monkeypatch):
         compare(batch, i, d)
     from merge_cases import check_merge_many
     check_merge_many(emu, [[docs[20 + 3 * i + r] for i in range(2)] for r in range(3)])
+
+
+def test_checksum_outranks_reconstruction_errors(emu):
+    blob, offs = emu.gen_map_docs(0xE770, 2, 3, 3, 20, 16, 1)
+    for i in range(2):
+        ac.check_error_precedence(emu, blob[offs[i]:offs[i + 1]])

@@ -292,3 +292,19 @@ def test_hash_id_tables(engine, golden_dir, monkeypatch):
         _compare(batch, i, d)
     from merge_cases import check_merge_many
     check_merge_many(engine, [[docs[20 + 3 * i + r] for i in range(2)] for r in range(3)])
+
+
+def test_checksum_outranks_reconstruction_errors(engine):
+    """the checksum kernel runs beside the count pass on the side stream: its verdict still comes first"""
+    import apply_cases
+    blob, offs = engine.gen_map_docs(0xE770, 2, 3, 3, 20, 16, 1)
+    for i in range(2):
+        apply_cases.check_error_precedence(engine, blob[offs[i]:offs[i + 1]])
+    # and in a large batch, where the two streams really overlap
+    blob, offs = engine.gen_map_docs(0xE771, 3000, 4, 5, 50, 128, 8)
+    docs = [bytearray(blob[offs[i]:offs[i + 1]]) for i in range(3000)]
+    for i in range(0, 3000, 7):
+        n = len(docs[i]); docs[i][n // 3:n // 3 + 96] = b"\xff" * 96
+    b = engine.load_batch([bytes(d) for d in docs])
+    for i in range(3000):
+        assert b.status(i)[0] == (2 if i % 7 == 0 else 0), (i, b.status(i))
