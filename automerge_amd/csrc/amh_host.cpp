@@ -88,6 +88,10 @@ struct amh_ctx {
   rt_stream side{};          // second stream: kernels that are independent of the main chain run beside it (fork / join by events)
   rt_event ev_fork{}, ev_fork2{}, ev_join{};
   DevPool pool;
+  // pinned staging area of apply / merge_many calls, kept between calls (grow only): no page faults on fresh memory
+  // every call, and the H2D copy of the change chunks runs at the pinned rate
+  u8* stage = nullptr;
+  size_t stage_cap = 0;
   bool profiling = false;
   double kernel_ms[AK_NUM] = {0};
   uint64_t kernel_calls[AK_NUM] = {0};
@@ -943,18 +947,18 @@ struct RawBuf {
 
 // per-document host bookkeeping of a batch call on a few threads (documents are independent)
 template <class F>
-static void host_parallel_for(u32 n, F f) {
+static void host_parallel_for(u32 n, F f, u32 min_items = 128, u32 grain = 32) {
   unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
   if (const char* e = getenv("OMP_NUM_THREADS")) { int v = atoi(e); if (v > 0) nt = std::min<unsigned>(nt, (unsigned)v); }
-  if (n < 128 || nt < 2) { for (u32 i = 0; i < n; i++) f(i); return; }
+  if (n < min_items || nt < 2) { for (u32 i = 0; i < n; i++) f(i); return; }
   std::atomic<u32> next{0};
   std::vector<std::thread> ts;
   for (unsigned t = 0; t < nt; t++)
     ts.emplace_back([&]() {
       for (;;) {
-        u32 lo = next.fetch_add(32);
+        u32 lo = next.fetch_add(grain);
         if (lo >= n) break;
-        u32 hi = std::min(n, lo + 32);
+        u32 hi = std::min(n, lo + grain);
         for (u32 i = lo; i < hi; i++) f(i);
       }
     });
@@ -1524,7 +1528,14 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   results.assign(P, 0);
   if (P == 0) return AMH_SUCCESS;
   PhaseTimer pt(who);
-  if (!ensure_chg(dst) || !ensure_host_arena(dst->staged)) { set_error(ctx, std::string(who) + ": D2H copy failed"); return AMH_ERR_DEVICE; }
+  // the host view of dst's history (hashes, deps, actors: ~100 bytes per change) comes back on a helper thread while
+  // this one splits, stages and decodes the incoming chunks; it is first needed by the decisions further down
+  bool view_ok = true;
+  std::thread view_thread([&]() {
+    rt_set_device(ctx->device);
+    view_ok = ensure_chg(dst) && ensure_host_arena(dst->staged);
+  });
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } view_joiner{view_thread};
   const HostView& ha = dst->hv;
   const BatchDev& DB = dst->B;
   // ---- chunks of every pair: the new ones, then the document's queue -------------------------------
@@ -1558,6 +1569,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       for (auto& hc : per_pair[p]) chunks.push_back(std::move(hc));
     }
   }
+  pt.mark("apply: split");
   // document chunks inside the streams (load_incremental of a whole saved document): loaded as a batch of their own
   // without the heads check (load.rs:90-93), each then stands for its re-derived changes
   {
@@ -1619,13 +1631,12 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   hb->ctx = ctx;
   ApplyRun ap;
   std::vector<u64> doc_off;
-  RawBuf h_arena;
+  struct StageView { u8* p = nullptr; size_t n = 0; u8* data() const { return p; } size_t size() const { return n; } } h_arena;
   ap.s_desc.resize(P); ap.s_cnt.resize(P); ap.s_row_base.assign(P + 1, 0);
   std::vector<u32> staged_of;   // U index -> chunks index
   {
     u64 off = 0;
     for (u32 p = 0; p < P; p++) {
-      memset(&ap.s_desc[p], 0, sizeof(DocDesc)); memset(&ap.s_cnt[p], 0, sizeof(DocCounts));
       u64 region = off;
       ap.s_desc[p].chunk_off = region;
       for (u32 k = pc_base[p]; k < pc_base[p + 1]; k++) {
@@ -1642,7 +1653,15 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       if (off - region >= 0xFFFFFFF0ull) { set_error(ctx, std::string(who) + ": changes of one document exceed 4 GiB"); return AMH_ERR_BATCH_TOO_LARGE; }
       ap.s_desc[p].chunk_len = (u32)(off - region);
     }
-    if (!h_arena.alloc((size_t)off + 256)) { set_error(ctx, std::string(who) + ": out of host memory"); return AMH_ERR_OOM; }
+    pt.mark("apply: stage layout");
+    if ((size_t)off + 256 > ctx->stage_cap) {
+      rt_sync(ctx->stream);   // nothing may still be copying out of the old area
+      if (ctx->stage) rt_host_free(ctx->stage);
+      ctx->stage_cap = ((size_t)off + 256) + ((size_t)off + 256) / 4;
+      ctx->stage = (u8*)rt_host_alloc(ctx->stage_cap);
+      if (!ctx->stage) { ctx->stage_cap = 0; set_error(ctx, std::string(who) + ": out of host memory"); return AMH_ERR_OOM; }
+    }
+    h_arena.p = ctx->stage; h_arena.n = (size_t)off + 256;   // read until the decisions below are made; the reload inside mg_execute may stage again
     memset(h_arena.data() + off, 0, 256);
     host_parallel_for((u32)staged_of.size(), [&](u32 u) {   // chunk bytes + the alignment gap behind them
       u64 o0 = doc_off[2 * (size_t)u], o1 = doc_off[2 * (size_t)u + 1], next = (o1 + 15) & ~(u64)15;
@@ -1652,7 +1671,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   }
   u32 NCH = (u32)staged_of.size();
   ap.n_chunks = NCH;
-  pt.mark("apply: split + stage (host)");
+  pt.mark("apply: stage copy");
   std::vector<i32> u_status(NCH, 0);
   std::vector<ChgHdr> hdr(NCH);
   std::vector<DocCounts> u_cnt(NCH);
@@ -1726,6 +1745,9 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     collect_profile(ctx);
   }
   pt.mark("apply: U decode + verify", &ctx->stream);
+  view_thread.join();
+  if (!view_ok) { set_error(ctx, std::string(who) + ": D2H copy failed"); return AMH_ERR_DEVICE; }
+  pt.mark("apply: wait for dst's host view");
   // ---- host: which changes apply, in which order (automerge.rs:797-858); actors; merged history -----
   MgPlan pl;
   mg_plan_init(pl, P, DB.n_docs, P, NCH);
@@ -1733,7 +1755,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   ap.c_applied.assign((size_t)NCH + 1, 0);
   ap.amap_base.assign((size_t)NCH + 1, 0);
   ap.ix_base.assign(P + 1, 0);
-  std::vector<std::vector<u32>> new_queue(P), amap_of(NCH);
+  std::vector<std::vector<u32>> new_queue(P);
   std::vector<u8> queue_dirty(P, 0);
   typedef std::pair<const u8*, u32> Bytes;
   auto bcmp = [](Bytes x, Bytes y) { int c = memcmp(x.first, y.first, std::min(x.second, y.second)); return c ? c : (x.second < y.second ? -1 : (x.second > y.second ? 1 : 0)); };
@@ -1764,16 +1786,50 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       ap.s_cnt[p].n_rows = rb1 - rb0;
     }
   }
+  // Pairs are decided in blocks of DEC_BLK by a few host threads; a block appends into one set of vectors (with the
+  // offsets at which each of its pairs starts) and reuses one set of scratch containers, so the join below is a few
+  // bulk appends per block and a pair costs no allocations of its own.
+  struct HashIndex {   // change hash -> position in the merged history; keys are pointers to 32 stable bytes
+    std::vector<u32> slot, val;
+    std::vector<const u8*> key;
+    u32 mask = 0;
+    void reset(size_t n) { size_t cap = 16; while (cap < 2 * n + 2) cap <<= 1; slot.assign(cap, 0); key.clear(); val.clear(); mask = (u32)cap - 1; }
+    const u32* find(const u8* h) const {
+      u64 k; memcpy(&k, h, 8);
+      for (u32 i = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & mask; slot[i]; i = (i + 1) & mask)
+        if (memcmp(key[slot[i] - 1], h, 32) == 0) return &val[slot[i] - 1];
+      return nullptr;
+    }
+    void emplace(const u8* h, u32 v) {
+      u64 k; memcpy(&k, h, 8);
+      u32 i = (u32)((k * 0x9E3779B97F4A7C15ull) >> 40) & mask;
+      for (; slot[i]; i = (i + 1) & mask) if (memcmp(key[slot[i] - 1], h, 32) == 0) return;
+      key.push_back(h); val.push_back(v); slot[i] = (u32)key.size();
+    }
+  };
+  typedef std::pair<const u8*, u32> BytesT;
+  struct Ix { u32 actor, start, nops, row; };
   struct PairOut {
     std::vector<u32> map_a, map_b, map_b2a, m_actor_off, m_actor_len, m_actor_rank, mc_from, mc_ndeps, mc_dep_base, m_dep_idx, mc_doc;
     std::vector<u8> mc_is_dep;
     std::vector<u32> ix_actor, ix_start, ix_nops, ix_row;
-    u64 arena_need = 0;
+    std::vector<u32> amap, amap_u, amap_at;                  // actor maps of the applied chunks, flat; chunk u's starts at amap_at
+    std::vector<u32> p_mapa, p_mapb, p_actor, p_chg, p_ix;   // per pair of the block: where its entries start in the vectors above
+    std::vector<u64> p_arena;                                // per pair: bytes of the merged arena it needs (0 = none)
     int failed = 0;
+    // scratch, cleared per pair
+    HashIndex history;
+    std::vector<std::pair<BytesT, u64>> per_actor;
+    std::vector<u32> fresh, oldq, order, queue, la, lb, lb2a;
+    std::vector<BytesT> sact, tmp;
+    std::vector<Ix> ix;
   };
-  std::vector<PairOut> outs(P);
-  // the decisions of a pair only read shared state: pairs are worked on by a few host threads, results joined below
+  const u32 DEC_BLK = 64;
+  const u32 n_blk = (P + DEC_BLK - 1) / DEC_BLK;
+  std::vector<PairOut> outs(n_blk);
   auto decide = [&](u32 p, PairOut& o) {
+    o.p_mapa.push_back((u32)o.map_a.size()); o.p_mapb.push_back((u32)o.map_b.size()); o.p_actor.push_back((u32)o.m_actor_off.size());
+    o.p_chg.push_back((u32)o.mc_from.size()); o.p_ix.push_back((u32)o.ix_actor.size()); o.p_arena.push_back(0);
     u32 a = items[p].doc;
     int mode = items[p].mode;
     auto &map_a = o.map_a, &map_b = o.map_b, &map_b2a = o.map_b2a, &m_actor_off = o.m_actor_off, &m_actor_len = o.m_actor_len, &m_actor_rank = o.m_actor_rank;
@@ -1781,7 +1837,8 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     auto& mc_is_dep = o.mc_is_dep;
     if (dst->status[a]) { p_status[p] = dst->status[a]; results[p] = dst->status[a]; o.failed = 1; return; }
     // usable new chunks under the call's policy
-    std::vector<u32> fresh, oldq;
+    auto &fresh = o.fresh, &oldq = o.oldq;
+    fresh.clear(); oldq.clear();
     i32 first_err = 0;
     for (u32 k = pc_base[p]; k < pc_base[p + 1]; k++) {
       HostChunk& hc = chunks[k];
@@ -1802,35 +1859,42 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     for (u32 i = 1; i < na && sorted; i++) sorted = bcmp(abytes(i - 1), abytes(i)) < 0;
     if (!sorted) { p_status[p] = AMH_E_UNSUPPORTED; results[p] = AMH_E_UNSUPPORTED; o.failed = 1; return; }
     u32 nca = ha.cnt[a].n_chg, cba = ha.chg_base[a];
-    std::unordered_map<Hash32, u32, Hash32Hasher> history;
-    history.reserve((size_t)nca * 2 + fresh.size() * 2 + 1);
-    for (u32 i = 0; i < nca; i++) { Hash32 h; memcpy(h.b, ha.c_hash.data() + (size_t)(cba + i) * 32, 32); history.emplace(h, i); }
-    std::map<std::string, u64> per_actor;   // actor -> number of its changes in the history (states, automerge.rs:771-779)
-    for (u32 i = 0; i < nca; i++) { Bytes ab = abytes(ha.c_actor[cba + i]); per_actor[std::string((const char*)ab.first, ab.second)]++; }
-    auto hash_of = [&](u32 k) { Hash32 h; memcpy(h.b, u_hash.data() + (size_t)chunks[k].staged * 32, 32); return h; };
-    auto actor_of = [&](u32 k) { u32 u = chunks[k].staged; const u8* q = h_arena.data() + doc_off[2 * (size_t)u]; return std::string((const char*)q + hdr[u].actor_off, hdr[u].actor_len); };
+    HashIndex& history = o.history;
+    history.reset((size_t)nca + (pc_base[p + 1] - pc_base[p]));
+    for (u32 i = 0; i < nca; i++) history.emplace(ha.c_hash.data() + (size_t)(cba + i) * 32, i);
+    auto& per_actor = o.per_actor;   // actor -> number of its changes in the history (states, automerge.rs:771-779); a handful per document
+    per_actor.clear();
+    auto actor_slot = [&](Bytes ab) -> u64& {
+      for (auto& e : per_actor) if (bcmp(e.first, ab) == 0) return e.second;
+      per_actor.push_back({ab, 0});
+      return per_actor.back().second;
+    };
+    for (u32 i = 0; i < nca; i++) actor_slot(abytes(ha.c_actor[cba + i]))++;
+    auto hash_of = [&](u32 k) { return (const u8*)u_hash.data() + (size_t)chunks[k].staged * 32; };
+    auto actor_of = [&](u32 k) { u32 u = chunks[k].staged; const u8* q = h_arena.data() + doc_off[2 * (size_t)u]; return Bytes(q + hdr[u].actor_off, hdr[u].actor_len); };
     auto ready = [&](u32 k) {
       u32 u = chunks[k].staged;
       const u8* q = h_arena.data() + doc_off[2 * (size_t)u] + hdr[u].deps_off;
-      for (u32 i = 0; i < hdr[u].n_deps; i++) { Hash32 h; memcpy(h.b, q + 32 * (size_t)i, 32); if (!history.count(h)) return false; }
+      for (u32 i = 0; i < hdr[u].n_deps; i++) if (!history.find(q + 32 * (size_t)i)) return false;
       return true;
     };
-    std::vector<u32> order, queue = oldq;
-    auto apply = [&](u32 k) { history.emplace(hash_of(k), nca + (u32)order.size()); order.push_back(k); per_actor[actor_of(k)]++; };
+    auto &order = o.order, &queue = o.queue;
+    order.clear();
+    queue = oldq;
+    auto apply = [&](u32 k) { history.emplace(hash_of(k), nca + (u32)order.size()); order.push_back(k); actor_slot(actor_of(k))++; };
     bool dup = false;
     auto drain = [&]() {   // pop_next_causally_ready_change (automerge.rs:849-858): linear scan + swap_remove
       for (;;) {
         bool got = false;
         for (size_t q = 0; q < queue.size(); q++)
-          if (ready(queue[q])) { u32 k = queue[q]; queue[q] = queue.back(); queue.pop_back(); if (!history.count(hash_of(k))) apply(k); got = true; break; }
+          if (ready(queue[q])) { u32 k = queue[q]; queue[q] = queue.back(); queue.pop_back(); if (!history.find(hash_of(k))) apply(k); got = true; break; }
         if (!got) break;
       }
     };
     for (size_t fi = 0; fi < fresh.size() && !dup; fi++) {
       u32 k = fresh[fi];
-      if (!history.count(hash_of(k))) {
-        auto it = per_actor.find(actor_of(k));
-        if (it != per_actor.end() && it->second >= hdr[chunks[k].staged].seq) { dup = true; break; }
+      if (!history.find(hash_of(k))) {
+        if (actor_slot(actor_of(k)) >= hdr[chunks[k].staged].seq) { dup = true; break; }
         if (ready(k)) apply(k); else queue.push_back(k);
       }
       // every buffer is one apply_changes call: the queue is drained at its end
@@ -1842,7 +1906,8 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     new_queue[p] = queue; queue_dirty[p] = 1;
     if (order.empty()) { p_status[p] = -1; return; }
     // actor table of S for this pair: the actors of the applied changes, bytewise sorted
-    std::vector<Bytes> sact, tmp;
+    auto &sact = o.sact, &tmp = o.tmp;
+    sact.clear();
     for (u32 k : order) { chunk_actors(chunks[k].staged, tmp); sact.insert(sact.end(), tmp.begin(), tmp.end()); }
     std::sort(sact.begin(), sact.end(), [&](Bytes x, Bytes y) { return bcmp(x, y) < 0; });
     sact.erase(std::unique(sact.begin(), sact.end(), [&](Bytes x, Bytes y) { return bcmp(x, y) == 0; }), sact.end());
@@ -1850,7 +1915,8 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     const u8* region = h_arena.data() + ap.s_desc[p].chunk_off;
     u32 lenA = ha.desc[a].chunk_len, lenApad = (lenA + 15u) & ~15u, lenB = ap.s_desc[p].chunk_len;
     a_len_pad[p] = lenApad;
-    std::vector<u32> la(na), lb(nb), lb2a(nb, AMH_NULL32);
+    auto &la = o.la, &lb = o.lb, &lb2a = o.lb2a;
+    la.assign(na, 0); lb.assign(nb, 0); lb2a.assign(nb, AMH_NULL32);
     {
       u32 i = 0, j = 0, k = 0;
       while (i < na || j < nb) {
@@ -1876,18 +1942,19 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       for (u32 k = 0; k < ha.c_ndeps[cba + i]; k++) m_dep_idx.push_back(ha.dep_idx[ha.c_dep_base[cba + i] + k]);
     }
     u32 mark_len = ha.desc[a].ocol[OC_MARK_NAME].len;
-    struct Ix { u32 actor, start, nops, row; };
-    std::vector<Ix> ix;
+    auto& ix = o.ix;
+    ix.clear();
     for (u32 k : order) {
       u32 u = chunks[k].staged;
       ap.c_applied[u] = 1;
       mc_from.push_back(0x80000000u | u); mc_doc.push_back(p); mc_is_dep.push_back(0);
       mc_ndeps.push_back(hdr[u].n_deps); mc_dep_base.push_back((u32)m_dep_idx.size());
       const u8* q = h_arena.data() + doc_off[2 * (size_t)u] + hdr[u].deps_off;
-      for (u32 i = 0; i < hdr[u].n_deps; i++) { Hash32 h; memcpy(h.b, q + 32 * (size_t)i, 32); m_dep_idx.push_back(history[h]); }
+      for (u32 i = 0; i < hdr[u].n_deps; i++) m_dep_idx.push_back(*history.find(q + 32 * (size_t)i));
       mark_len |= u_desc[u].ocol[OC_MARK_NAME].len;
       chunk_actors(u, tmp);
-      for (auto& x : tmp) amap_of[u].push_back(s_index(x));
+      o.amap_u.push_back(u); o.amap_at.push_back((u32)o.amap.size());
+      for (auto& x : tmp) o.amap.push_back(s_index(x));
       ix.push_back(Ix{s_index(tmp[0]), (u32)hdr[u].start_op, u_cnt[u].n_rows, u_row_base[u]});
     }
     std::sort(ix.begin(), ix.end(), [](const Ix& x, const Ix& y) { return x.actor != y.actor ? x.actor < y.actor : x.start < y.start; });
@@ -1896,16 +1963,33 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       for (u32 k = 0; k < mc_ndeps[c]; k++) mc_is_dep[first_c + m_dep_idx[mc_dep_base[c] + k]] = 1;
     m_cnt[p].n_chg = nca + (u32)order.size();
     m_desc[p].chunk_len = lenApad + lenB;
-    m_desc[p].n_actors = (u32)m_actor_off.size();
+    m_desc[p].n_actors = (u32)m_actor_off.size() - o.p_actor.back();
     m_desc[p].ocol[OC_MARK_NAME].len = mark_len;
-    o.arena_need = (lenApad + lenB + 15u) & ~15ull;
+    o.p_arena.back() = (lenApad + lenB + 15u) & ~15ull;
     };
-  host_parallel_for(P, [&](u32 p) { decide(p, outs[p]); });
-  for (u32 p = 0; p < P; p++) {
-    PairOut& o = outs[p];
-    mapa_base[p] = (u32)map_a.size(); mapb_base[p] = (u32)map_b.size();
-    m_actor_base[p] = (u32)m_actor_off.size(); m_chg_base[p] = (u32)mc_from.size();
-    ap.ix_base[p] = (u32)ap.ix_actor.size();
+  pt.mark("apply: decisions: setup");
+  host_parallel_for(n_blk, [&](u32 blk) {
+    for (u32 p = blk * DEC_BLK, e = std::min(P, p + DEC_BLK); p < e; p++) decide(p, outs[blk]);
+  }, 4, 1);
+  pt.mark("apply: decisions: per pair (threads)");
+  {   // one reservation per joined vector
+    size_t n_map_a = 0, n_map_b = 0, n_act = 0, n_chg = 0, n_dep = 0, n_ix = 0, n_amap = 0;
+    for (auto& o : outs) { n_map_a += o.map_a.size(); n_map_b += o.map_b.size(); n_act += o.m_actor_off.size(); n_chg += o.mc_from.size(); n_dep += o.m_dep_idx.size(); n_ix += o.ix_actor.size(); n_amap += o.amap.size(); }
+    map_a.reserve(map_a.size() + n_map_a); map_b.reserve(map_b.size() + n_map_b); map_b2a.reserve(map_b2a.size() + n_map_b);
+    m_actor_off.reserve(m_actor_off.size() + n_act); m_actor_len.reserve(m_actor_len.size() + n_act); m_actor_rank.reserve(m_actor_rank.size() + n_act);
+    mc_from.reserve(mc_from.size() + n_chg); mc_ndeps.reserve(mc_ndeps.size() + n_chg); mc_dep_base.reserve(mc_dep_base.size() + n_chg);
+    mc_doc.reserve(mc_doc.size() + n_chg); mc_is_dep.reserve(mc_is_dep.size() + n_chg); m_dep_idx.reserve(m_dep_idx.size() + n_dep);
+    ap.ix_actor.reserve(n_ix); ap.ix_start.reserve(n_ix); ap.ix_nops.reserve(n_ix); ap.ix_row.reserve(n_ix); ap.amap.reserve(n_amap);
+  }
+  for (u32 blk = 0; blk < n_blk; blk++) {
+    PairOut& o = outs[blk];
+    const u32 b_mapa = (u32)map_a.size(), b_mapb = (u32)map_b.size(), b_actor = (u32)m_actor_off.size(), b_chg = (u32)mc_from.size(), b_ix = (u32)ap.ix_actor.size();
+    for (u32 p = blk * DEC_BLK, e = std::min(P, p + DEC_BLK), i = 0; p < e; p++, i++) {
+      mapa_base[p] = b_mapa + o.p_mapa[i]; mapb_base[p] = b_mapb + o.p_mapb[i];
+      m_actor_base[p] = b_actor + o.p_actor[i]; m_chg_base[p] = b_chg + o.p_chg[i];
+      ap.ix_base[p] = b_ix + o.p_ix[i];
+      if (o.p_arena[i]) { m_desc[p].chunk_off = arena_len; arena_len += o.p_arena[i]; }
+    }
     n_failed += o.failed;
     u32 dep0 = (u32)m_dep_idx.size();
     for (auto& v : o.mc_dep_base) v += dep0;
@@ -1925,12 +2009,10 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     ap.ix_start.insert(ap.ix_start.end(), o.ix_start.begin(), o.ix_start.end());
     ap.ix_nops.insert(ap.ix_nops.end(), o.ix_nops.begin(), o.ix_nops.end());
     ap.ix_row.insert(ap.ix_row.end(), o.ix_row.begin(), o.ix_row.end());
-    if (o.arena_need) { m_desc[p].chunk_off = arena_len; arena_len += o.arena_need; }
+    const u32 b_amap = (u32)ap.amap.size();
+    for (size_t i = 0; i < o.amap_u.size(); i++) ap.amap_base[o.amap_u[i]] = b_amap + o.amap_at[i];
+    ap.amap.insert(ap.amap.end(), o.amap.begin(), o.amap.end());
     o = PairOut();
-  }
-  for (u32 u = 0; u < NCH; u++) {
-    ap.amap_base[u] = (u32)ap.amap.size();
-    ap.amap.insert(ap.amap.end(), amap_of[u].begin(), amap_of[u].end());
   }
   ap.amap_base[NCH] = (u32)ap.amap.size();
   mapa_base[P] = (u32)map_a.size(); mapb_base[P] = (u32)map_b.size();
@@ -1950,7 +2032,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   bool any_work = false;
   for (u32 p = 0; p < P; p++) any_work = any_work || p_status[p] == 0;
   int rc = AMH_SUCCESS;
-  pt.mark("apply: decisions (host)");
+  pt.mark("apply: decisions: join");
   if (any_work) {
     if (arena_len >= 0xFFFFFFF0ull || mc_from.size() >= 0x7FFFFFFFull) { set_error(ctx, std::string(who) + ": batch too large"); return AMH_ERR_BATCH_TOO_LARGE; }
     BatchDev SB;
@@ -2274,6 +2356,7 @@ extern "C" void amh_ctx_destroy(amh_ctx* ctx) {
   rt_sync(ctx->stream);
   rt_sync(ctx->side);
   ctx->pool.trim();
+  if (ctx->stage) rt_host_free(ctx->stage);
   rt_event_destroy(&ctx->ev_fork);
   rt_event_destroy(&ctx->ev_fork2);
   rt_event_destroy(&ctx->ev_join);

@@ -27,6 +27,7 @@ inline void rt_event_create(rt_event*) {}
 inline void rt_event_destroy(rt_event*) {}
 inline void rt_event_record(rt_event* e, rt_stream) { e->t = std::chrono::steady_clock::now(); }
 inline float rt_event_ms(rt_event* a, rt_event* b) { return std::chrono::duration<float, std::milli>(b->t - a->t).count(); }
+inline void rt_set_device(int) {}
 inline bool rt_stream_create(rt_stream* s) { *s = nullptr; return true; }
 inline void rt_stream_wait(rt_stream, rt_event*) {}
 inline const char* rt_last_error() { return "emu"; }
@@ -59,6 +60,7 @@ inline void rt_event_create(rt_event* e) { (void)hipEventCreate(&e->e); }
 inline void rt_event_destroy(rt_event* e) { (void)hipEventDestroy(e->e); }
 inline void rt_event_record(rt_event* e, rt_stream s) { (void)hipEventRecord(e->e, s); }
 inline float rt_event_ms(rt_event* a, rt_event* b) { float ms = 0; (void)hipEventSynchronize(b->e); (void)hipEventElapsedTime(&ms, a->e, b->e); return ms; }
+inline void rt_set_device(int d) { (void)hipSetDevice(d); }   // per host thread
 inline bool rt_stream_create(rt_stream* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess; }
 inline void rt_stream_wait(rt_stream s, rt_event* e) { (void)hipStreamWaitEvent(s, e->e, 0); }   // s goes on once e has happened
 inline const char* rt_last_error() { return hipGetErrorString(hipGetLastError()); }
