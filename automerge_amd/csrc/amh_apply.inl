@@ -22,7 +22,7 @@ AMH_DEV void k_ap_parse(const MergeDev& G, u32 c) {
   for (int i = 0; i < CC_COUNT; i++) { D.ccol[i].off = 0; D.ccol[i].len = 0; }
   for (int i = 0; i < OC_COUNT; i++) { D.ocol[i].off = 0; D.ocol[i].len = 0; }
   H.deps_off = H.n_deps = H.actor_off = H.actor_len = H.msg_off = H.msg_len = H.others_off = H.n_other = H.extra_off = H.extra_len = 0;
-  H.seq = H.start_op = 0; H.time = 0;
+  H.seq = H.start_op = 0; H.time = 0; H.mark_len = 0; H.pad_ = 0;
   u64 start = U.doc_off[2 * (u64)c], avail = U.doc_off[2 * (u64)c + 1] - start;
   D.chunk_off = start;
   D.chunk_len = 0;
@@ -72,6 +72,7 @@ AMH_DEV void k_ap_parse(const MergeDev& G, u32 c) {
   u64 t2;
   cm_init(m, odata, otot, D.ocol);
   if (parse_col_meta<2>(p, meta_pos, end, len, t2, &m) || cm_finish<2>(m)) { amh_fail(U, c, AMH_E_PARSE); return; }
+  H.mark_len = D.ocol[OC_MARK_NAME].len;
 }
 
 // ------------------------------------------------------------------------------------------

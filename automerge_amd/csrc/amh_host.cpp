@@ -1636,6 +1636,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   std::vector<u32> staged_of;   // U index -> chunks index
   {
     u64 off = 0;
+    staged_of.reserve(chunks.size()); ap.c_pair.reserve(chunks.size()); ap.c_rel.reserve(chunks.size()); doc_off.reserve(2 * chunks.size());
     for (u32 p = 0; p < P; p++) {
       u64 region = off;
       ap.s_desc[p].chunk_off = region;
@@ -1675,7 +1676,6 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   std::vector<i32> u_status(NCH, 0);
   std::vector<ChgHdr> hdr(NCH);
   std::vector<DocCounts> u_cnt(NCH);
-  std::vector<DocDesc> u_desc(NCH);
   std::vector<u8> u_hash((size_t)NCH * 32 + 32);
   std::vector<u32> u_row_base(NCH + 1, 0);
   BatchDev& U = ap.U;
@@ -1738,7 +1738,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     launch(ctx, AK_DECODE_OPS, U, NCH * OC_COUNT);
     mg0(MK_AP_VERIFY, tot_rows);
     if (!rt_d2h(u_status.data(), U.status, NCH * sizeof(i32), ctx->stream) || !rt_d2h(hdr.data(), ap.d_hdr, NCH * sizeof(ChgHdr), ctx->stream) ||
-        !rt_d2h(u_cnt.data(), U.cnt, NCH * sizeof(DocCounts), ctx->stream) || !rt_d2h(u_desc.data(), U.desc, NCH * sizeof(DocDesc), ctx->stream) ||
+        !rt_d2h(u_cnt.data(), U.cnt, NCH * sizeof(DocCounts), ctx->stream) ||
         !rt_d2h(u_hash.data(), U.doc_hash, (size_t)NCH * 32, ctx->stream) || !rt_d2h(u_row_base.data(), U.row_base, (NCH + 1) * sizeof(u32), ctx->stream) ||
         !rt_sync(ctx->stream))
       return faild("device pipeline failed");
@@ -1951,7 +1951,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       mc_ndeps.push_back(hdr[u].n_deps); mc_dep_base.push_back((u32)m_dep_idx.size());
       const u8* q = h_arena.data() + doc_off[2 * (size_t)u] + hdr[u].deps_off;
       for (u32 i = 0; i < hdr[u].n_deps; i++) m_dep_idx.push_back(*history.find(q + 32 * (size_t)i));
-      mark_len |= u_desc[u].ocol[OC_MARK_NAME].len;
+      mark_len |= hdr[u].mark_len;
       chunk_actors(u, tmp);
       o.amap_u.push_back(u); o.amap_at.push_back((u32)o.amap.size());
       for (auto& x : tmp) o.amap.push_back(s_index(x));
