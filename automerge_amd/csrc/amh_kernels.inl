@@ -891,7 +891,7 @@ AMH_DEV void k_bucket(const BatchDev& B, u32 t) {
   while (c != AMH_EMPTY32 && B.c_max_op[c] < ctr) c = B.c_next_same_actor[c];
   if (c == AMH_EMPTY32) { amh_fail(B, d, AMH_E_MISSING_CHANGE); return; }
   B.t_chg[t] = c;
-  amh_atomic_add(&B.c_nops[c], 1);
+  amh_atomic_inc_grouped(B.c_nops, c);
 }
 
 // K10  start_op per change — change_collector.rs:179, 194-202.  Thread per change.
