@@ -836,7 +836,7 @@ AMH_DEV void k_succ(const BatchDev& B, u32 e) {
     }
   } else {
     B.s_target[e] = AMH_PENDING32;
-    amh_atomic_add(&B.dt_base[d], 1);   // zero after the scan of the (still empty) table sizes: used as the counter
+    amh_atomic_inc_grouped(B.dt_base, d);   // zero after the scan of the (still empty) table sizes: used as the counter
   }
 }
 AMH_DEV void k_dt_size(const BatchDev& B, u32 d) {
