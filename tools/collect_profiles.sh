@@ -13,4 +13,5 @@ timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fet
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_${TAG} -o w -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $O/${TAG}_pmc_w.json 2> $O/${TAG}_pmc_w.err
 timeout -k 10 400 python3 $R/bench.py --workload merge --steps 2 --warmup 1 > $O/${TAG}_bench_merge.json 2> $O/${TAG}_bench_merge.err
 timeout -k 10 300 python3 $R/bench.py --workload sync --steps 3 --warmup 1 > $O/${TAG}_bench_sync.json 2> $O/${TAG}_bench_sync.err
+timeout -k 10 300 python3 $R/bench.py --workload apply --steps 3 --warmup 1 --no-cpu > $O/${TAG}_bench_apply.json 2> $O/${TAG}_bench_apply.err
 ls -la $O/prof_${TAG} $O/pmc_fetch_${TAG} $O/pmc_write_${TAG}
