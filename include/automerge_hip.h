@@ -106,7 +106,9 @@ typedef struct amh_batch_stats {
 
 /* ---- context ----------------------------------------------------------------------------- */
 /* n_gpus must be 1: one context (and one process) per GPU; multi-GPU = one rank per GPU sharding
- * the batch by document. */
+ * the batch by document.  A context owns two HIP streams (the main chain and a side stream
+ * for kernels that are independent of it), a caching device allocator and a pinned staging area; calls on one
+ * context must not overlap (one caller thread at a time), every call returns with both streams drained. */
 amh_ctx* amh_ctx_create(const int* gpu_ids, int n_gpus);
 void amh_ctx_destroy(amh_ctx*);
 const char* amh_last_error(const amh_ctx*);   /* message of the last failed call (may be NULL ctx) */
