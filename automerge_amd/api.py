@@ -41,6 +41,7 @@ EXPORTS = [
     "amh_changes", "amh_hydrate_json", "amh_doc_max_op", "amh_merge_batch", "amh_apply_changes", "amh_save_batch",
     "amh_sync_summaries", "amh_ctx_set_profiling", "amh_ctx_num_kernels", "amh_ctx_kernel_name", "amh_ctx_kernel_time",
     "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free", "amh_apply_batch", "amh_doc_queue_len", "amh_merge_many", "amh_save_after",
+    "amh_sync_summaries_noalloc",
 ]
 
 DOC_ERRORS = {
@@ -87,6 +88,7 @@ def bind(lib):
                                       C.POINTER(BytesOut), C.POINTER(C.POINTER(C.c_uint64))]
     lib.amh_u64_free.argtypes = [C.POINTER(C.c_uint64)]
     lib.amh_sync_summaries.argtypes = [vp, vp, C.POINTER(BytesOut)]
+    lib.amh_sync_summaries_noalloc.argtypes = [vp, vp, vp, C.c_size_t, vp]
     lib.amh_save_batch.argtypes = [vp, vp, C.POINTER(SaveOpts), C.POINTER(BytesOut)]
     lib.amh_merge_batch.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]
     lib.amh_apply_changes.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t]
@@ -303,6 +305,12 @@ class Batch:
         raw = C.string_at(o.data, o.len) if o.len else b""
         self.engine.lib.amh_bytes_free(C.byref(o))
         return raw
+
+    def sync_summaries_noalloc(self, d_out_ptr, cap, d_meta_ptr):
+        """amh_sync_summaries_noalloc: records into the caller's device buffer (raw device addresses), nothing allocated."""
+        rc = self.engine.lib.amh_sync_summaries_noalloc(self.engine.ctx, self.h, d_out_ptr, cap, d_meta_ptr)
+        if rc != 0:
+            raise EngineError(f"amh_sync_summaries_noalloc failed: {rc} {self.engine._err()}")
 
     def sync_summaries(self):
         """Per document: dict(doc, status, heads=[32-byte hashes, sorted], bloom=bytes) — get_heads + make_bloom_filter(last_sync=[])."""

@@ -397,12 +397,15 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   if (!ok) return fail("device out of memory");
   rt_memset(B.s_row, 0xFF, NS * 4, ctx->stream);
   rt_memset(B.r_doc, 0xFF, NR * 4, ctx->stream);
-  // "absent column" defaults of the nullable op columns (the staged decoders skip columns no document of a wave has)
-  rt_memset(B.r_obj_actor, 0xFF, NR * 4, ctx->stream); rt_memset(B.r_obj_ctr, 0xFF, NR * 4, ctx->stream);
-  rt_memset(B.r_key_actor, 0xFF, NR * 4, ctx->stream); rt_memset(B.r_key_ctr, 0xFF, NR * 4, ctx->stream);
+  // "absent column" defaults of the two string columns (their staged decoder skips columns no document of a wave has);
+  // every other column writes its own nulls (amh_segdec.inl)
   rt_memset(B.r_key_off, 0, NR * 4, ctx->stream); rt_memset(B.r_key_len, 0xFF, NR * 4, ctx->stream);
   rt_memset(B.r_mark_off, 0, NR * 4, ctx->stream); rt_memset(B.r_mark_len, 0xFF, NR * 4, ctx->stream);
+#ifdef AMH_EMU
+  rt_memset(B.r_obj_actor, 0xFF, NR * 4, ctx->stream); rt_memset(B.r_obj_ctr, 0xFF, NR * 4, ctx->stream);
+  rt_memset(B.r_key_actor, 0xFF, NR * 4, ctx->stream); rt_memset(B.r_key_ctr, 0xFF, NR * 4, ctx->stream);
   rt_memset(B.r_expand, 0, NR, ctx->stream);
+#endif
   rt_memset(B.chg_actor_map, 0, ((size_t)b->tot_map + 1) * 4, ctx->stream);
   launch(ctx, AK_ACTORS, B, n);
   launch(ctx, AK_CHG_INIT, B, B.tot_chg);
@@ -1729,11 +1732,13 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     ap.d_u_chg = balloc<u32>(hb, NR, &ok); ap.d_u_fill = balloc<u32>(hb, NR, &ok);
     if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
     rt_memset(U.r_doc, 0xFF, NR * 4, ctx->stream);
-    rt_memset(U.r_obj_actor, 0xFF, NR * 4, ctx->stream); rt_memset(U.r_obj_ctr, 0xFF, NR * 4, ctx->stream);
-    rt_memset(U.r_key_actor, 0xFF, NR * 4, ctx->stream); rt_memset(U.r_key_ctr, 0xFF, NR * 4, ctx->stream);
     rt_memset(U.r_key_off, 0, NR * 4, ctx->stream); rt_memset(U.r_key_len, 0xFF, NR * 4, ctx->stream);
     rt_memset(U.r_mark_off, 0, NR * 4, ctx->stream); rt_memset(U.r_mark_len, 0xFF, NR * 4, ctx->stream);
+#ifdef AMH_EMU
+    rt_memset(U.r_obj_actor, 0xFF, NR * 4, ctx->stream); rt_memset(U.r_obj_ctr, 0xFF, NR * 4, ctx->stream);
+    rt_memset(U.r_key_actor, 0xFF, NR * 4, ctx->stream); rt_memset(U.r_key_ctr, 0xFF, NR * 4, ctx->stream);
     rt_memset(U.r_expand, 0, NR, ctx->stream);
+#endif
     rt_memset(U.s_row, 0xFF, NS * 4, ctx->stream);
     launch(ctx, AK_DECODE_OPS, U, NCH * OC_COUNT);
     mg0(MK_AP_VERIFY, tot_rows);
@@ -2325,6 +2330,26 @@ extern "C" int amh_sync_summaries(amh_ctx* ctx, const amh_batch* bc, amh_bytes_o
   out->len = total;
   collect_profile(ctx);
   return AMH_SUCCESS;
+}
+
+// The same records written into the caller's device buffer, with nothing allocated on the host or the device: no pool,
+// no event, no copy to the host (include/automerge_hip.h).  Returns when the kernels are queued on the context's stream
+// and waits for them (hipStreamSynchronize allocates nothing), so d_out / d_meta are complete on return.
+extern "C" int amh_sync_summaries_noalloc(amh_ctx* ctx, const amh_batch* b, uint8_t* d_out, size_t cap, uint32_t* d_meta) {
+  if (!ctx || !b || !d_meta || (cap && !d_out)) { set_error(ctx, "invalid argument"); return AMH_ERR_INVALID_ARG; }
+#ifdef AMH_EMU
+  return AMH_ERR_UNIMPLEMENTED;
+#else
+  if (b->B.n_docs > AMH_NOALLOC_MAX_DOCS) { set_error(ctx, "amh_sync_summaries_noalloc: more than 1,048,576 documents in the batch (static scratch limit)"); return AMH_ERR_BATCH_TOO_LARGE; }
+  if (cap > 0xFFFFFFFFull) cap = 0xFFFFFFFFull;   // record offsets are 32-bit
+  rt_set_device(ctx->device);
+  const char* err = nullptr;
+  int rc = amh_sync_noalloc_run(b->B, ctx->device, d_out, (u32)cap, d_meta, (void*)ctx->stream, &err);
+  if (rc == 2) { set_error(ctx, err ? err : "over the static limit"); return AMH_ERR_BATCH_TOO_LARGE; }
+  if (rc != 0) { set_error(ctx, err ? err : "device error"); return AMH_ERR_DEVICE; }
+  if (!rt_sync(ctx->stream)) { set_error(ctx, std::string("device pipeline failed: ") + rt_last_error()); return AMH_ERR_DEVICE; }
+  return AMH_SUCCESS;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

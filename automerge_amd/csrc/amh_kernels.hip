@@ -239,17 +239,14 @@ __device__ __forceinline__ void decode_col_body(const BatchDev& B, DecShared& S)
   }
   if ((COL == OC_ID_CTR || COL == OC_SUCC_CTR) && live && !failed && cnt) amh_atomic_max(&B.doc_max_op[dd], mx);
 }
-// all 15 column streams in one launch: blockIdx.y = column (uniform per wave), blockIdx.x = 64 documents
-__global__ void __launch_bounds__(64) g_decode_cols(BatchDev B) {
+// the two string columns (map keys, mark names): blockIdx.y = column (uniform per wave), blockIdx.x = 64 documents.
+// Every other column goes through the segment-parallel decoder (amh_segdec.inl).
+__global__ void __launch_bounds__(64) g_decode_strs(BatchDev B) {
   __shared__ DecShared S;
-  switch (blockIdx.y) {
-#define DC(col) case col: decode_col_body<col>(B, S); break;
-    DC(OC_OBJ_ACTOR) DC(OC_OBJ_CTR) DC(OC_KEY_ACTOR) DC(OC_KEY_CTR) DC(OC_KEY_STR) DC(OC_ID_ACTOR) DC(OC_ID_CTR) DC(OC_INSERT)
-    DC(OC_ACTION) DC(OC_VAL_META) DC(OC_SUCC_NUM) DC(OC_SUCC_ACTOR) DC(OC_SUCC_CTR) DC(OC_EXPAND) DC(OC_MARK_NAME)
-#undef DC
-    default: break;
-  }
+  if (blockIdx.y == 0) decode_col_body<OC_KEY_STR>(B, S);
+  else decode_col_body<OC_MARK_NAME>(B, S);
 }
+#include "amh_segdec.inl"
 
 // ------------------------------------------------------------------------------------------
 // Row / succ / change / dep counts (device form of k_count), same staging as the column decode:
@@ -854,7 +851,8 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (k == AK_COUNT) { hipLaunchKernelGGL(g_count_lds, dim3((B.n_docs + 63) / 64), dim3(64), 0, s, B); return; }
   if (k == AK_DECODE_OPS) {
-    hipLaunchKernelGGL(g_decode_cols, dim3((B.n_docs + 63) / 64, OC_COUNT), dim3(64), 0, s, B);
+    hipLaunchKernelGGL(g_decode_strs, dim3((B.n_docs + 63) / 64, 2), dim3(64), 0, s, B);
+    hipLaunchKernelGGL(g_decode_seg, dim3((B.n_docs + SD_WAVES - 1) / SD_WAVES, SD_NCOLS), dim3(64 * SD_WAVES), 0, s, B);
     return;
   }
   if (k == AK_SAVE_SIZE) { hipLaunchKernelGGL((g_save_lds<false>), dim3((B.n_docs + 63) / 64, 8), dim3(64), 0, s, B); return; }
@@ -1156,4 +1154,54 @@ __global__ void __launch_bounds__(AMH_BLOCK) g_copy_segments(const u64* src, con
 void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void* stream) {
   if (n == 0) return;
   hipLaunchKernelGGL(g_copy_segments, dim3(n), dim3(AMH_BLOCK), 0, (hipStream_t)stream, src, len, dst_off, dst);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// amh_sync_summaries_noalloc (include/automerge_hip.h): the sync summaries of a batch written into the caller's device
+// buffer with no allocation of any kind.  What amh_sync_summaries takes from the pool per call — the record offsets
+// and the scan's tile sums — lives in this file-scope device array instead.  Each GPU the library runs on holds its own
+// copy of the array (at its own address) until the process ends; every call on a GPU shares it, so calls that overlap
+// on one GPU race.  Nothing in it has to start at zero: the size kernel writes sync_off[0 .. n), the scan writes
+// sync_off[n] and every tile sum before it reads it.
+// ------------------------------------------------------------------------------------------
+#define AMH_NOALLOC_SCAN_WORDS 1024u   // amh_scan_tmp_words(AMH_NOALLOC_MAX_DOCS) = 512 + 1 + 2, rounded up
+#define AMH_NOALLOC_WORDS (AMH_NOALLOC_MAX_DOCS + 64u + AMH_NOALLOC_SCAN_WORDS)
+static __device__ __align__(256) u32 scratch[AMH_NOALLOC_WORDS];   // 4 MiB + 4 KiB
+#define AMH_NOALLOC_MAX_DEVICES 64
+static u32* g_scratch_ptr[AMH_NOALLOC_MAX_DEVICES];                // device address of `scratch` on each GPU (never the array's name)
+
+__global__ void g_sync_meta(const u32* total, u32 cap, u32* meta) {
+  u32 t = *total;
+  meta[0] = t;
+  meta[1] = t > cap ? 1u : 0u;
+}
+
+int amh_sync_noalloc_run(const BatchDev& B0, int device, u8* d_out, u32 cap, u32* d_meta, void* stream, const char** err) {
+  hipStream_t s = (hipStream_t)stream;
+  if (device < 0 || device >= AMH_NOALLOC_MAX_DEVICES) { *err = "device index out of range"; return 1; }
+  if (B0.n_docs > AMH_NOALLOC_MAX_DOCS) { *err = "too many documents for the static scratch area (AMH_NOALLOC_MAX_DOCS)"; return 2; }
+  if (amh_scan_tmp_words(B0.n_docs) > AMH_NOALLOC_SCAN_WORDS) { *err = "scan scratch too small"; return 2; }
+  if (!g_scratch_ptr[device]) {   // once per device, with that device current
+    if (hipSetDevice(device) != hipSuccess) { *err = "hipSetDevice failed"; return 1; }
+    u32* p = nullptr;
+    if (hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) { *err = "hipGetSymbolAddress(scratch) failed"; return 1; }
+    g_scratch_ptr[device] = p;
+  }
+  u32* ptr = g_scratch_ptr[device];
+  BatchDev B = B0;
+  const u32 n = B.n_docs;
+  B.sync_off = ptr;
+  B.sync_out = d_out;
+  B.sync_cap = cap ? cap : 1u;   // 0 would mean "no limit": a zero-capacity buffer receives nothing
+  if (n == 0) {
+    if (hipMemsetAsync(d_meta, 0, 2 * sizeof(u32), s) != hipSuccess) { *err = "hipMemsetAsync failed"; return 1; }
+    return 0;
+  }
+  amh_launch(AK_SYNC_SIZE, B, n, stream);
+  amh_scan_inplace(ptr, n, ptr + AMH_NOALLOC_MAX_DOCS + 64u, stream);
+  amh_launch(AK_SYNC_FILL, B, n, stream);
+  hipLaunchKernelGGL(g_sync_meta, dim3(1), dim3(1), 0, s, (const u32*)(ptr + n), cap, d_meta);
+  if (hipGetLastError() != hipSuccess) { *err = "kernel launch failed"; return 1; }
+  return 0;
 }

@@ -181,6 +181,7 @@ struct BatchDev {
   u8* sv_out;
   u32* sync_off;                 // [n_docs + 1] record offsets of the sync summaries
   u8* sync_out;
+  u32 sync_cap;                  // 0 = sync_out holds every record; else its capacity: records that end beyond it are not written
 };
 
 // ---------------------------------------------------------------------------------------------

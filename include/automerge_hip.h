@@ -200,6 +200,15 @@ int amh_save_after(const amh_batch*, uint32_t doc, const uint8_t* heads32, size_
  * heads[32 x n], u32 bloom_len, bloom bytes (BloomFilter::to_bytes: uleb n, uleb 10, uleb 7, bits).
  * The all-gather across ranks is done by the caller's torch.distributed group. */
 int amh_sync_summaries(amh_ctx*, const amh_batch*, amh_bytes_out* out);
+/* No counterpart in the reference.  For callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  The records of amh_sync_summaries, byte for byte, written into the
+ * caller's DEVICE buffer d_out (cap bytes); d_meta (device, 2 x u32) receives {total bytes of all records, 1 if cap
+ * was too small}: a record that would end beyond cap is not written, the ones in front of it are.  The call allocates
+ * nothing on the host or the device (no pool, no event, no host copy): record offsets and scan temporaries live in a
+ * static device array inside the library (4 MiB per GPU the library runs on, held until the process ends).
+ * Limit: at most 1,048,576 documents in the batch (AMH_ERR_BATCH_TOO_LARGE beyond).  Calls on one GPU share that
+ * array: calls that overlap on one GPU (two contexts, two threads) race.  Returns with the stream drained. */
+int amh_sync_summaries_noalloc(amh_ctx*, const amh_batch*, uint8_t* d_out, size_t cap, uint32_t* d_meta);
 
 /* ---- measurement ------------------------------------------------------------------------------
  * HIP-event timing of every kernel launch of the context's stream (for bench.py's roofline leg). */
