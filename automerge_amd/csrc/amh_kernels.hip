@@ -849,7 +849,7 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
 void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
   if (n == 0) return;
   hipStream_t s = (hipStream_t)stream;
-  if (k == AK_COUNT) { hipLaunchKernelGGL(g_count_lds, dim3((B.n_docs + 63) / 64), dim3(64), 0, s, B); return; }
+  if (k == AK_COUNT) { hipLaunchKernelGGL(g_count_seg, dim3((B.n_docs + SD_WAVES - 1) / SD_WAVES, 2), dim3(64 * SD_WAVES), 0, s, B); return; }
   if (k == AK_DECODE_OPS) {
     hipLaunchKernelGGL(g_decode_strs, dim3((B.n_docs + 63) / 64, 2), dim3(64), 0, s, B);
     hipLaunchKernelGGL(g_decode_seg, dim3((B.n_docs + SD_WAVES - 1) / SD_WAVES, SD_NCOLS), dim3(64 * SD_WAVES), 0, s, B);

@@ -7,20 +7,23 @@
 //   tile    256 column bytes -> LDS (one coalesced dword load per lane)
 //   tokens  LEB128 boundaries = bytes without the continuation bit: 4 ballots give the rank of every token end, the end
 //           offsets go to LDS in token order (a token that does not end inside the tile is left for the next tile, which
-//           starts at its first byte: nothing but four scalars is carried between tiles)
-//   values  lane t decodes token t out of LDS (one unaligned 8-byte peek, the 7-bit groups packed in registers)
-//   headers which tokens are run headers is a chain (a header says where the next one is).  Run and null headers hop by
-//           exactly 2 tokens, so from a header at p the chain visits p, p + 2, ... until it meets a NEGATIVE token at that
-//           parity: one ballot of the signs + scalar bit arithmetic resolves every run / null header up to the next
-//           literal header at once; the scalar loop iterates per LITERAL header only
+//           starts at its first byte: nothing but a few scalars is carried between tiles)
+//   values  lane t decodes token t out of LDS (one unaligned peek, the 7-bit groups packed in registers).  Groups whose
+//           tokens all fit 4 bytes (values below 2^28: nearly everything) run in 32-bit arithmetic, the others in 64-bit
+//   headers which tokens are run headers is a chain (a header says where the next one is: 2 tokens on for a run or a
+//           null run, 1 + n for a literal run of n).  No literal header in sight: the headers are every second token
+//           (bit arithmetic on one ballot).  Otherwise pointer doubling over the 64 tokens: 5 rounds of "reached tokens
+//           flag their successor in LDS, every token squares its successor function" — vector work of fixed cost,
+//           because the scalar unit is shared by the four SIMDs of a CU and a scalar loop per header starved it
 //   items   run header -> (count, value of the next token); null header -> (count = next token, null); literal value ->
 //           (1, own value).  An exclusive wave scan of the counts gives every item its first row; a second scan carries
 //           the running sum of a delta column (or the raw-value offsets, or the succ bases) across the items
-//   expand  64 rows at a time: item starts are scattered into an LDS row of flags, an inclusive max-scan turns them into
-//           "item of this row", the item's fields come over by ds_bpermute, one coalesced store per output array
+//   expand  64 rows at a time.  A group of literal values only: every item is one row, the values are compacted through
+//           LDS.  Otherwise item starts are scattered into an LDS row of flags, an inclusive max-scan turns them into
+//           "item of this row", the item's fields come over by ds_bpermute.  One coalesced store per output array.
 //
 // Error semantics are the serial decoder's: a malformed token only fails the document if the decoder would have read
-// it before producing the last row it was asked for (row index of the token < rows wanted); the first such token in
+// it before producing the last row it was asked for (rows in front of the token < rows wanted); the first such token in
 // stream order decides the error kind.  A column that ends early yields nulls where the reference's iterator does
 // (`None`), and fails where it is required.
 #pragma once
@@ -31,12 +34,13 @@
 struct SdWave {
   u32 tile[SD_TILE / 4 + 4];   // + 16 bytes: the 8-byte peek of the last token may read past the tile
   unsigned short tokend[SD_TILE];
-  u32 xs[64];
+  u32 xs[64], ys[64];
+  u8 flag[192];              // header flags [0, 64], then one scratch slot per lane
 };
 
 #include "amh_segdec_prims.inl"
 
-// what the wave carries from tile to tile
+// what the wave carries from group to group (all uniform)
 struct SdStream {
   const u8* src;      // arena address of the document's chunk
   u32 pos, end;       // byte cursor / end of the column, chunk relative
@@ -44,17 +48,20 @@ struct SdStream {
   u32 row;            // rows produced
   u64 lit;            // values of an open literal run still to come
   u32 btok;           // boolean columns: tokens consumed so far (parity = value)
-  i32 err;            // first error (0 = none)
+  u64 acc;            // delta: running value; value meta: raw offset; succ count: entries so far
 };
 
+template <bool WIDE> struct SdT { typedef u32 U; typedef i32 S; };
+template <> struct SdT<true> { typedef u64 U; typedef i64 S; };
+
 // One group of <= 64 tokens, one per lane, classified: what every lane's token contributes.
-struct SdItems {
-  u32 cnt;            // rows of this lane's item (0: the token is a header of a literal run, a run's value, ...), clamped to the rows still wanted
+template <bool WIDE> struct SdItems {
+  u32 cnt;            // rows of this lane's item (0: the token is the header of a literal run, a run's value, ...), clamped to the rows still wanted
   u32 rs;             // rows of the group in front of the item (exclusive scan of cnt)
   u32 total;          // rows of the whole group (uniform; may exceed what is wanted)
   bool isnull;
-  u64 u;              // value as unsigned LEB128
-  i64 s;              // value as signed LEB128
+  typename SdT<WIDE>::U u;   // value as unsigned LEB128
+  typename SdT<WIDE>::S s;   // value as signed LEB128
 };
 
 enum { SD_RLE_U = 0, SD_RLE_S = 1, SD_BOOL = 2 };
@@ -83,11 +90,9 @@ __device__ __forceinline__ u32 sd_load_tile(SdWave& W, const SdStream& S, u32 la
   return ntok;
 }
 
-// token t of the tile: value both ways; ok_u / ok_s = a valid u64 / i64 for the lenient readers (decodable_impls.rs:58-96)
-__device__ __forceinline__ void sd_token(const SdWave& W, u32 t, u32 skip, u64& u, i64& s, bool& ok_u, bool& ok_s) {
-  u32 e = W.tokend[t];
-  u32 b0 = t ? (u32)W.tokend[t - 1] + 1 : skip;
-  u32 nb = e - b0 + 1;
+// token starting at tile byte b0, nb bytes: value both ways; ok_u / ok_s = a valid u64 / i64 for the lenient readers
+// (decodable_impls.rs:58-96)
+__device__ __forceinline__ void sd_token64(const SdWave& W, u32 b0, u32 nb, u64& u, i64& s, bool& ok_u, bool& ok_s) {
   const u32* w = W.tile + (b0 >> 2);
   u32 w0 = w[0], w1 = w[1], w2 = w[2];
   u32 sh = (b0 & 3) * 8;
@@ -113,251 +118,389 @@ __device__ __forceinline__ void sd_token(const SdWave& W, u32 t, u32 skip, u64& 
     else if (nb == 10) { ok_u = b <= 1; ok_s = b == 0 || b == 0x7f; }
   }
 }
+// the same for a token of at most 4 bytes
+__device__ __forceinline__ void sd_token32(const SdWave& W, u32 b0, u32 nb, u32& u, i32& s) {
+  const u32* w = W.tile + (b0 >> 2);
+  u32 w0 = w[0], w1 = w[1];
+  u32 x = __builtin_amdgcn_alignbyte(w1, w0, b0 & 3);
+  x &= 0xFFFFFFFFu >> (32 - 8 * nb);
+  x = (x & 0x007f007fu) | ((x & 0x7f007f00u) >> 1);
+  x = (x & 0x00003fffu) | ((x & 0x3fff0000u) >> 2);
+  u = x;
+  u32 sh = 32 - 7 * nb;
+  s = (i32)(x << sh) >> sh;
+}
 
-// The next group of tokens of the tile, from token t0.  Returns the number of tokens consumed (uniform; 0 = the group
-// ends in a header whose value lies in the next tile, or nothing is left).  terr = this lane's token (or the value token
-// behind its header) is malformed for the role it plays.
-template <int KIND>
-__device__ __forceinline__ u32 sd_group(const SdWave& W, SdStream& S, u32 lane, u32 t0, u32 ntok, u32 skip, SdItems& I, bool& terr) {
-  const u32 m = ntok - t0 < 64 ? ntok - t0 : 64;
-  u64 u = 0; i64 s = 0; bool ok_u = true, ok_s = true;
-  if (lane < m) sd_token(W, t0 + lane, skip, u, s, ok_u, ok_s);
+// The group of tokens t0 .. t0 + m of the tile (lane = token; b0 / nb = where the lane's token lies).  Returns the number
+// of tokens consumed (uniform; 0 = the group ends in a header whose value lies in the next tile).  terr = this lane's
+// token (or the value token behind its header) is malformed for the role it plays.  lit / btok: the stream's state
+// behind the consumed tokens (the caller commits them).
+template <int KIND, bool WIDE>
+__device__ __forceinline__ u32 sd_group(SdWave& W, const SdStream& S, u32 lane, u32 m, u32 b0, u32 nb, SdItems<WIDE>& I, bool& terr, u64& lit_out, u32& btok_out) {
+  typedef typename SdT<WIDE>::U UV;
+  typedef typename SdT<WIDE>::S SV;
+  UV u = 0; SV s = 0; bool ok_u = true, ok_s = true;
+  if (WIDE) { u64 uu = 0; i64 ss = 0; if (lane < m) sd_token64(W, b0, nb, uu, ss, ok_u, ok_s); u = (UV)uu; s = (SV)ss; }
+  else { u32 uu; i32 ss; sd_token32(W, b0, nb, uu, ss); if (lane >= m) { uu = 0; ss = 0; } u = (UV)uu; s = (SV)ss; }
   const u32 rem = S.want - S.row;
   u32 c;
-  u64 cnt64 = 0;
+  UV cnt = 0;
   bool isnull = false;
   terr = false;
+  I.u = 0; I.s = 0;
+  lit_out = S.lit; btok_out = S.btok;
   if (KIND == SD_BOOL) {   // every token is a count; the value alternates, starting with false (boolean.rs:84-101)
     c = m;
-    if (lane < m) { cnt64 = u; terr = !ok_u; }
+    if (lane < m) { cnt = u; terr = !ok_u; }
     I.u = (S.btok + lane) & 1;   // the value the count stands for
-    I.s = 0;
-    S.btok += c;
+    btok_out = S.btok + c;
   } else {
+    // Which tokens are headers.  In front: p0 values of a literal run that opened in an earlier group.
     const u64 NEG = __ballot(lane < m && s < 0);
-    u64 HDR = 0, LITH = 0, LITV = 0;
-    u64 lit = S.lit;
-    u32 p = 0;
-    if (lit) { u32 k = lit < m ? (u32)lit : m; LITV = sd_low_bits(k); lit -= k; p = k; }
-    while (p < m) {
-      u64 par = 0x5555555555555555ull << (p & 1), above = ~(u64)0 << p;
-      u64 cand = NEG & par & above;
-      if (!cand) {   // run / null headers to the end of the group; each needs its value token inside the group
-        u64 hm = par & above & sd_low_bits(m - 1);
-        HDR |= hm;
-        p += 2 * (u32)__builtin_popcountll(hm);
-        break;
+    const u32 p0 = S.lit < m ? (u32)S.lit : m;
+    u64 lit = S.lit - p0;
+    bool reach = false;
+    c = m;
+    if (p0 < m) {
+      if (!(NEG >> p0)) {
+        // no literal header in sight: run / null headers hop by 2, each needs its value token inside the group
+        const u64 hm = (0x5555555555555555ull << (p0 & 1)) & (~(u64)0 << p0) & sd_low_bits(m - 1);
+        reach = (hm >> lane) & 1;
+        c = p0 + 2 * (u32)__builtin_popcountll(hm);
+      } else {
+        // the chain of headers by pointer doubling: a header at t names the next one at J(t) = t + 2 (run, null) or
+        // t + 1 + n (literal run of n); a chain makes at most 32 hops inside 64 tokens = 5 rounds.  Reached tokens are
+        // flagged in LDS (lanes that are not reached yet write to a slot of their own behind the flags).
+        u32 hop = 2;
+        if (s < 0) { UV n = (UV)0 - (UV)s; hop = 1 + (n < 64 ? (u32)n : 64u); }
+        const u32 jraw = lane + hop;
+        u32 J = jraw < 64 ? jraw : 64;
+        reach = lane == p0;
+        sd_lds_sync();
+        W.flag[lane] = reach ? 1 : 0;
+        sd_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+          W.flag[reach ? J : 65 + lane] = 1;
+          sd_lds_sync();
+          reach = W.flag[lane] != 0;
+          u32 jn = (u32)__shfl((int)J, (int)(J & 63), 64);
+          J = J >= 64 ? 64 : jn;
+          sd_lds_sync();
+        }
+        reach = reach && lane < m;
+        // the last header decides where the group ends and what it leaves open
+        const u32 h = 63 - (u32)__builtin_clzll(__ballot(reach));
+        if ((NEG >> h) & 1) {
+          u64 n = WIDE ? (u64)0 - sd_bcast64((u64)s, h) : (u64)((u32)0 - sd_bcast((u32)s, h));
+          lit = h + 1 + n - m;            // the run ends at or behind the end of the group (else a later header were reached)
+        } else if (h + 2 > m) c = h;      // its value token lies in the next group / tile
       }
-      u32 q = (u32)__builtin_ctzll(cand);
-      HDR |= par & above & sd_low_bits(q);
-      LITH |= (u64)1 << q;
-      u64 nlit = (u64)0 - (u64)sd_bcast64((u64)s, q);
-      u32 room = m - (q + 1);
-      u32 k = nlit < room ? (u32)nlit : room;
-      if (k) LITV |= sd_low_bits(k) << (q + 1);
-      lit = nlit - k;
-      p = q + 1 + k;
     }
-    c = p < m ? p : m;
-    S.lit = lit;
-    const bool is_hdr = (HDR >> lane) & 1, is_lith = (LITH >> lane) & 1, is_litv = (LITV >> lane) & 1;
+    lit_out = lit;
+    const bool prev_rh = sd_prev((u32)(reach && s >= 0)) != 0;   // the token in front is a run / null header: this is its value
+    const bool is_hdr = reach && s >= 0 && lane < c, is_lith = reach && s < 0, is_litv = lane < c && !reach && !prev_rh;
     // the token behind a run / null header
-    u64 nu = (u64)__shfl_down((u32)u, 1, 64) | ((u64)__shfl_down((u32)(u >> 32), 1, 64) << 32);
-    i64 ns = (i64)((u64)__shfl_down((u32)s, 1, 64) | ((u64)__shfl_down((u32)((u64)s >> 32), 1, 64) << 32));
-    bool n_ok_u = __shfl_down((int)ok_u, 1, 64), n_ok_s = __shfl_down((int)ok_s, 1, 64);
+    UV nu; SV ns; bool n_ok_u = true, n_ok_s = true;
+    if (WIDE) {
+      nu = (UV)((u64)sd_next((u32)u) | ((u64)sd_next((u32)((u64)u >> 32)) << 32));
+      ns = (SV)((u64)sd_next((u32)s) | ((u64)sd_next((u32)((u64)s >> 32)) << 32));
+      n_ok_u = sd_next((u32)ok_u); n_ok_s = sd_next((u32)ok_s);
+    } else { nu = (UV)sd_next((u32)u); ns = (SV)sd_next((u32)s); }
     if (is_hdr) {
-      if (s > 0) { cnt64 = (u64)s; I.u = nu; I.s = ns; terr = !ok_s || !(KIND == SD_RLE_S ? n_ok_s : n_ok_u); }
-      else { cnt64 = nu; isnull = true; I.u = 0; I.s = 0; terr = !ok_s || !n_ok_u || nu > (u64)INT64_MAX; }
+      if (s > 0) { cnt = (UV)s; I.u = nu; I.s = ns; terr = !ok_s || !(KIND == SD_RLE_S ? n_ok_s : n_ok_u); }
+      else { cnt = nu; isnull = true; terr = !ok_s || !n_ok_u || (WIDE && (u64)nu > (u64)INT64_MAX); }
     } else if (is_litv) {
-      cnt64 = 1; I.u = u; I.s = s; terr = !(KIND == SD_RLE_S ? ok_s : ok_u);
+      cnt = 1; I.u = u; I.s = s; terr = !(KIND == SD_RLE_S ? ok_s : ok_u);
     } else if (is_lith) {
       terr = !ok_s;
     }
-    if (lane >= c) { cnt64 = 0; terr = false; }
+    if (lane >= c) { cnt = 0; terr = false; }
   }
   I.isnull = isnull;
-  I.cnt = cnt64 < rem ? (u32)cnt64 : rem;
+  I.cnt = cnt < rem ? (u32)cnt : rem;
   u32 inc = sd_scan_add(I.cnt);
   I.rs = inc - I.cnt;
   I.total = sd_bcast(inc, 63);
   return c;
 }
 
-// rows [r0, r0 + 64) of a group: the lane (= item) each row belongs to.  Needs I.total > r0.
-__device__ __forceinline__ u32 sd_row_item(SdWave& W, const SdItems& I, u32 lane, u32 r0) {
+// rows [r0, r0 + 64) of a group: the lane (= item) each row belongs to.  Needs total > r0.
+__device__ __forceinline__ u32 sd_row_item(SdWave& W, u32 cnt, u32 rs, u32 lane, u32 r0) {
   sd_lds_sync();
   W.xs[lane] = 0;
   sd_lds_sync();
-  const bool has = I.cnt != 0;
-  if (has && I.rs >= r0 && I.rs < r0 + 64) W.xs[I.rs - r0] = lane + 1;
+  const bool has = cnt != 0;
+  if (has && rs >= r0 && rs < r0 + 64) W.xs[rs - r0] = lane + 1;
   sd_lds_sync();
-  u64 cover = __ballot(has && I.rs <= r0 && r0 - I.rs < I.cnt);   // the item that holds row r0: exactly one
+  u64 cover = __ballot(has && rs <= r0 && r0 - rs < cnt);   // the item that holds row r0: exactly one
   u32 f = W.xs[lane];
   if (lane == 0) f = (u32)__builtin_ctzll(cover) + 1;
   return sd_scan_max(f) - 1;
 }
 
-// One column stream.  COL selects what an item means and where its rows go.
-template <u32 COL>
-__device__ __forceinline__ void sd_decode_column(const BatchDev& B, u32 d, SdWave& W) {
-  constexpr bool SUCC_ENTRY = COL == OC_SUCC_ACTOR || COL == OC_SUCC_CTR;
-  constexpr bool IS_DELTA = COL == OC_KEY_CTR || COL == OC_ID_CTR || COL == OC_SUCC_CTR;
-  constexpr bool IS_BOOL = COL == OC_INSERT || COL == OC_EXPAND;
-  constexpr int KIND = IS_BOOL ? SD_BOOL : (IS_DELTA ? SD_RLE_S : SD_RLE_U);
+template <u32 COL> struct SdCol {
+  static constexpr bool SUCC_ENTRY = COL == OC_SUCC_ACTOR || COL == OC_SUCC_CTR;
+  static constexpr bool IS_DELTA = COL == OC_KEY_CTR || COL == OC_ID_CTR || COL == OC_SUCC_CTR;
+  static constexpr bool IS_BOOL = COL == OC_INSERT || COL == OC_EXPAND;
+  static constexpr int KIND = IS_BOOL ? SD_BOOL : (IS_DELTA ? SD_RLE_S : SD_RLE_U);
   // a column that ends early (or is absent): the reference's iterator yields None, which these accept as null
-  constexpr bool NULLABLE = COL == OC_OBJ_ACTOR || COL == OC_OBJ_CTR || COL == OC_KEY_ACTOR || COL == OC_KEY_CTR ||
-                            COL == OC_ID_ACTOR || COL == OC_ID_CTR || COL == OC_EXPAND;
-  const u32 lane = threadIdx.x & 63;
-  const DocDesc& D = B.desc[d];
-  const u32 want = SUCC_ENTRY ? B.cnt[d].n_succ : B.cnt[d].n_rows;
-  if (want == 0) return;
-  const u32 obase = SUCC_ENTRY ? B.succ_base[d] : B.row_base[d];
-  SdStream S;
-  S.src = B.arena + D.chunk_off;
-  S.pos = D.ocol[COL].off;
-  S.end = S.pos + D.ocol[COL].len;
-  S.want = want; S.row = 0; S.lit = 0; S.btok = 0; S.err = 0;
-  u64 acc = 0;                 // delta: running value; value meta: raw offset; succ count: entries so far
-  u32 mx = 0;
-  const u64 raw_len = D.ocol[OC_VAL_RAW].len;
-  const u32 sbase = COL == OC_SUCC_NUM ? B.succ_base[d] : 0;
+  static constexpr bool NULLABLE = COL == OC_OBJ_ACTOR || COL == OC_OBJ_CTR || COL == OC_KEY_ACTOR || COL == OC_KEY_CTR ||
+                                   COL == OC_ID_ACTOR || COL == OC_ID_CTR || COL == OC_EXPAND;
+  static constexpr bool HAS_ACC = IS_DELTA || COL == OC_VAL_META || COL == OC_SUCC_NUM;
+};
+
+template <u32 COL>
+__device__ __forceinline__ void sd_store_row(const BatchDev& B, u32 d, u32 o, u32 a, u32 b, u32 c) {
+  if (COL == OC_KEY_CTR) B.r_key_ctr[o] = c;
+  else if (COL == OC_ID_CTR) { B.r_id_ctr[o] = c; B.r_doc[o] = d; }
+  else if (COL == OC_SUCC_CTR) B.s_ctr[o] = c;
+  else if (COL == OC_VAL_META) { B.r_vmeta[o] = (u64)a | ((u64)b << 32); B.r_vraw_off[o] = c; }
+  else if (COL == OC_SUCC_NUM) { B.r_succ_cnt[o] = a; B.r_succ_base[o] = c; }
+  else if (COL == OC_OBJ_ACTOR) B.r_obj_actor[o] = a;
+  else if (COL == OC_OBJ_CTR) B.r_obj_ctr[o] = a;
+  else if (COL == OC_KEY_ACTOR) B.r_key_actor[o] = a;
+  else if (COL == OC_ID_ACTOR) B.r_id_actor[o] = a;
+  else if (COL == OC_SUCC_ACTOR) B.s_actor[o] = a;
+  else if (COL == OC_ACTION) B.r_action[o] = (u8)a;
+  else if (COL == OC_INSERT) B.r_insert[o] = (u8)a;
+  else if (COL == OC_EXPAND) B.r_expand[o] = (u8)a;
+}
+
+// One group of one column stream: classify, compute the items, check, write the rows, advance the stream.
+// Returns the tokens consumed (0 = none could be), or SD_REDO when 32-bit arithmetic does not hold the group (the
+// caller runs it again with WIDE); fail receives the error that ends the document.
+#define SD_REDO 0xFFFFFFFFu
+template <u32 COL, bool WIDE>
+__device__ __forceinline__ u32 sd_do_group(const BatchDev& B, u32 d, SdWave& W, SdStream& S, u32 lane, u32 m, u32 b0, u32 nb,
+                                           u32 obase, u32 sbase, u32 raw_len, u32& mx, i32& fail) {
+  typedef SdCol<COL> C;
+  SdItems<WIDE> I;
+  bool terr;
+  u64 lit_new; u32 btok_new;
+  const u32 rem = S.want - S.row;
+  const u32 c = sd_group<C::KIND, WIDE>(W, S, lane, m, b0, nb, I, terr, lit_new, btok_new);
+  if (c == 0) return 0;
+  // ---- what the item's rows hold: a (per item), b (per item), cc + step * k for row k of the item -----------------
+  const u32 cnt = I.cnt;
+  const u32 reach = I.rs < rem ? (rem - I.rs < cnt ? rem - I.rs : cnt) : 0;   // rows of the item the decoder delivers
+  i32 ecode = terr ? AMH_E_READ_OP : 0;
+  u32 e0 = 0, e1 = 0, e2 = 0, step = 0;
+  u64 acc_new = S.acc;
+  u32 mx_new = mx;
+  if (C::IS_DELTA) {
+    if (WIDE) {
+      u64 sv = (u64)(i64)I.s;
+      u64 tot = I.isnull ? 0 : sv * cnt;
+      u64 inc = sd_scan_add64(tot);
+      u64 first = S.acc + (inc - tot) + sv;           // value of the item's first row
+      if (I.isnull) { e2 = AMH_NULL32; if (C::SUCC_ENTRY && reach && !ecode) ecode = AMH_E_READ_OP; }
+      else {
+        e2 = (u32)first; step = (u32)sv;
+        if (reach && !ecode) {
+          i64 lo = (i64)first, hi = (i64)(first + sv * (reach - 1));
+          if (lo > hi) { i64 t = lo; lo = hi; hi = t; }
+          if (lo < 0 || hi >= 0xFFFFFFFFll) ecode = AMH_E_READ_OP;   // key.rs:172-179, opid.rs:107-113
+          else if (COL != OC_KEY_CTR && (u32)hi > mx_new) mx_new = (u32)hi;
+        }
+      }
+      acc_new = S.acc + sd_bcast64(inc, 63);
+    } else {
+      // 32-bit: the running value is below 2^30 (caller) and no item moves it by 2^24 or more, so nothing wraps
+      i32 sv = (i32)I.s;
+      u32 mag = sv < 0 ? (u32)-sv : (u32)sv;
+      bool big = !I.isnull && (__umulhi(mag, cnt) != 0 || mag * cnt >= (1u << 24));
+      if (__ballot(big)) return SD_REDO;
+      i32 tot = I.isnull ? 0 : sv * (i32)cnt;
+      i32 inc = (i32)sd_scan_add((u32)tot);
+      i32 first = (i32)(u32)S.acc + (inc - tot) + sv;
+      if (I.isnull) { e2 = AMH_NULL32; if (C::SUCC_ENTRY && reach && !ecode) ecode = AMH_E_READ_OP; }
+      else {
+        e2 = (u32)first; step = (u32)sv;
+        if (reach && !ecode) {
+          i32 lo = first, hi = first + sv * (i32)(reach - 1);
+          if (lo > hi) { i32 t = lo; lo = hi; hi = t; }
+          if (lo < 0) ecode = AMH_E_READ_OP;
+          else if (COL != OC_KEY_CTR && (u32)hi > mx_new) mx_new = (u32)hi;
+        }
+      }
+      acc_new = (u64)((i64)S.acc + (i64)(i32)sd_bcast((u32)inc, 63));
+    }
+  } else if (C::IS_BOOL) {
+    e0 = (u32)I.u;
+  } else if (COL == OC_VAL_META) {
+    u64 uv = (u64)I.u;
+    u64 l = ((uv & 15) >= 3) ? (uv >> 4) : 0;
+    e0 = (u32)uv; e1 = (u32)(uv >> 32);
+    if (WIDE) {
+      u64 tot = l * cnt;
+      u64 inc = sd_scan_add64(tot);
+      u64 first = S.acc + (inc - tot);
+      e2 = (u32)first; step = (u32)l;
+      if (reach && !ecode) {
+        if (I.isnull) ecode = AMH_E_READ_OP;
+        else if ((uv & 15) >= 3) {   // null / bool never touch the raw column (value.rs:221-224)
+          u64 last = first + l * (reach - 1);
+          if (l > raw_len || last > raw_len - l) ecode = AMH_E_READ_OP;
+        }
+      }
+      acc_new = S.acc + sd_bcast64(inc, 63);
+    } else {
+      u32 l32 = (u32)l;
+      bool big = __umulhi(l32, cnt) != 0 || l32 * cnt >= (1u << 24);
+      if (__ballot(big)) return SD_REDO;
+      u32 tot = l32 * cnt;
+      u32 inc = sd_scan_add(tot);
+      u32 first = (u32)S.acc + (inc - tot);
+      e2 = first; step = l32;
+      if (reach && !ecode) {
+        if (I.isnull) ecode = AMH_E_READ_OP;
+        else if ((uv & 15) >= 3) {
+          u32 last = first + l32 * (reach - 1);
+          if (l32 > raw_len || last > raw_len - l32) ecode = AMH_E_READ_OP;
+        }
+      }
+      acc_new = S.acc + sd_bcast(inc, 63);
+    }
+  } else if (COL == OC_SUCC_NUM) {
+    u32 v = (u32)I.u;
+    u32 tot = v * cnt;
+    u32 inc = sd_scan_add(tot);
+    e0 = v; e2 = sbase + (u32)S.acc + (inc - tot); step = v;
+    if (reach && !ecode && I.isnull) ecode = AMH_E_READ_OP;
+    acc_new = S.acc + sd_bcast(inc, 63);
+  } else {   // plain RLE of u64: obj actor / ctr, key actor, id actor, action, succ actor
+    e0 = I.isnull ? AMH_NULL32 : (u32)I.u;
+    if (reach && !ecode) {
+      const bool over = WIDE ? (u64)I.u >= 0xFFFFFFFFull : false;
+      if (COL == OC_ACTION) { if (I.isnull) ecode = AMH_E_READ_OP; else if (I.u > 7) ecode = AMH_E_INVALID_OP; }
+      else if (COL == OC_SUCC_ACTOR) { if (I.isnull) ecode = AMH_E_READ_OP; else if (over) ecode = AMH_E_MISSING_ACTOR; }
+      else if (!I.isnull && over) ecode = COL == OC_OBJ_CTR ? AMH_E_READ_OP : AMH_E_MISSING_ACTOR;
+    }
+  }
+  // a malformed token counts only if the decoder gets to it: rows in front of it < rows wanted
+  const u64 bad = __ballot(ecode != 0 && I.rs < rem);
+  if (bad) { fail = (i32)sd_bcast((u32)ecode, (u32)__builtin_ctzll(bad)); return c; }
+  // ---- expand ------------------------------------------------------------------------------------------------
+  const u32 R = I.total < rem ? I.total : rem;
+  const u32 orow = obase + S.row;
+  if (__ballot(cnt > 1) == 0) {
+    // literal values only (and empty runs): every item is one row, R <= 64; compact through LDS
+    constexpr bool TWO = COL == OC_VAL_META || COL == OC_SUCC_NUM;
+    u32 v1 = (C::IS_DELTA) ? e2 : e0;
+    sd_lds_sync();
+    if (cnt) { W.xs[I.rs] = v1; if (TWO) W.ys[I.rs] = e2; }
+    sd_lds_sync();
+    u32 a = W.xs[lane], cc = TWO ? W.ys[lane] : a, b = 0;
+    if (WIDE && COL == OC_VAL_META) {   // the upper half of a value meta is zero unless WIDE
+      sd_lds_sync();
+      if (cnt) W.xs[I.rs] = e1;
+      sd_lds_sync();
+      b = W.xs[lane];
+    }
+    if (lane < R) sd_store_row<COL>(B, d, orow + lane, a, b, cc);
+  } else {
+    for (u32 r0 = 0; r0 < R; r0 += 64) {
+      const u32 t = sd_row_item(W, cnt, I.rs, lane, r0);
+      const u32 my = r0 + lane;
+      const u32 k = my - (u32)__shfl((int)I.rs, (int)t, 64);
+      u32 a = 0, b = 0, cc = 0;
+      if (C::IS_DELTA) cc = (u32)__shfl((int)e2, (int)t, 64) + (u32)__shfl((int)step, (int)t, 64) * k;
+      else if (COL == OC_VAL_META) {
+        a = (u32)__shfl((int)e0, (int)t, 64);
+        if (WIDE) b = (u32)__shfl((int)e1, (int)t, 64);
+        cc = (u32)__shfl((int)e2, (int)t, 64) + (u32)__shfl((int)step, (int)t, 64) * k;
+      } else if (COL == OC_SUCC_NUM) {
+        a = (u32)__shfl((int)e0, (int)t, 64);
+        cc = (u32)__shfl((int)e2, (int)t, 64) + a * k;
+      } else a = (u32)__shfl((int)e0, (int)t, 64);
+      if (my < R) sd_store_row<COL>(B, d, orow + my, a, b, cc);
+    }
+  }
+  S.row += R;
+  S.lit = lit_new;
+  S.btok = btok_new;
+  S.acc = acc_new;
+  mx = mx_new;
+  return c;
+}
+
+// The walk of one column stream: tiles, groups of tokens, the carry between them.  F supplies what a group means:
+//   template <bool WIDE> u32 group(SdWave&, SdStream&, lane, m, b0, nb, i32& fail)   tokens consumed / 0 / SD_REDO
+//   bool wide(const SdStream&)                                                        force 64-bit arithmetic
+// Returns 0 or the error that ends the document; `stuck` is the error for tokens that cannot be read.  Stops when
+// S.row reaches S.want or the column ends (the caller decides what an early end means; S.lit tells whether it fell
+// inside a literal run).
+template <class F>
+__device__ __forceinline__ i32 sd_walk(SdWave& W, SdStream& S, u32 lane, F& f, i32 stuck) {
   i32 fail = 0;
-  while (S.row < want && S.pos < S.end && !fail) {
+  while (S.row < S.want && S.pos < S.end) {
     u32 tb, skip, avail;
     sd_lds_sync();   // the previous tile has been read
     const u32 ntok = sd_load_tile(W, S, lane, tb, skip, avail);
     u32 t0 = 0;
-    while (t0 < ntok && S.row < want) {
-      SdItems I;
-      bool terr;
-      const u32 rem = want - S.row;
-      const u32 c = sd_group<KIND>(W, S, lane, t0, ntok, skip, I, terr);
-      if (c == 0) break;
-      // ---- what the item's rows hold -----------------------------------------------------------
-      const u32 cnt = I.cnt;
-      const u32 reach = I.rs < rem ? (rem - I.rs < cnt ? rem - I.rs : cnt) : 0;   // rows of the item the decoder delivers
-      i32 ecode = terr ? AMH_E_READ_OP : 0;
-      u32 e0 = 0, e1 = 0, e2 = 0, step = 0;
-      if (IS_DELTA) {
-        u64 tot = I.isnull ? 0 : (u64)I.s * cnt;
-        u64 inc = sd_scan_add64(tot);
-        u64 first = acc + (inc - tot) + (u64)I.s;           // value of the item's first row
-        if (I.isnull) { e2 = AMH_NULL32; step = 0; if (SUCC_ENTRY && reach && !ecode) ecode = AMH_E_READ_OP; }
-        else {
-          e2 = (u32)first; step = (u32)(u64)I.s;
-          if (reach && !ecode) {
-            i64 lo = (i64)first, hi = (i64)(first + (u64)I.s * (reach - 1));
-            if (lo > hi) { i64 t = lo; lo = hi; hi = t; }
-            if (lo < 0 || hi >= 0xFFFFFFFFll) ecode = AMH_E_READ_OP;   // key.rs:172-179, opid.rs:107-113
-            else if (COL != OC_KEY_CTR && (u32)hi > mx) mx = (u32)hi;
-          }
-        }
-        acc += sd_bcast64(inc, 63);
-      } else if (IS_BOOL) {
-        e0 = (u32)I.u;
-      } else if (COL == OC_VAL_META) {
-        u64 l = ((I.u & 15) >= 3) ? (I.u >> 4) : 0;
-        u64 tot = l * cnt;
-        u64 inc = sd_scan_add64(tot);
-        u64 first = acc + (inc - tot);
-        e0 = (u32)I.u; e1 = (u32)(I.u >> 32); e2 = (u32)first; step = (u32)l;
-        if (reach && !ecode) {
-          if (I.isnull) ecode = AMH_E_READ_OP;
-          else if ((I.u & 15) >= 3) {   // null / bool never touch the raw column (value.rs:221-224)
-            u64 last = first + l * (reach - 1);
-            if (l > raw_len || last > raw_len - l) ecode = AMH_E_READ_OP;
-          }
-        }
-        acc += sd_bcast64(inc, 63);
-      } else if (COL == OC_SUCC_NUM) {
-        u32 v = (u32)I.u;
-        u32 tot = v * cnt;
-        u32 inc = sd_scan_add(tot);
-        e0 = v; e2 = sbase + (u32)acc + (inc - tot); step = v;
-        if (reach && !ecode && I.isnull) ecode = AMH_E_READ_OP;
-        acc += sd_bcast(inc, 63);
-      } else {   // plain RLE of u64: obj actor / ctr, key actor, id actor, action, succ actor
-        e0 = I.isnull ? AMH_NULL32 : (u32)I.u;
-        if (reach && !ecode) {
-          if (COL == OC_ACTION) { if (I.isnull) ecode = AMH_E_READ_OP; else if (I.u > 7) ecode = AMH_E_INVALID_OP; }
-          else if (COL == OC_SUCC_ACTOR) { if (I.isnull) ecode = AMH_E_READ_OP; else if (I.u >= 0xFFFFFFFFull) ecode = AMH_E_MISSING_ACTOR; }
-          else if (!I.isnull && I.u >= 0xFFFFFFFFull) ecode = COL == OC_OBJ_CTR ? AMH_E_READ_OP : AMH_E_MISSING_ACTOR;
-        }
-      }
-      // a malformed token counts only if the decoder gets to it: rows in front of it < rows wanted
-      const u64 bad = __ballot(ecode != 0 && I.rs < rem);
-      if (bad) { fail = (i32)sd_bcast((u32)ecode, (u32)__builtin_ctzll(bad)); break; }
-      // ---- expand ------------------------------------------------------------------------------
-      const u32 R = I.total < rem ? I.total : rem;
-      for (u32 r0 = 0; r0 < R; r0 += 64) {
-        const u32 t = sd_row_item(W, I, lane, r0);
-        const u32 my = r0 + lane;
-        const u32 k = my - (u32)__shfl((int)I.rs, (int)t, 64);
-        const u32 o = obase + S.row + my;
-        const bool live = my < R;
-        if (IS_DELTA) {
-          u32 v = (u32)__shfl((int)e2, (int)t, 64) + (u32)__shfl((int)step, (int)t, 64) * k;
-          if (live) {
-            if (COL == OC_KEY_CTR) B.r_key_ctr[o] = v;
-            else if (COL == OC_ID_CTR) { B.r_id_ctr[o] = v; B.r_doc[o] = d; }
-            else B.s_ctr[o] = v;
-          }
-        } else if (COL == OC_VAL_META) {
-          u32 a = (u32)__shfl((int)e0, (int)t, 64), b = (u32)__shfl((int)e1, (int)t, 64);
-          u32 ro = (u32)__shfl((int)e2, (int)t, 64) + (u32)__shfl((int)step, (int)t, 64) * k;
-          if (live) { B.r_vmeta[o] = (u64)a | ((u64)b << 32); B.r_vraw_off[o] = ro; }
-        } else if (COL == OC_SUCC_NUM) {
-          u32 a = (u32)__shfl((int)e0, (int)t, 64);
-          u32 sb = (u32)__shfl((int)e2, (int)t, 64) + a * k;
-          if (live) { B.r_succ_cnt[o] = a; B.r_succ_base[o] = sb; }
-        } else {
-          u32 a = (u32)__shfl((int)e0, (int)t, 64);
-          if (live) {
-            if (COL == OC_OBJ_ACTOR) B.r_obj_actor[o] = a;
-            else if (COL == OC_OBJ_CTR) B.r_obj_ctr[o] = a;
-            else if (COL == OC_KEY_ACTOR) B.r_key_actor[o] = a;
-            else if (COL == OC_ID_ACTOR) B.r_id_actor[o] = a;
-            else if (COL == OC_SUCC_ACTOR) B.s_actor[o] = a;
-            else if (COL == OC_ACTION) B.r_action[o] = (u8)a;
-            else if (COL == OC_INSERT) B.r_insert[o] = (u8)a;
-            else if (COL == OC_EXPAND) B.r_expand[o] = (u8)a;
-          }
-        }
-      }
-      S.row += R;
+    while (t0 < ntok && S.row < S.want) {
+      const u32 m = ntok - t0 < 64 ? ntok - t0 : 64;
+      const u32 t = t0 + (lane < m ? lane : 0);
+      const u32 b0 = t ? (u32)W.tokend[t - 1] + 1 : skip;
+      const u32 nb = lane < m ? (u32)W.tokend[t] - b0 + 1 : 1;
+      // 32-bit arithmetic where every token has at most 4 bytes (and the functor does not object)
+      const bool wide = __ballot(nb > 4) != 0 || f.wide(S);
+      u32 c = SD_REDO;
+      if (!wide) c = f.template group<false>(W, S, lane, m, b0, nb, fail);
+      if (c == SD_REDO) c = f.template group<true>(W, S, lane, m, b0, nb, fail);
+      if (c == 0 || fail) break;
       t0 += c;
     }
-    if (fail) break;
+    if (fail) return fail;
     // next tile: from the first token that was not consumed
-    u32 npos = tb + (t0 ? (u32)W.tokend[t0 - 1] + 1 : skip);
-    npos = sd_uniform(npos);
+    const u32 npos = sd_uniform(tb + (t0 ? (u32)W.tokend[t0 - 1] + 1 : skip));
     if (npos == S.pos) {
       // no token could be consumed: a token longer than the tile, one cut off by the end of the column, or a run /
       // null header whose value the column no longer holds — the serial reader fails on all of them
-      if (S.row < want) fail = AMH_E_READ_OP;
-      break;
+      return S.row < S.want ? stuck : 0;
     }
     S.pos = npos;
   }
+  return 0;
+}
+
+template <u32 COL> struct SdDecodeF {
+  const BatchDev& B;
+  u32 d, obase, sbase, raw_len, mx;
+  __device__ __forceinline__ bool wide(const SdStream& S) const { return SdCol<COL>::HAS_ACC && S.acc >= (1u << 30); }
+  template <bool WIDE>
+  __device__ __forceinline__ u32 group(SdWave& W, SdStream& S, u32 lane, u32 m, u32 b0, u32 nb, i32& fail) {
+    return sd_do_group<COL, WIDE>(B, d, W, S, lane, m, b0, nb, obase, sbase, raw_len, mx, fail);
+  }
+};
+
+// One column stream.  COL selects what an item means and where its rows go.
+template <u32 COL>
+__device__ __forceinline__ void sd_decode_column(const BatchDev& B, u32 d, SdWave& W) {
+  typedef SdCol<COL> C;
+  const u32 lane = threadIdx.x & 63;
+  const DocDesc& D = B.desc[d];
+  const u32 want = C::SUCC_ENTRY ? B.cnt[d].n_succ : B.cnt[d].n_rows;
+  if (want == 0) return;
+  const u32 obase = C::SUCC_ENTRY ? B.succ_base[d] : B.row_base[d];
+  SdStream S;
+  S.src = B.arena + D.chunk_off;
+  S.pos = D.ocol[COL].off;
+  S.end = S.pos + D.ocol[COL].len;
+  S.want = want; S.row = 0; S.lit = 0; S.btok = 0; S.acc = 0;
+  SdDecodeF<COL> f{B, d, obase, COL == OC_SUCC_NUM ? B.succ_base[d] : 0u, D.ocol[OC_VAL_RAW].len, 0u};
+  const i32 fail = sd_walk(W, S, lane, f, AMH_E_READ_OP);
   if (fail) { if (lane == 0) amh_fail(B, d, fail); return; }
   if (S.row < want) {
     // the column is exhausted.  Inside a literal run the reader fails (the announced value is missing); otherwise
     // the iterator yields None from here on
-    bool ok = NULLABLE && S.lit == 0;
+    bool ok = C::NULLABLE && S.lit == 0;
     if (!ok) { if (lane == 0) amh_fail(B, d, AMH_E_READ_OP); return; }
-    for (u32 r = S.row + lane; r < want; r += 64) {
-      u32 o = obase + r;
-      if (COL == OC_OBJ_ACTOR) B.r_obj_actor[o] = AMH_NULL32;
-      else if (COL == OC_OBJ_CTR) B.r_obj_ctr[o] = AMH_NULL32;
-      else if (COL == OC_KEY_ACTOR) B.r_key_actor[o] = AMH_NULL32;
-      else if (COL == OC_KEY_CTR) B.r_key_ctr[o] = AMH_NULL32;
-      else if (COL == OC_ID_ACTOR) B.r_id_actor[o] = AMH_NULL32;
-      else if (COL == OC_ID_CTR) { B.r_id_ctr[o] = AMH_NULL32; B.r_doc[o] = d; }
-      else if (COL == OC_EXPAND) B.r_expand[o] = 0;
-    }
+    for (u32 r = S.row + lane; r < want; r += 64) sd_store_row<COL>(B, d, obase + r, COL == OC_EXPAND ? 0u : AMH_NULL32, 0, AMH_NULL32);
   }
   if (COL == OC_ID_CTR || COL == OC_SUCC_CTR) {
-    u32 m = sd_scan_max(mx);
+    u32 m = sd_scan_max(f.mx);
     if (lane == 63 && m) amh_atomic_max(&B.doc_max_op[d], m);
   }
 }
@@ -366,7 +509,7 @@ __device__ __forceinline__ void sd_decode_column(const BatchDev& B, u32 d, SdWav
 #define SD_NCOLS 13
 __global__ void __launch_bounds__(64 * SD_WAVES) g_decode_seg(BatchDev B) {
   __shared__ SdWave W[SD_WAVES];
-  const u32 wave = threadIdx.x >> 6;
+  const u32 wave = sd_uniform(threadIdx.x >> 6);   // uniform on purpose: descriptors, cursors and loop conditions stay scalar
   const u32 d = blockIdx.x * SD_WAVES + wave;
   if (d >= B.n_docs || B.status[d] != 0) return;
   SdWave& w = W[wave];
@@ -376,5 +519,104 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_decode_seg(BatchDev B) {
     DC(7, OC_ACTION) DC(8, OC_VAL_META) DC(9, OC_SUCC_NUM) DC(10, OC_SUCC_ACTOR) DC(11, OC_SUCC_CTR) DC(12, OC_EXPAND)
 #undef DC
     default: break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Count pass (doc_op_columns.rs:327-331; device form of k_count): rows = items of the id-counter column, succ entries
+// = sum of the first `rows` succ counts, changes = values of the change actor column up to its first null, deps = sum
+// of the first `changes` dep counts.  The same walk without the expand: one wave per (document, half) — the op
+// columns and the change columns are independent.
+// ------------------------------------------------------------------------------------------
+enum { SD_CNT_ITEMS = 0, SD_CNT_SUM = 1, SD_CNT_UNTIL_NULL = 2 };
+template <int MODE> struct SdCountF {
+  i32 err;            // what a malformed token is called here (ReadOp / ReadChange)
+  u64 sum;            // SD_CNT_SUM: per lane
+  bool stopped;       // SD_CNT_UNTIL_NULL: the first null ended the column
+  __device__ __forceinline__ bool wide(const SdStream&) const { return false; }
+  template <bool WIDE>
+  __device__ __forceinline__ u32 group(SdWave& W, SdStream& S, u32 lane, u32 m, u32 b0, u32 nb, i32& fail) {
+    SdItems<WIDE> I;
+    bool terr;
+    u64 lit_new; u32 btok_new;
+    const u32 rem = S.want - S.row;
+    const u32 c = sd_group<MODE == SD_CNT_ITEMS ? SD_RLE_S : SD_RLE_U, WIDE>(W, S, lane, m, b0, nb, I, terr, lit_new, btok_new);
+    if (c == 0) return 0;
+    const u32 reach = I.rs < rem ? (rem - I.rs < I.cnt ? rem - I.rs : I.cnt) : 0;
+    i32 ecode = terr ? err : 0;
+    u32 R = I.total < rem ? I.total : rem;
+    u64 live = ~(u64)0;      // lanes in front of the point where the reader stops
+    if (MODE == SD_CNT_ITEMS) {
+      if (!ecode && I.isnull && I.cnt) ecode = err;   // a null id is "unexpected null" (opid.rs:114-117)
+    } else if (MODE == SD_CNT_SUM) {
+      if (!ecode && reach) {
+        if (I.isnull) ecode = err;
+        else if ((u64)I.u > AMH_MAX_ROWS_PER_DOC) ecode = AMH_E_TOO_LARGE;
+        else sum += (u64)I.u * reach;
+      }
+    } else {
+      const u64 nul = __ballot(I.isnull && I.cnt != 0);
+      if (nul) {   // the first null ends the column: nothing behind it is read
+        const u32 L = (u32)__builtin_ctzll(nul);
+        live = sd_low_bits(L + 1);
+        const u32 before = sd_bcast(I.rs, L);
+        if (before < rem) { R = before; stopped = true; }
+      }
+    }
+    const u64 bad = __ballot(ecode != 0 && I.rs < rem) & live;
+    if (bad) { fail = (i32)sd_bcast((u32)ecode, (u32)__builtin_ctzll(bad)); return c; }
+    S.row += R;
+    if (stopped) S.want = S.row;
+    S.lit = lit_new;
+    return c;
+  }
+};
+
+template <int MODE>
+__device__ __forceinline__ i32 sd_count_column(const BatchDev& B, u32 d, SdWave& W, ColRef cr, u32 want, i32 err, u32& out) {
+  const u32 lane = threadIdx.x & 63;
+  SdStream S;
+  S.src = B.arena + B.desc[d].chunk_off;
+  S.pos = cr.off; S.end = cr.off + cr.len;
+  S.want = want; S.row = 0; S.lit = 0; S.btok = 0; S.acc = 0;
+  SdCountF<MODE> f{err, 0, false};
+  out = 0;
+  if (want == 0) return 0;
+  i32 fail = sd_walk(W, S, lane, f, err);
+  if (fail) return fail;
+  if (MODE == SD_CNT_SUM) {
+    if (S.row < want) return err;   // fewer values than rows
+    u64 tot = sd_bcast64(sd_scan_add64(f.sum), 63);
+    if (tot > AMH_MAX_ROWS_PER_DOC) return AMH_E_TOO_LARGE;
+    out = (u32)tot;
+  } else {
+    if (S.row > AMH_MAX_ROWS_PER_DOC) return AMH_E_TOO_LARGE;   // want = the limit + 1
+    if (!f.stopped && S.lit != 0) return err;                    // the column ends inside a literal run
+    out = S.row;
+  }
+  return 0;
+}
+
+__global__ void __launch_bounds__(64 * SD_WAVES) g_count_seg(BatchDev B) {
+  __shared__ SdWave W[SD_WAVES];
+  const u32 wave = sd_uniform(threadIdx.x >> 6);
+  const u32 d = blockIdx.x * SD_WAVES + wave;
+  if (d >= B.n_docs || B.status[d] != 0 || B.desc[d].chunk_len == 0) return;
+  const u32 lane = threadIdx.x & 63;
+  const DocDesc& D = B.desc[d];
+  SdWave& w = W[wave];
+  u32 a = 0, b = 0;
+  i32 fail;
+  if (blockIdx.y == 0) {
+    fail = sd_count_column<SD_CNT_ITEMS>(B, d, w, D.ocol[OC_ID_CTR], AMH_MAX_ROWS_PER_DOC + 1, AMH_E_READ_OP, a);
+    if (!fail) fail = sd_count_column<SD_CNT_SUM>(B, d, w, D.ocol[OC_SUCC_NUM], a, AMH_E_READ_OP, b);
+  } else {
+    fail = sd_count_column<SD_CNT_UNTIL_NULL>(B, d, w, D.ccol[CC_ACTOR], AMH_MAX_ROWS_PER_DOC + 1, AMH_E_READ_CHANGE, a);
+    if (!fail) fail = sd_count_column<SD_CNT_SUM>(B, d, w, D.ccol[CC_DEPS_NUM], a, AMH_E_READ_CHANGE, b);
+  }
+  if (lane == 0) {
+    if (fail) amh_fail(B, d, fail);
+    else if (blockIdx.y == 0) { B.cnt[d].n_rows = a; B.cnt[d].n_succ = b; }
+    else { B.cnt[d].n_chg = a; B.cnt[d].n_deps = b; }
   }
 }

@@ -43,6 +43,10 @@ __device__ __forceinline__ u32 sd_bcast(u32 v, u32 src_lane) { return (u32)__bui
 __device__ __forceinline__ u64 sd_bcast64(u64 v, u32 src_lane) {
   return (u64)sd_bcast((u32)v, src_lane) | ((u64)sd_bcast((u32)(v >> 32), src_lane) << 32);
 }
+// lane i receives lane i + 1's value (lane 63: 0): DPP wave_shl:1
+__device__ __forceinline__ u32 sd_next(u32 v) { return sd_dpp<0x130, 0xF, 0xF>(0, v); }
+// lane i receives lane i - 1's value (lane 0: 0): DPP wave_shr:1
+__device__ __forceinline__ u32 sd_prev(u32 v) { return sd_dpp<0x138, 0xF, 0xF>(0, v); }
 __device__ __forceinline__ u32 sd_uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 sd_low_bits(u32 k) { return k >= 64 ? ~(u64)0 : (((u64)1 << k) - 1); }   // bits [0, k)
 __device__ __forceinline__ u32 sd_mbcnt(u64 m) {   // set bits of m below this lane
