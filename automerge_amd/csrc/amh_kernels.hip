@@ -74,275 +74,126 @@ AMH_GLOBAL(k_dt_size)
 AMH_GLOBAL_X(k_succ_link)
 
 // ------------------------------------------------------------------------------------------
-// Op-column decode, LDS-staged (device form of k_decode_ops; the stream decoders are the same
-// functions).  One wave = one column of 64 consecutive documents, lane = document, so the whole wave
-// runs one decoder.  Each lane reads its column through a DEC_W-byte window in LDS; windows are
-// refilled cooperatively with 4-byte coalesced loads whenever some lane is about to run out.  Decoded
-// values are collected DEC_K rows at a time in LDS and written back cooperatively, 64 contiguous
-// bytes per document per store, instead of one 4-byte store per lane per row.
+// Op-column decode.  Every numeric and boolean column (and the count pass) goes through the segment-parallel decoder,
+// one wave per column stream (amh_segdec.inl).  The two string columns (map keys, mark names) are decoded here in two
+// phases per wave of 64 documents: their streams cannot be tokenised by continuation bits (string bytes follow the
+// lengths), but they are run-dominated (a map's rows are sorted by key), so the serial part is short:
+//   walk    lane = document: each lane reads the next elements of its column through a 64-byte LDS window (refilled
+//           cooperatively, 4-byte coalesced loads) and notes one ITEM per run / literal value / null run — (first row,
+//           offset, length) — in LDS, DS_K items per lane and pass.  Strings are validated once per item, not per row.
+//   expand  the wave takes the 64 documents in turn and writes the rows of the noted items, 64 rows per store.
 // ------------------------------------------------------------------------------------------
 #define DEC_W 64u          // window bytes per lane
-#define DEC_NEED 24u       // a decode step reads at most two LEB128 numbers past pos
-#define DEC_K 8u           // rows buffered per lane between write-backs
-#define DEC_KS (DEC_K + 1)
+#define DEC_NEED 24u       // a walk step reads at most two LEB128 numbers past pos
+#define DS_K 8u            // items noted per lane between expands
 
-struct DecShared {
+struct DsShared {
   u32 win[64][DEC_W / 4 + 1];
-  u32 o0[64 * DEC_KS], o1[64 * DEC_KS], o2[64 * DEC_KS];
-  u64 src[64];     // arena byte address of each lane's window
-  u32 rb[64], cnt[64];
+  u64 src[64];               // arena byte address of each lane's window
+  u32 it_rs[64][DS_K + 1];   // first row (document relative) of each noted item; [n] = the row behind the last one
+  u32 it_off[64][DS_K], it_len[64][DS_K];
+  u32 it_n[64], rb[64];
 };
 
 __device__ __forceinline__ u32 wave_max_u32(u32 v) {
   for (int off = 32; off > 0; off >>= 1) { u32 o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
   return v;
 }
-__device__ __forceinline__ u32 obase_succ(const BatchDev& B, u32 d) { return B.succ_base[d]; }
 
+#include "amh_segdec_prims.inl"
 template <u32 COL>
-__device__ __forceinline__ void decode_col_body(const BatchDev& B, DecShared& S) {
-  constexpr bool SUCC_ENTRY = COL == OC_SUCC_ACTOR || COL == OC_SUCC_CTR;
-  constexpr bool IS_DELTA = COL == OC_KEY_CTR || COL == OC_ID_CTR || COL == OC_SUCC_CTR;
-  constexpr bool IS_STR = COL == OC_KEY_STR || COL == OC_MARK_NAME;
-  constexpr bool IS_BOOL = COL == OC_INSERT || COL == OC_EXPAND;
+__device__ __forceinline__ void decode_str_body(const BatchDev& B, DsShared& S) {
   const u32 lane = threadIdx.x;
   const u32 d = blockIdx.x * 64 + lane;
-  bool live = d < B.n_docs && B.status[d] == 0;
+  const bool live = d < B.n_docs && B.status[d] == 0;
   const u32 dd = d < B.n_docs ? d : 0;
   const DocDesc& D = B.desc[dd];
-  const u32 cnt = live ? (SUCC_ENTRY ? B.cnt[dd].n_succ : B.cnt[dd].n_rows) : 0;
-  const u32 obase = SUCC_ENTRY ? B.succ_base[dd] : B.row_base[dd];
-  const u8* chunk = B.arena + D.chunk_off;
+  const u32 want = live ? B.cnt[dd].n_rows : 0;
   const u32 off = D.ocol[COL].off, len = D.ocol[COL].len;
-  S.rb[lane] = obase;
-  S.cnt[lane] = cnt;
-  const u32 cnt_max = wave_max_u32(cnt);
-  if (cnt_max == 0) return;
-  // nullable columns that no document of this wave has: the host pre-filled the arrays with the
-  // "null" pattern (amh_load_staged), nothing to decode
-  constexpr bool NULLABLE = COL == OC_OBJ_ACTOR || COL == OC_OBJ_CTR || COL == OC_KEY_ACTOR || COL == OC_KEY_CTR ||
-                            COL == OC_KEY_STR || COL == OC_EXPAND || COL == OC_MARK_NAME;
-  if (NULLABLE && !__ballot(cnt != 0 && len != 0)) return;
-  // decoder state
-  RleDec r; DeltaDec dl; BoolDec bd;
+  // a column no document of this wave has: the host pre-filled the arrays with the "null" pattern (amh_load_staged)
+  if (!__ballot(want != 0 && len != 0)) return;
+  S.rb[lane] = B.row_base[dd];
+  u32* o_off = COL == OC_KEY_STR ? B.r_key_off : B.r_mark_off;
+  u32* o_len = COL == OC_KEY_STR ? B.r_key_len : B.r_mark_len;
+  const u8* gp = B.arena + D.chunk_off;
+  const u8* wp = (const u8*)S.win[lane];
   u32 wbase = off & ~3u;
-  const u8* wp = (const u8*)S.win[lane];
-  rle_init(r, wp - wbase, off, len); r.gp = chunk;
-  delta_init(dl, wp - wbase, off, len);
-  bool_init(bd, wp - wbase, off, len);
-  u64 raw_off = 0; const u64 raw_len = D.ocol[OC_VAL_RAW].len;   // VAL_META
-  u32 succ_run = 0;                                               // SUCC_NUM
-  u32 mx = 0;                                                     // ID_CTR / SUCC_CTR
-  bool failed = false;
-  i32 fail_code = 0;
-  bool first = true;
-  for (u32 i = 0; i < cnt_max; i++) {
-    // ---- window refill --------------------------------------------------------------------
-    u64 pos = IS_DELTA ? dl.r.pos : (IS_BOOL ? bd.pos : r.pos);
-    bool need = first || (live && !failed && i < cnt && pos + DEC_NEED > (u64)wbase + DEC_W && (u64)wbase + DEC_W < (u64)off + len);
-    if (__ballot(need)) {
-      first = false;
-      u32 nb = (pos > (u64)off + len ? off + len : (u32)pos) & ~3u;
-      wbase = nb;
-      S.src[lane] = D.chunk_off + nb;
-      __syncthreads();
-#pragma unroll 4
-      for (u32 l0 = 0; l0 < 64; l0 += 64 / (DEC_W / 4)) {
-        u32 l = l0 + lane / (DEC_W / 4), k = lane % (DEC_W / 4);
-        S.win[l][k] = *(const u32*)(B.arena + S.src[l] + 4 * k);   // the arena is padded: reading past a column is harmless
-      }
-      __syncthreads();
-      const u8* np = wp - wbase;
-      r.p = np; dl.r.p = np; bd.p = np;
-    }
-    // ---- one row per lane -------------------------------------------------------------------
-    if (i < cnt && !failed) {
-      u64 v = 0; u32 aux = 0; bool isnull = false; i64 sv = 0;
-      u32 slot = lane * DEC_KS + (i % DEC_K);
-      if (IS_DELTA) {
-        int rc = delta_next(dl, sv, isnull);
-        bool none = rc == 1 || isnull;
-        if (rc < 0 || (SUCC_ENTRY && none)) { failed = true; fail_code = AMH_E_READ_OP; }
-        else if (!none && (sv < 0 || sv >= 0xFFFFFFFFll)) { failed = true; fail_code = AMH_E_READ_OP; }
-        else { S.o0[slot] = none ? AMH_NULL32 : (u32)sv; if (!none && (u32)sv > mx) mx = (u32)sv; }
-      } else if (IS_STR) {
-        int rc = rle_next<2>(r, v, aux, isnull);
-        bool none = rc == 1 || isnull;
-        if (rc < 0) { failed = true; fail_code = AMH_E_READ_OP; }
-        else { S.o0[slot] = none ? 0 : (u32)v; S.o1[slot] = none ? AMH_NULL32 : aux; }
-      } else if (IS_BOOL) {
-        bool b = false;
-        int rc = len ? bool_next(bd, b) : 1;
-        if (COL == OC_INSERT ? rc != 0 : rc < 0) { failed = true; fail_code = AMH_E_READ_OP; }
-        else S.o0[slot] = (rc == 0 && b) ? 1 : 0;
-      } else if (COL == OC_VAL_META) {
-        int rc = rle_next<0>(r, v, aux, isnull);
-        if (rc != 0 || isnull) { failed = true; fail_code = AMH_E_READ_OP; }
-        else {
-          S.o0[slot] = (u32)v; S.o1[slot] = (u32)(v >> 32); S.o2[slot] = (u32)raw_off;
-          if ((v & 15) >= 3) {
-            u64 l = v >> 4;
-            if (l > raw_len || raw_off > raw_len - l) { failed = true; fail_code = AMH_E_READ_OP; }
-            raw_off += l;
-          }
-        }
-      } else if (COL == OC_SUCC_NUM) {
-        int rc = rle_next<0>(r, v, aux, isnull);
-        if (rc != 0 || isnull) { failed = true; fail_code = AMH_E_READ_OP; }
-        else { S.o0[slot] = (u32)v; S.o1[slot] = obase_succ(B, dd) + succ_run; succ_run += (u32)v; }
-      } else {  // plain RLE of u64: obj actor / ctr, key actor, id actor, action, succ actor
-        int rc = rle_next<0>(r, v, aux, isnull);
-        bool none = rc == 1 || isnull;
-        if (rc < 0) { failed = true; fail_code = AMH_E_READ_OP; }
-        else if (COL == OC_ACTION) {
-          if (none) { failed = true; fail_code = AMH_E_READ_OP; }
-          else if (v > 7) { failed = true; fail_code = AMH_E_INVALID_OP; }
-          else S.o0[slot] = (u32)v;
-        } else if (COL == OC_SUCC_ACTOR) {
-          if (none) { failed = true; fail_code = AMH_E_READ_OP; }
-          else if (v >= 0xFFFFFFFFull) { failed = true; fail_code = AMH_E_MISSING_ACTOR; }
-          else S.o0[slot] = (u32)v;
-        } else {
-          if (!none && v >= 0xFFFFFFFFull) { failed = true; fail_code = COL == OC_OBJ_CTR ? AMH_E_READ_OP : AMH_E_MISSING_ACTOR; }
-          else S.o0[slot] = none ? AMH_NULL32 : (u32)v;
-        }
-      }
-      if (failed) { amh_fail(B, dd, fail_code); S.cnt[lane] = i; }   // rows from i on are never written back
-    }
-    // ---- write-back every DEC_K rows ---------------------------------------------------------
-    if ((i % DEC_K) == DEC_K - 1 || i + 1 == cnt_max) {
-      u32 i0 = i - (i % DEC_K);
-      __syncthreads();
-#pragma unroll 4
-      for (u32 l0 = 0; l0 < 64; l0 += 64 / DEC_K) {
-        u32 l = l0 + lane / DEC_K, k = lane % DEC_K;
-        if (i0 + k >= S.cnt[l]) continue;
-        u32 o = S.rb[l] + i0 + k, sl = l * DEC_KS + k;
-        if (COL == OC_OBJ_ACTOR) B.r_obj_actor[o] = S.o0[sl];
-        else if (COL == OC_OBJ_CTR) B.r_obj_ctr[o] = S.o0[sl];
-        else if (COL == OC_KEY_ACTOR) B.r_key_actor[o] = S.o0[sl];
-        else if (COL == OC_KEY_CTR) B.r_key_ctr[o] = S.o0[sl];
-        else if (COL == OC_KEY_STR) { B.r_key_off[o] = S.o0[sl]; B.r_key_len[o] = S.o1[sl]; }
-        else if (COL == OC_ID_ACTOR) B.r_id_actor[o] = S.o0[sl];
-        else if (COL == OC_ID_CTR) { B.r_id_ctr[o] = S.o0[sl]; B.r_doc[o] = blockIdx.x * 64 + l; }
-        else if (COL == OC_INSERT) B.r_insert[o] = (u8)S.o0[sl];
-        else if (COL == OC_ACTION) B.r_action[o] = (u8)S.o0[sl];
-        else if (COL == OC_VAL_META) { B.r_vmeta[o] = (u64)S.o0[sl] | ((u64)S.o1[sl] << 32); B.r_vraw_off[o] = S.o2[sl]; }
-        else if (COL == OC_SUCC_NUM) { B.r_succ_cnt[o] = S.o0[sl]; B.r_succ_base[o] = S.o1[sl]; }
-        else if (COL == OC_SUCC_ACTOR) B.s_actor[o] = S.o0[sl];
-        else if (COL == OC_SUCC_CTR) B.s_ctr[o] = S.o0[sl];
-        else if (COL == OC_EXPAND) B.r_expand[o] = (u8)S.o0[sl];
-        else if (COL == OC_MARK_NAME) { B.r_mark_off[o] = S.o0[sl]; B.r_mark_len[o] = S.o1[sl]; }
-      }
-      __syncthreads();
-    }
-  }
-  if ((COL == OC_ID_CTR || COL == OC_SUCC_CTR) && live && !failed && cnt) amh_atomic_max(&B.doc_max_op[dd], mx);
-}
-// the two string columns (map keys, mark names): blockIdx.y = column (uniform per wave), blockIdx.x = 64 documents.
-// Every other column goes through the segment-parallel decoder (amh_segdec.inl).
-__global__ void __launch_bounds__(64) g_decode_strs(BatchDev B) {
-  __shared__ DecShared S;
-  if (blockIdx.y == 0) decode_col_body<OC_KEY_STR>(B, S);
-  else decode_col_body<OC_MARK_NAME>(B, S);
-}
-#include "amh_segdec.inl"
-
-// ------------------------------------------------------------------------------------------
-// Row / succ / change / dep counts (device form of k_count), same staging as the column decode:
-// lane = document, each lane reads its column through an LDS window refilled cooperatively.
-// Four passes: id-counter run headers -> rows; succ-count values -> succ entries; change actor
-// values -> changes; dep-count values -> deps.
-// ------------------------------------------------------------------------------------------
-struct CountShared {
-  u32 win[64][DEC_W / 4 + 1];
-  u64 src[64];
-};
-__global__ void __launch_bounds__(64) g_count_lds(BatchDev B) {
-  __shared__ CountShared S;
-  const u32 lane = threadIdx.x;
-  const u32 d = blockIdx.x * 64 + lane;
-  const u32 dd = d < B.n_docs ? d : 0;
-  bool live = d < B.n_docs && B.status[dd] == 0 && B.desc[dd].chunk_len != 0;
-  const DocDesc& D = B.desc[dd];
-  const u8* wp = (const u8*)S.win[lane];
-  i32 fail_code = 0;
-  u64 rows = 0, succ = 0, chg = 0, deps = 0;
-  for (int pass = 0; pass < 4; pass++) {
-    const ColRef cr = pass == 0 ? D.ocol[OC_ID_CTR] : pass == 1 ? D.ocol[OC_SUCC_NUM] : pass == 2 ? D.ccol[CC_ACTOR] : D.ccol[CC_DEPS_NUM];
-    const u32 off = cr.off, len = cr.len;
-    const i32 err = pass < 2 ? AMH_E_READ_OP : AMH_E_READ_CHANGE;
-    RleDec r;
-    u32 wbase = off & ~3u;
-    rle_init(r, wp - wbase, off, len);
-    r.gp = B.arena + D.chunk_off;
-    u64 lit = 0;            // pass 0: literal values still to skip
-    u64 todo = pass == 1 ? rows : (pass == 3 ? chg : 0);   // passes 1, 3: values to read
-    bool active = live && fail_code == 0;
-    if (pass == 1 || pass == 3) active = active && todo > 0;
-    bool first = true;
-    while (__ballot(active)) {
-      bool need = first || (active && r.pos + DEC_NEED > (u64)wbase + DEC_W && (u64)wbase + DEC_W < (u64)off + len);
+  const u8* p = wp - wbase;
+  u64 pos = off;
+  const u64 end = (u64)off + len;
+  u64 lit = 0;
+  u32 row = 0;
+  bool failed = false, first = true;
+  while (__ballot(row < want && !failed)) {
+    u32 n_it = 0;
+    for (u32 step = 0; step < DS_K; step++) {
+      const bool active = row < want && !failed;
+      // ---- window refill ------------------------------------------------------------------
+      bool need = first || (active && pos < end && pos + DEC_NEED > (u64)wbase + DEC_W && (u64)wbase + DEC_W < end);
       if (__ballot(need)) {
         first = false;
-        u32 nb = (r.pos > (u64)off + len ? off + len : (u32)r.pos) & ~3u;
+        u32 nb = (pos > end ? (u32)end : (u32)pos) & ~3u;
         wbase = nb;
         S.src[lane] = D.chunk_off + nb;
-        __syncthreads();
+        sd_lds_sync();
 #pragma unroll 4
         for (u32 l0 = 0; l0 < 64; l0 += 64 / (DEC_W / 4)) {
           u32 l = l0 + lane / (DEC_W / 4), k = lane % (DEC_W / 4);
-          S.win[l][k] = *(const u32*)(B.arena + S.src[l] + 4 * k);
+          S.win[l][k] = *(const u32*)(B.arena + S.src[l] + 4 * k);   // the arena is padded: reading past a column is harmless
         }
-        __syncthreads();
-        r.p = wp - wbase;
+        sd_lds_sync();
+        p = wp - wbase;
       }
-      if (!active) continue;
-      u64 v = 0; u32 aux = 0; bool isnull = false;
-      if (pass == 0) {
-        if (lit > 0) {
-          if (!rle_read_value<1>(r, v, aux)) { fail_code = err; active = false; }
-          lit--;
-        } else if (r.pos >= r.end) {
-          active = false;
-        } else {
-          i64 n;
-          if (!rd_sleb_lenient(r.p, r.pos, r.end, n)) { fail_code = err; active = false; }
-          else if (n > 0) {
-            if (!rle_read_value<1>(r, v, aux)) { fail_code = err; active = false; }
-            rows += (u64)n;
-          } else if (n < 0) {
-            u64 k = (n == INT64_MIN) ? (u64)INT64_MAX : (u64)(-n);
-            if (k > r.end - r.pos) { fail_code = err; active = false; }   // each literal takes >= 1 byte
-            else { lit = k; rows += k; }
-          } else {
-            u64 nulls;
-            if (!rd_uleb_lenient(r.p, r.pos, r.end, nulls) || nulls) { fail_code = err; active = false; }   // a null id is "unexpected null" (opid.rs:114-117)
-          }
-          if (active && rows > AMH_MAX_ROWS_PER_DOC) { fail_code = AMH_E_TOO_LARGE; active = false; }
-        }
-      } else if (pass == 2) {
-        int rc = rle_next<0>(r, v, aux, isnull);
-        if (rc < 0) { fail_code = err; active = false; }
-        else if (rc == 1 || isnull) active = false;
-        else { chg++; if (chg > AMH_MAX_ROWS_PER_DOC) { fail_code = AMH_E_TOO_LARGE; active = false; } }
-      } else {
-        int rc = rle_next<0>(r, v, aux, isnull);
-        if (rc != 0 || isnull) { fail_code = err; active = false; }
+      // ---- one element per lane ----------------------------------------------------------------
+      if (active) {
+        const u32 rem = want - row;
+        u32 cnt = 0, v_off = 0, v_len = AMH_NULL32;
+        bool want_str = false;
+        if (lit > 0) { lit--; cnt = 1; want_str = true; }
+        else if (pos >= end) cnt = rem;                       // exhausted: the iterator yields None from here on
         else {
-          u64& acc = pass == 1 ? succ : deps;
-          acc += v;
-          if (v > AMH_MAX_ROWS_PER_DOC || acc > AMH_MAX_ROWS_PER_DOC) { fail_code = AMH_E_TOO_LARGE; active = false; }
-          if (--todo == 0) active = false;
+          i64 n;
+          if (!rd_sleb_lenient(p, pos, end, n)) failed = true;
+          else if (n > 0) { cnt = (u64)n < rem ? (u32)n : rem; want_str = true; }
+          else if (n < 0) { lit = (n == INT64_MIN ? (u64)INT64_MAX : (u64)(-n)) - 1; cnt = 1; want_str = true; }
+          else {
+            u64 nulls;
+            if (!rd_uleb_lenient(p, pos, end, nulls) || nulls > (u64)INT64_MAX) failed = true;
+            else cnt = nulls < rem ? (u32)nulls : rem;
+          }
+        }
+        if (want_str && !failed) {   // rle_read_value<2>: length, bytes (validated where they lie, in the arena)
+          u64 sl;
+          if (!rd_uleb_lenient(p, pos, end, sl) || sl > end - pos || !amh_valid_utf8(gp + pos, sl)) failed = true;
+          else { v_off = (u32)pos; v_len = (u32)sl; pos += sl; }
+        }
+        if (failed) amh_fail(B, dd, AMH_E_READ_OP);
+        else if (cnt) {
+          S.it_rs[lane][n_it] = row; S.it_off[lane][n_it] = v_off; S.it_len[lane][n_it] = v_len;
+          n_it++;
+          row += cnt;
         }
       }
     }
-  }
-  if (d < B.n_docs && live) {
-    if (fail_code) amh_fail(B, dd, fail_code);
-    else { DocCounts& C = B.cnt[dd]; C.n_rows = (u32)rows; C.n_succ = (u32)succ; C.n_chg = (u32)chg; C.n_deps = (u32)deps; }
+    S.it_n[lane] = n_it;
+    S.it_rs[lane][n_it] = row;
+    sd_lds_sync();
+    // ---- expand: the documents in turn, 64 rows per store ---------------------------------------
+    for (u32 l = 0; l < 64; l++) {
+      const u32 n = S.it_n[l];
+      if (n == 0) continue;
+      const u32 r_begin = S.it_rs[l][0], r_end = S.it_rs[l][n], rb = S.rb[l];
+      for (u32 r0 = r_begin; r0 < r_end; r0 += 64) {
+        const u32 r = r0 + lane;
+        u32 k = 0;
+        for (u32 j = 1; j < n; j++) k = S.it_rs[l][j] <= r ? j : k;
+        if (r < r_end) { o_off[rb + r] = S.it_off[l][k]; o_len[rb + r] = S.it_len[l][k]; }
+      }
+    }
+    sd_lds_sync();
   }
 }
+#include "amh_segdec.inl"
 
 // ------------------------------------------------------------------------------------------
 // Change re-encode, LDS-staged (replaces the thread-per-(change, column) kernels k_encode_size /
@@ -851,8 +702,7 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (k == AK_COUNT) { hipLaunchKernelGGL(g_count_seg, dim3((B.n_docs + SD_WAVES - 1) / SD_WAVES, 2), dim3(64 * SD_WAVES), 0, s, B); return; }
   if (k == AK_DECODE_OPS) {
-    hipLaunchKernelGGL(g_decode_strs, dim3((B.n_docs + 63) / 64, 2), dim3(64), 0, s, B);
-    hipLaunchKernelGGL(g_decode_seg, dim3((B.n_docs + SD_WAVES - 1) / SD_WAVES, SD_NCOLS), dim3(64 * SD_WAVES), 0, s, B);
+    hipLaunchKernelGGL(g_decode_seg, dim3((B.n_docs + SD_WAVES - 1) / SD_WAVES, SD_NCOLS + 2), dim3(64 * SD_WAVES), 0, s, B);
     return;
   }
   if (k == AK_SAVE_SIZE) { hipLaunchKernelGGL((g_save_lds<false>), dim3((B.n_docs + 63) / 64, 8), dim3(64), 0, s, B); return; }

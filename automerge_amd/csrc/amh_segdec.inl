@@ -505,15 +505,27 @@ __device__ __forceinline__ void sd_decode_column(const BatchDev& B, u32 d, SdWav
   }
 }
 
-// blockIdx.y = column (uniform per workgroup), one wave per document
+// All op columns of a batch in one launch.  blockIdx.y = column (uniform per workgroup).  y = 0, 1: the two string columns,
+// one wave per 64 documents (decode_str_body; first in the grid so that these few long-running waves start at once and
+// run beside the rest); y >= 2: one wave per (document, column).
 #define SD_NCOLS 13
+union SdBlockShared {
+  SdWave w[SD_WAVES];
+  DsShared s;
+};
 __global__ void __launch_bounds__(64 * SD_WAVES) g_decode_seg(BatchDev B) {
-  __shared__ SdWave W[SD_WAVES];
+  __shared__ SdBlockShared L;
+  if (blockIdx.y < 2) {
+    if (threadIdx.x >= 64 || blockIdx.x * 64 >= B.n_docs) return;
+    if (blockIdx.y == 0) decode_str_body<OC_KEY_STR>(B, L.s);
+    else decode_str_body<OC_MARK_NAME>(B, L.s);
+    return;
+  }
   const u32 wave = sd_uniform(threadIdx.x >> 6);   // uniform on purpose: descriptors, cursors and loop conditions stay scalar
   const u32 d = blockIdx.x * SD_WAVES + wave;
   if (d >= B.n_docs || B.status[d] != 0) return;
-  SdWave& w = W[wave];
-  switch (blockIdx.y) {
+  SdWave& w = L.w[wave];
+  switch (blockIdx.y - 2) {
 #define DC(i, col) case i: sd_decode_column<col>(B, d, w); break;
     DC(0, OC_OBJ_ACTOR) DC(1, OC_OBJ_CTR) DC(2, OC_KEY_ACTOR) DC(3, OC_KEY_CTR) DC(4, OC_ID_ACTOR) DC(5, OC_ID_CTR) DC(6, OC_INSERT)
     DC(7, OC_ACTION) DC(8, OC_VAL_META) DC(9, OC_SUCC_NUM) DC(10, OC_SUCC_ACTOR) DC(11, OC_SUCC_CTR) DC(12, OC_EXPAND)
