@@ -442,15 +442,28 @@ __global__ void __launch_bounds__(64) g_encode_grp(BatchDev B) {
   }
   (void)chunk; (void)pn;
 }
+#include "amh_segenc.inl"
+// Two forms of the change re-encode.  Batches of small changes (the headline: 50 ops per change): lane = change, 64
+// changes per wave in step (g_encode_grp) — a wave per change would spend itself on per-column set-up, and the
+// scalar unit of a CU, shared by its four SIMDs, would be the limit.  Larger changes: one wave per (change, column
+// group), 64 values per step (g_encode_seg), whose cost does not depend on how the ops are spread over the changes.
 template <bool STORE>
 static void launch_encode(const BatchDev& B, hipStream_t s) {
-  const dim3 g((B.tot_chg + 63) / 64), b(64);
-  hipLaunchKernelGGL((g_encode_grp<STORE, 1>), g, b, 0, s, B);
-  hipLaunchKernelGGL((g_encode_grp<STORE, 2>), g, b, 0, s, B);
-  hipLaunchKernelGGL((g_encode_grp<STORE, 3>), g, b, 0, s, B);
-  hipLaunchKernelGGL((g_encode_grp<STORE, 4>), g, b, 0, s, B);
-  hipLaunchKernelGGL((g_encode_grp<STORE, 5>), g, b, 0, s, B);
-  hipLaunchKernelGGL((g_encode_grp<STORE, 6>), g, b, 0, s, B);
+  // AMH_ENCODE_FORM=seg | lane forces one form (tests run every document shape through both)
+  const char* form = getenv("AMH_ENCODE_FORM");
+  const bool lane_form = form ? form[0] == 'l' : (u64)B.tot_ops < (u64)B.tot_chg * 192;
+  if (lane_form) {
+    const dim3 g((B.tot_chg + 63) / 64), b(64);
+    hipLaunchKernelGGL((g_encode_grp<STORE, 1>), g, b, 0, s, B);
+    hipLaunchKernelGGL((g_encode_grp<STORE, 2>), g, b, 0, s, B);
+    hipLaunchKernelGGL((g_encode_grp<STORE, 3>), g, b, 0, s, B);
+    hipLaunchKernelGGL((g_encode_grp<STORE, 4>), g, b, 0, s, B);
+    hipLaunchKernelGGL((g_encode_grp<STORE, 5>), g, b, 0, s, B);
+    hipLaunchKernelGGL((g_encode_grp<STORE, 6>), g, b, 0, s, B);
+    return;
+  }
+  const u32 parts = (u64)B.tot_ops >= (u64)B.tot_chg * 1024 ? SC_GROUPS : 1;
+  hipLaunchKernelGGL((g_encode_seg<STORE>), dim3((B.tot_chg + SD_WAVES - 1) / SD_WAVES, parts), dim3(64 * SD_WAVES), 0, s, B);
 }
 
 

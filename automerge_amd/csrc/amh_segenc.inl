@@ -1,0 +1,416 @@
+// Segment-parallel column ENCODE (device only; included by amh_kernels.hip): the reference's run-length encoders
+// (rle.rs:31-133, delta.rs:10-43, boolean.rs:11-51; value.rs:320-369 for the raw column) as wave-wide bit arithmetic
+// instead of one lane stepping a state machine.
+//
+// One wave encodes one column of one change (or document), 64 values per step, and walks the column BACKWARDS.
+// The canonical encoding is a function of run structure alone ("parallel form"):
+//   * value i starts a run iff it differs from value i - 1 (nulls compare equal to nulls), ends one iff it differs from
+//     value i + 1;
+//   * a non-null run of length 1 is a "lone" value; maximal stretches of lone values are literal runs: sleb(-k), then
+//     the k values;
+//   * a longer run is sleb(length), value; a null run is 0, uleb(length); a column of nothing but nulls is empty.
+// What a run start must write depends on where the run ENDS (its length) — which lies ahead of it.  Walking backwards,
+// everything ahead of a tile is already known and is carried in four scalars (does the next value start a run / is it
+// lone, how long are the run and the literal stretch that begin there), so no header is ever reserved and patched,
+// and a literal run of any length costs nothing extra.  Inside a tile the run structure is three ballots (equal to
+// the previous value, null, valid) and shifts of them; every lane finds the end of its run with a count of trailing
+// zeros.  Each lane then knows the up to four numbers it has to write: [header of a literal run that starts the
+// column] [its own run header] [its value / null count] [header of the literal run that starts behind it]; an
+// exclusive scan of their sizes places them.  The size pass runs the same walk without the stores and gives the
+// column length from which the store pass counts down.
+#pragma once
+
+struct ScCarry {       // about the first value behind the tile (all uniform)
+  bool start0;         // it starts a run (true when there is none)
+  bool lone0;          // it is a lone value
+  u32 runlen0;         // length of its run counted from it
+  u32 litlen0;         // lone values from it on
+};
+struct ScRoles {
+  bool is_start, is_lone, is_lh, emit_p;
+  u32 rl;              // length of the run that starts here
+  u32 k_lh;            // is_lh: length of the literal run that starts behind this value
+  u32 k_p;             // emit_p: length of the literal run that starts the column
+};
+__device__ __forceinline__ u32 sc_ctz64(u64 x) { return x ? (u32)__builtin_ctzll(x) : 64u; }
+
+// EQP bit i: value base + i equals value base + i - 1 (bit 0 looks at the value in front of the tile; clear at the
+// start of the column).  NUL bit i: value base + i is null.  cnt = values in the tile.  Updates the carry.
+__device__ __forceinline__ ScRoles sc_roles(u64 EQP, u64 NUL, u32 cnt, u32 base, u32 lane, ScCarry& c) {
+  const u64 VALID = sd_low_bits(cnt), top = (u64)1 << (cnt - 1);
+  const u64 START = ~EQP & VALID;
+  const u64 END = ((START >> 1) | (c.start0 ? top : 0)) & VALID;
+  const u64 LONE = START & END & ~NUL;
+  const u64 LONEN = ((LONE >> 1) | (c.lone0 ? top : 0)) & VALID;
+  const u64 LH = ~LONE & LONEN & VALID;
+  ScRoles r;
+  r.is_start = (START >> lane) & 1; r.is_lone = (LONE >> lane) & 1; r.is_lh = (LH >> lane) & 1;
+  // the run that starts here ends at the next END bit, or behind the tile
+  { const u64 e = END >> lane; r.rl = e ? (u32)__builtin_ctzll(e) + 1 : (cnt - lane) + c.runlen0; }
+  // lone values from lane + 1 on
+  {
+    const u32 room = cnt - (lane < cnt ? lane + 1 : cnt);
+    const u32 z = lane + 1 < 64 ? sc_ctz64(~LONE >> (lane + 1)) : 0;
+    r.k_lh = z >= room ? room + (c.lone0 ? c.litlen0 : 0) : z;
+  }
+  // the carry for the tile in front of this one
+  ScCarry n;
+  n.start0 = START & 1;
+  n.lone0 = LONE & 1;
+  n.runlen0 = END ? (u32)__builtin_ctzll(END) + 1 : cnt + c.runlen0;
+  { const u32 z = sc_ctz64(~LONE); n.litlen0 = (LONE & 1) ? (z >= cnt ? cnt + (c.lone0 ? c.litlen0 : 0) : z) : 0; }
+  c = n;
+  r.emit_p = base == 0 && lane == 0 && n.lone0;
+  r.k_p = n.litlen0;
+  return r;
+}
+__device__ __forceinline__ ScCarry sc_carry_init() { ScCarry c; c.start0 = true; c.lone0 = false; c.runlen0 = 0; c.litlen0 = 0; return c; }
+
+// lane i receives lane i - 1's 64-bit value
+__device__ __forceinline__ u64 sd_prev64(u64 v) { return (u64)sd_prev((u32)v) | ((u64)sd_prev((u32)(v >> 32)) << 32); }
+
+// ---- numeric columns ---------------------------------------------------------------------------------------------
+// Src: void load(u32 e, u64& v, bool& isnull) const — value e of the column (any lane may ask for any e < n).
+// SIGNED: values are written as sleb128 (deltas), else uleb128.  STORE: out = first byte of the column, col_len = its
+// length (from the size pass).  Returns the column length.
+template <bool SIGNED, bool STORE, class Src>
+__device__ __forceinline__ u32 sc_rle_column(const Src& src, u32 n, u8* out, u32 col_len, u32 lane) {
+  if (n == 0 || (STORE && col_len == 0)) return 0;
+  ScCarry carry = sc_carry_init();
+  u32 total = 0;
+  bool any = false;
+  for (u32 base = (n - 1) & ~63u;; base -= 64) {
+    const u32 cnt = n - base < 64 ? n - base : 64;
+    const u32 e = base + lane;
+    const bool valid = lane < cnt;
+    u64 v = 0; bool nul = true;
+    if (valid) src.load(e, v, nul);
+    u64 pv = sd_prev64(v); bool pn = sd_prev((u32)nul) != 0;
+    if (lane == 0 && base > 0) src.load(base - 1, pv, pn);
+    const bool eqp = valid && e > 0 && pn == nul && (nul || pv == v);
+    const u64 EQP = __ballot(eqp), NUL = __ballot(nul && valid);
+    any = any || (~NUL & sd_low_bits(cnt)) != 0;
+    const ScRoles r = sc_roles(EQP, NUL, cnt, base, lane, carry);
+    // the numbers this lane writes, in order: P (literal header at the start of the column), H (run header), V (value
+    // or null count), L (header of the literal run that starts behind this value)
+    const bool hasP = r.emit_p, hasH = r.is_start && !r.is_lone, hasV = r.is_start, hasL = r.is_lh;
+    const i64 nP = -(i64)r.k_p, nH = nul ? 0 : (i64)r.rl, nL = -(i64)r.k_lh;
+    const u32 sP = hasP ? sleb_size_fast(nP) : 0, sH = hasH ? sleb_size_fast(nH) : 0, sL = hasL ? sleb_size_fast(nL) : 0;
+    const u32 sV = !hasV ? 0 : (nul ? uleb_size_fast(r.rl) : (SIGNED ? sleb_size_fast((i64)v) : uleb_size_fast(v)));
+    const u32 len = sP + sH + sV + sL;
+    const u32 inc = sd_scan_add(len);
+    const u32 T = sd_bcast(inc, 63);
+    total += T;
+    if (STORE && len) {
+      u8* o = out + (col_len - total) + (inc - len);
+      if (hasP) o += wr_sleb(o, nP);
+      if (hasH) o += wr_sleb(o, nH);
+      if (hasV) o += nul ? wr_uleb(o, r.rl) : (SIGNED ? wr_sleb(o, (i64)v) : wr_uleb(o, v));
+      if (hasL) wr_sleb(o, nL);
+    }
+    if (base == 0) break;
+  }
+  return any ? total : 0;   // a column of nulls is not written at all (rle.rs:33)
+}
+
+// ---- boolean columns (boolean.rs:35-50): alternating run lengths, the first one counts `false` ----------------------
+// Src: bool load(u32 e) const.  MAYBE: nothing unless some value is true (MaybeBooleanEncoder, boolean.rs:131-137).
+template <bool MAYBE, bool STORE, class Src>
+__device__ __forceinline__ u32 sc_bool_column(const Src& src, u32 n, u8* out, u32 col_len, u32 lane) {
+  if (n == 0 || (STORE && col_len == 0)) return 0;
+  ScCarry carry = sc_carry_init();
+  u32 total = 0;
+  bool any_true = false;
+  for (u32 base = (n - 1) & ~63u;; base -= 64) {
+    const u32 cnt = n - base < 64 ? n - base : 64;
+    const u32 e = base + lane;
+    const bool valid = lane < cnt;
+    bool v = valid ? src.load(e) : false;
+    bool pv = sd_prev((u32)v) != 0;
+    if (lane == 0 && base > 0) pv = src.load(base - 1);
+    const bool eqp = valid && e > 0 && pv == v;
+    const u64 EQP = __ballot(eqp);
+    any_true = any_true || __ballot(v && valid) != 0;
+    const ScRoles r = sc_roles(EQP, 0, cnt, base, lane, carry);
+    // a column that starts with `true` starts with an empty run of `false`
+    const bool hasZ = base == 0 && lane == 0 && v;
+    const u32 sV = r.is_start ? uleb_size_fast(r.rl) : 0;
+    const u32 len = (hasZ ? 1u : 0u) + sV;
+    const u32 inc = sd_scan_add(len);
+    total += sd_bcast(inc, 63);
+    if (STORE && len) {
+      u8* o = out + (col_len - total) + (inc - len);
+      if (hasZ) *o++ = 0;
+      if (r.is_start) wr_uleb(o, r.rl);
+    }
+    if (base == 0) break;
+  }
+  return (MAYBE && !any_true) ? 0 : total;
+}
+
+// ---- string columns ------------------------------------------------------------------------------------------------
+// A string value is (length, bytes): up to 8 bytes travel in a register (`inl`), longer ones are a pointer.
+struct ScStr { u64 bytes; const u8* p; u32 len; bool inl, isnull; };
+__device__ __forceinline__ bool sc_str_eq(const ScStr& a, const ScStr& b) {
+  if (a.isnull != b.isnull) return false;
+  if (a.isnull) return true;
+  if (a.len != b.len) return false;
+  if (a.inl && b.inl) return a.bytes == b.bytes;
+  if (a.inl || b.inl) {   // one side in a register (<= 8 bytes), the other a pointer to as many bytes
+    const u64 x = a.inl ? a.bytes : amh_peek8_any(a.p) & amh_low_bytes(a.len), y = b.inl ? b.bytes : amh_peek8_any(b.p) & amh_low_bytes(b.len);
+    return x == y;
+  }
+  if (a.p == b.p) return true;
+  for (u32 i = 0; i < a.len; i += 8) {
+    u64 d = amh_peek8_any(a.p + i) ^ amh_peek8_any(b.p + i);
+    const u32 rest = a.len - i;
+    if (rest < 8) d &= amh_low_bytes(rest);
+    if (d) return false;
+  }
+  return true;
+}
+// Src: ScStr load(u32 e) const
+template <bool STORE, class Src>
+__device__ __forceinline__ u32 sc_str_column(const Src& src, u32 n, u8* out, u32 col_len, u32 lane) {
+  if (n == 0 || (STORE && col_len == 0)) return 0;
+  ScCarry carry = sc_carry_init();
+  u32 total = 0;
+  bool any = false;
+  for (u32 base = (n - 1) & ~63u;; base -= 64) {
+    const u32 cnt = n - base < 64 ? n - base : 64;
+    const u32 e = base + lane;
+    const bool valid = lane < cnt;
+    ScStr v; v.bytes = 0; v.p = 0; v.len = 0; v.inl = true; v.isnull = true;
+    if (valid) v = src.load(e);
+    ScStr pv; pv.isnull = true; pv.bytes = 0; pv.p = 0; pv.len = 0; pv.inl = true;
+    if (valid && e > 0) pv = src.load(e - 1);   // (a second load of the neighbour: the values are in L1 / L2)
+    const bool eqp = valid && e > 0 && sc_str_eq(v, pv);
+    const u64 EQP = __ballot(eqp), NUL = __ballot(v.isnull && valid);
+    any = any || (~NUL & sd_low_bits(cnt)) != 0;
+    const ScRoles r = sc_roles(EQP, NUL, cnt, base, lane, carry);
+    const bool nul = v.isnull;
+    const bool hasP = r.emit_p, hasH = r.is_start && !r.is_lone, hasV = r.is_start, hasL = r.is_lh;
+    const i64 nP = -(i64)r.k_p, nH = nul ? 0 : (i64)r.rl, nL = -(i64)r.k_lh;
+    const u32 sP = hasP ? sleb_size_fast(nP) : 0, sH = hasH ? sleb_size_fast(nH) : 0, sL = hasL ? sleb_size_fast(nL) : 0;
+    const u32 sV = !hasV ? 0 : (nul ? uleb_size_fast(r.rl) : uleb_size_fast(v.len) + v.len);
+    const u32 len = sP + sH + sV + sL;
+    const u32 inc = sd_scan_add(len);
+    total += sd_bcast(inc, 63);
+    if (STORE && len) {
+      u8* o = out + (col_len - total) + (inc - len);
+      if (hasP) o += wr_sleb(o, nP);
+      if (hasH) o += wr_sleb(o, nH);
+      if (hasV) {
+        if (nul) o += wr_uleb(o, r.rl);
+        else {
+          o += wr_uleb(o, v.len);
+          if (v.inl) for (u32 i = 0; i < v.len; i++) o[i] = (u8)(v.bytes >> (8 * i));
+          else for (u32 i = 0; i < v.len; i++) o[i] = v.p[i];
+          o += v.len;
+        }
+      }
+      if (hasL) wr_sleb(o, nL);
+    }
+    if (base == 0) break;
+  }
+  return any ? total : 0;
+}
+
+// ---- raw value bytes (value.rs:320-369): the payloads back to back ---------------------------------------------------
+// kind 0 nothing, 1 bytes at p, 2 an integer written as sleb128, 3 up to 8 bytes in a register
+struct ScRaw { u32 kind, len; u64 x; const u8* p; };
+template <bool STORE, class Src>
+__device__ __forceinline__ u32 sc_raw_column(const Src& src, u32 n, u8* out, u32 col_len, u32 lane) {
+  if (n == 0 || (STORE && col_len == 0)) return 0;
+  u32 total = 0;
+  for (u32 base = (n - 1) & ~63u;; base -= 64) {
+    const u32 cnt = n - base < 64 ? n - base : 64;
+    ScRaw v; v.kind = 0; v.len = 0; v.x = 0; v.p = 0;
+    if (lane < cnt) v = src.load(base + lane);
+    const u32 len = v.kind == 0 ? 0 : (v.kind == 2 ? sleb_size_fast((i64)v.x) : v.len);
+    const u32 inc = sd_scan_add(len);
+    total += sd_bcast(inc, 63);
+    if (STORE && len) {
+      u8* o = out + (col_len - total) + (inc - len);
+      if (v.kind == 2) wr_sleb(o, (i64)v.x);
+      else if (v.kind == 3) for (u32 i = 0; i < len; i++) o[i] = (u8)(v.x >> (8 * i));
+      else for (u32 i = 0; i < len; i++) o[i] = v.p[i];
+    }
+    if (base == 0) break;
+  }
+  return total;
+}
+
+// ------------------------------------------------------------------------------------------
+// Change re-encode (change_op_columns.rs:146-329): one wave per (change, column group), the group's columns one after
+// the other out of the change view (k_change_view).  STORE = false: column lengths -> c_col_len; STORE = true: bytes
+// -> out_arena at the offsets k_chg_layout derived from those lengths.
+// Groups: 0 object id (columns 0, 1)  1 key (2, 3, 4)  2 insert / action / predNum / expand (5, 6, 9, 12)
+//         3 value (7, 8)  4 pred lists (10, 11)  5 mark names (13)
+// ------------------------------------------------------------------------------------------
+// The change view is read through a one-value cache per lane: the wave fetches the tile it starts with (the last one)
+// for all of its columns at once, before the first column is encoded, so the columns of a small change do not each
+// wait for memory in turn.
+template <class T> struct ScCached {
+  const T* g; u32 ce; T cx;
+  __device__ __forceinline__ void init(const T* p, u32 e, bool valid) { g = p; ce = 0xFFFFFFFFu; if (valid) { cx = p[e]; ce = e; } }
+  __device__ __forceinline__ T get(u32 e) const { T r = cx; if (e != ce) r = g[e]; return r; }
+};
+struct ScObjSrc {   // cv[0]: {object actor (change-local) or NULL32, object counter (0 = root)}
+  ScCached<uint2> g; bool ctr;
+  __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const { uint2 x = g.get(e); isnull = x.y == 0; v = ctr ? x.y : x.x; }
+};
+// cv[2]: {key actor, key counter, string offset, string length | flags}
+__device__ __forceinline__ bool sc_key_inl(const uint4& x) { return x.w != AMH_NULL32 && (x.w & AMH_CV_INLINE); }
+struct ScKeyActorSrc {
+  ScCached<uint4> g;
+  __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const { uint4 x = g.get(e); isnull = sc_key_inl(x) || x.x == AMH_NULL32; v = x.x; }
+};
+struct ScKeyCtrSrc {   // delta column: the value is the difference to the last non-null counter in front (delta.rs:23-27)
+  ScCached<uint4> g;
+  __device__ __forceinline__ bool ctr(u32 e, u32& c) const { uint4 x = g.get(e); c = x.y; return !(sc_key_inl(x) || x.y == AMH_NULL32); }
+  __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const {
+    u32 c, pc = 0;
+    isnull = !ctr(e, c);
+    v = 0;
+    if (isnull) return;
+    for (u32 j = e; j > 0; j--) { u32 t; if (ctr(j - 1, t)) { pc = t; break; } }
+    v = (u64)((i64)c - (i64)pc);
+  }
+};
+struct ScKeyStrSrc {
+  ScCached<uint4> g; const u8* chunk;
+  __device__ __forceinline__ ScStr load(u32 e) const {
+    uint4 x = g.get(e);
+    ScStr s; s.isnull = x.w == AMH_NULL32; s.inl = sc_key_inl(x);
+    s.bytes = s.inl ? ((u64)x.x | ((u64)x.y << 32)) : 0;
+    s.len = s.isnull ? 0 : (s.inl ? (x.w & 0xFF) : x.w);
+    s.p = chunk + x.z;
+    return s;
+  }
+};
+// cv[6]: {insert | expand << 1 | action << 8, pred count}
+struct ScInsertSrc { ScCached<uint2> g; __device__ __forceinline__ bool load(u32 e) const { return (g.get(e).x & 1) != 0; } };
+struct ScExpandSrc { ScCached<uint2> g; __device__ __forceinline__ bool load(u32 e) const { return (g.get(e).x & 2) != 0; } };
+struct ScActionSrc { ScCached<uint2> g; __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const { v = g.get(e).x >> 8; isnull = false; } };
+struct ScPredNumSrc { ScCached<uint2> g; __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const { v = g.get(e).y; isnull = false; } };
+// cv[8]: {meta lo, meta hi | kind << 8 | bytes << 16, payload or reference}
+struct ScValMetaSrc {
+  ScCached<uint4> g;
+  __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const { uint4 x = g.get(e); v = (u64)x.x | ((u64)(x.y & 0xFF) << 32); isnull = false; }
+};
+struct ScValRawSrc {
+  ScCached<uint4> g; const u8* chunk;
+  __device__ __forceinline__ ScRaw load(u32 e) const {
+    uint4 x = g.get(e);
+    ScRaw r; r.kind = (x.y >> 8) & 0xFF; r.x = (u64)x.z | ((u64)x.w << 32); r.p = chunk + x.z;
+    r.len = r.kind == 3 ? ((x.y >> 16) & 0xF) : (r.kind == 1 ? x.w : 0);
+    return r;
+  }
+};
+struct ScPredSrc { const u64* ids; const u32* amap; };   // the change's flattened pred lists (opid_list.rs:52-78)
+struct ScPredActorSrc : ScPredSrc { __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const { v = amap[(u32)ids[e]]; isnull = false; } };
+struct ScPredCtrSrc : ScPredSrc {
+  __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const {
+    const i64 c = (i64)(ids[e] >> 32), pc = e ? (i64)(ids[e - 1] >> 32) : 0;
+    v = (u64)(c - pc); isnull = false;
+  }
+};
+struct ScMarkSrc {
+  const BatchDev& B; const u32* ops; const u8* chunk;
+  __device__ __forceinline__ ScStr load(u32 e) const {
+    const u32 t = ops[e];
+    ScStr s; s.bytes = 0; s.inl = false; s.p = chunk; s.len = 0;
+    s.isnull = !(!op_is_del(B, t) && B.r_action[t] == 7 && B.r_mark_len[t] != AMH_NULL32);
+    if (!s.isnull) { s.p = chunk + B.r_mark_off[t]; s.len = B.r_mark_len[t]; }
+    return s;
+  }
+};
+
+// blockIdx.y of gridDim.y: the column groups are dealt over gridDim.y waves per change (1 = one wave encodes all the
+// columns of a change: batches of small changes; SC_GROUPS = a wave per group: few, large changes)
+#define SC_GROUPS 5
+template <bool STORE>
+__global__ void __launch_bounds__(64 * SD_WAVES) g_encode_seg(BatchDev B) {
+  const u32 wave = sd_uniform(threadIdx.x >> 6);
+  const u32 c = blockIdx.x * SD_WAVES + wave;
+  if (c >= B.tot_chg) return;
+  const u32 lane = threadIdx.x & 63;
+  u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
+  const u32 d = B.c_doc[c];
+  const bool live = B.status[d] == 0;
+  const u32 n = live ? B.c_nops[c] : 0;
+  const u32 base = B.c_op_base[c];
+  const u8* chunk = B.arena + B.desc[d].chunk_off;
+  if (STORE && !live) return;
+  // store pass: the column lengths of the size pass (as k_chg_layout left them) once, up front; the columns lie back to back
+  u32 clen[AMH_NCOLS], coff[AMH_NCOLS];
+  u8* cols = (u8*)0;
+  if (STORE) {
+    cols = B.out_arena + (u64)B.c_out_off[c] + B.c_cols_off[c];
+    u32 o = 0;
+#pragma unroll
+    for (int k = 0; k < AMH_NCOLS; k++) { clen[k] = cl[k]; coff[k] = o; o += clen[k]; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < AMH_NCOLS; k++) { clen[k] = 0; coff[k] = 0; }
+  }
+  auto out = [&](int k) -> u8* { return cols + coff[k]; };
+  auto put = [&](int k, u32 v) { if (!STORE && lane == 0) cl[k] = v; };
+  const u32 e0 = n ? ((n - 1) & ~63u) + lane : 0;   // this lane's value in the tile the walks start with
+  const bool v0 = n && e0 < n;
+  const bool all = gridDim.y == 1;
+  ScCached<uint2> cobj, cmisc;
+  ScCached<uint4> ckey, cval;
+  const u32 G0 = blockIdx.y;
+  if (all || G0 == 0) cobj.init((const uint2*)B.cv[0] + base, e0, v0);
+  if (all || G0 == 1) ckey.init((const uint4*)B.cv[2] + base, e0, v0);
+  if (all || G0 == 2) cmisc.init((const uint2*)B.cv[6] + base, e0, v0);
+  if (all || G0 == 3) cval.init((const uint4*)B.cv[8] + base, e0, v0);
+  for (u32 G = G0; G < SC_GROUPS; G += gridDim.y) {
+    if (G == 0) {   // object id (columns 0, 1) and mark names (13)
+      ScObjSrc sa{cobj, false}, sc{cobj, true};
+      u32 la = sc_rle_column<false, STORE>(sa, n, STORE ? out(0) : (u8*)0, clen[0], lane);
+      u32 lc = sc_rle_column<false, STORE>(sc, n, STORE ? out(1) : (u8*)0, clen[1], lane);
+      put(0, la); put(1, lc);
+      u32 lm = 0;
+      if (live && B.desc[d].ocol[OC_MARK_NAME].len != 0) {   // only documents with a mark column
+        ScMarkSrc sm{B, B.ops_sorted + base, chunk};
+        lm = sc_str_column<STORE>(sm, n, STORE ? out(13) : (u8*)0, clen[13], lane);
+      }
+      put(13, lm);
+    } else if (G == 1) {   // key (2, 3, 4)
+      ScKeyActorSrc sa{ckey};
+      ScKeyCtrSrc sk{ckey};
+      ScKeyStrSrc ss{ckey, chunk};
+      u32 la = sc_rle_column<false, STORE>(sa, n, STORE ? out(2) : (u8*)0, clen[2], lane);
+      u32 lk = sc_rle_column<true, STORE>(sk, n, STORE ? out(3) : (u8*)0, clen[3], lane);
+      u32 ls = sc_str_column<STORE>(ss, n, STORE ? out(4) : (u8*)0, clen[4], lane);
+      put(2, la); put(3, lk); put(4, ls);
+    } else if (G == 2) {   // insert, action, predNum, expand (5, 6, 9, 12)
+      ScInsertSrc si{cmisc};
+      ScActionSrc sa{cmisc};
+      ScPredNumSrc sp{cmisc};
+      ScExpandSrc se{cmisc};
+      u32 li = sc_bool_column<false, STORE>(si, n, STORE ? out(5) : (u8*)0, clen[5], lane);
+      u32 la = sc_rle_column<false, STORE>(sa, n, STORE ? out(6) : (u8*)0, clen[6], lane);
+      u32 lp = sc_rle_column<false, STORE>(sp, n, STORE ? out(9) : (u8*)0, clen[9], lane);
+      u32 le = sc_bool_column<true, STORE>(se, n, STORE ? out(12) : (u8*)0, clen[12], lane);
+      put(5, li); put(6, la); put(9, lp); put(12, le);
+    } else if (G == 3) {   // value (7, 8)
+      ScValMetaSrc sm{cval};
+      ScValRawSrc sr{cval, chunk};
+      u32 lm = sc_rle_column<false, STORE>(sm, n, STORE ? out(7) : (u8*)0, clen[7], lane);
+      u32 lr = sc_raw_column<STORE>(sr, n, STORE ? out(8) : (u8*)0, clen[8], lane);
+      put(7, lm); put(8, lr);
+    } else {   // pred lists (10, 11)
+      u32 pb = 0, pn = 0;
+      if (n) { pb = B.j_pred_base[base]; pn = B.j_pred_base[base + n] - pb; }
+      ScPredActorSrc sa; sa.ids = B.pred_ids + pb; sa.amap = B.chg_actor_map + B.c_map_base[c];
+      ScPredCtrSrc sc; sc.ids = sa.ids; sc.amap = sa.amap;
+      u32 la = sc_rle_column<false, STORE>(sa, pn, STORE ? out(10) : (u8*)0, clen[10], lane);
+      u32 lc = sc_rle_column<true, STORE>(sc, pn, STORE ? out(11) : (u8*)0, clen[11], lane);
+      put(10, la); put(11, lc);
+    }
+  }
+}

@@ -122,6 +122,20 @@ def test_device_arrays_match_host_emulation(engine, golden_dir):
         assert np.array_equal(a, b), name
 
 
+@pytest.mark.parametrize("form", ["seg", "lane"])
+def test_both_encoder_forms(engine, golden_dir, monkeypatch, form):
+    """the change re-encode has a wave-per-change form (large changes) and a lane-per-change form (batches of small
+    changes), chosen by the batch's average change size: every document shape through both"""
+    monkeypatch.setenv("AMH_ENCODE_FORM", form)
+    docs = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(golden_dir, "docs", "*.automerge")))]
+    docs += _docs_map(engine, 24, 77)
+    blob, offs = engine.gen_text_docs(0xF00D, 3, 3, 150, 900, 300, 2)
+    docs += [blob[offs[i]:offs[i + 1]] for i in range(9)]
+    batch = engine.load_batch(docs)
+    for i, d in enumerate(docs):
+        _compare(batch, i, d)
+
+
 def test_deep_dependency_chains(engine):
     """more dependency levels than the level-parallel hashing handles (AMH_LEVEL_CAP): sequential per-document hashing"""
     blob, offs = engine.gen_text_docs(0xD070, 2, 2, 20, 600, 10, 2)
