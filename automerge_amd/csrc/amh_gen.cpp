@@ -471,6 +471,49 @@ static void gen_map_doc(u64 seed, u32 n_actors, u32 rounds, u32 ops_per_change, 
 // runs of inserts at a random visible position (geometric run length, p = 0.2) and deletes.
 // Output per document: n_replicas saved documents (base + that replica's changes).
 struct Elem { u32 op; bool deleted; };
+// The element order of the text object under random edits: blocks of at most 2 * SEQ_BLOCK elements with their visible
+// counts, so that "the k-th visible element" and "insert here" cost a scan of the block table plus one block (the flat
+// vector this replaces made a 10M-op document quadratic).  Same positions, same documents as before.
+struct ElemSeq {
+  enum { SEQ_BLOCK = 4096 };
+  struct Block { std::vector<Elem> e; u32 vis = 0; };
+  std::vector<Block> blocks;
+  struct Pos { u32 b, i; };   // block, index inside it (i == size: behind the block's last element)
+  ElemSeq() { blocks.emplace_back(); }
+  void push_back(Elem x) {
+    if (blocks.back().e.size() >= SEQ_BLOCK) blocks.emplace_back();
+    blocks.back().e.push_back(x);
+    blocks.back().vis += x.deleted ? 0 : 1;
+  }
+  // the k-th (0-based) visible element
+  Pos kth_visible(u32 k) const {
+    u32 b = 0;
+    while (k >= blocks[b].vis) { k -= blocks[b].vis; b++; }
+    const std::vector<Elem>& e = blocks[b].e;
+    u32 i = 0;
+    for (u32 seen = 0;; i++) if (!e[i].deleted) { if (seen == k) break; seen++; }
+    return Pos{b, i};
+  }
+  Elem& at(Pos p) { return blocks[p.b].e[p.i]; }
+  void mark_deleted(Pos p) { at(p).deleted = true; blocks[p.b].vis--; }
+  // insert in front of p; returns the position behind the new element
+  Pos insert(Pos p, Elem x) {
+    Block& bl = blocks[p.b];
+    bl.e.insert(bl.e.begin() + p.i, x);
+    bl.vis += x.deleted ? 0 : 1;
+    p.i++;
+    if (bl.e.size() >= 2 * SEQ_BLOCK) {   // split; the cursor follows its element
+      Block nb;
+      nb.e.assign(bl.e.begin() + SEQ_BLOCK, bl.e.end());
+      bl.e.resize(SEQ_BLOCK);
+      for (const Elem& q : nb.e) nb.vis += q.deleted ? 0 : 1;
+      bl.vis -= nb.vis;
+      blocks.insert(blocks.begin() + p.b + 1, std::move(nb));
+      if (p.i > SEQ_BLOCK) { p.b++; p.i -= SEQ_BLOCK; }
+    }
+    return p;
+  }
+};
 static void gen_text_doc(u64 seed, u32 n_replicas, u32 base_len, u32 ops_per_replica, u32 ops_per_change, std::vector<std::vector<u8>>& outs) {
   Rng rng0(seed);
   std::vector<std::string> actors = make_actors(rng0, n_replicas + 1);
@@ -507,9 +550,9 @@ static void gen_text_doc(u64 seed, u32 n_replicas, u32 base_len, u32 ops_per_rep
     D.actors[a] = actors[ag];
     D.actors[base_actor] = actors[base_actor_g];
     make_base(D, base_actor);
-    std::vector<Elem> seq;  // element order of the text object
+    ElemSeq seq;  // element order of the text object
     for (u32 i = 1; i < D.ops.size(); i++) seq.push_back(Elem{i, false});
-    u32 n_vis = (u32)seq.size();
+    u32 n_vis = (u32)D.ops.size() - 1;
     u32 ctr = (u32)D.ops.size() + 1;  // next op counter
     u32 done = 0, seqno = 1, last_change = 0;
     while (done < ops_per_replica) {
@@ -522,14 +565,15 @@ static void gen_text_doc(u64 seed, u32 n_replicas, u32 base_len, u32 ops_per_rep
         bool del = n_vis > 0 && rng.below(100) < 30;
         if (del) {
           // the k-th visible element
-          u32 k = rng.below(n_vis), pos = 0;
-          for (u32 seen = 0; pos < seq.size(); pos++) if (!seq[pos].deleted) { if (seen == k) break; seen++; }
+          u32 k = rng.below(n_vis);
+          ElemSeq::Pos pos = seq.kth_visible(k);
+          const u32 target = seq.at(pos).op;
           GOp o;
           o.id = Id{ctr++, a}; o.obj = D.ops[0].id; o.action = 3;
-          o.key_kind = KEY_ELEM; o.elem = D.ops[seq[pos].op].id;
-          o.pred.push_back(D.ops[seq[pos].op].id);
-          D.ops[seq[pos].op].succ.push_back(o.id);
-          seq[pos].deleted = true;
+          o.key_kind = KEY_ELEM; o.elem = D.ops[target].id;
+          o.pred.push_back(D.ops[target].id);
+          D.ops[target].succ.push_back(o.id);
+          seq.mark_deleted(pos);
           n_vis--;
           c.ops.push_back((u32)D.ops.size());
           D.ops.push_back(o);
@@ -537,10 +581,11 @@ static void gen_text_doc(u64 seed, u32 n_replicas, u32 base_len, u32 ops_per_rep
           continue;
         }
         // a run of inserts after the k-th visible element (k = 0: at the head)
-        u32 k = rng.below(n_vis + 1), pos = 0;  // pos = index in seq after which to insert; 0 = head
-        if (k > 0) { for (u32 seen = 0; pos < seq.size(); pos++) if (!seq[pos].deleted) { seen++; if (seen == k) break; } pos++; }
-        Id prev = pos == 0 ? Id{} : D.ops[seq[pos - 1].op].id;
-        bool head = pos == 0;
+        u32 k = rng.below(n_vis + 1);  // insert behind the k-th visible element; 0 = at the head
+        ElemSeq::Pos pos{0, 0};
+        Id prev{};
+        bool head = k == 0;
+        if (k > 0) { pos = seq.kth_visible(k - 1); prev = D.ops[seq.at(pos).op].id; pos.i++; }
         // RGA: a new element goes right after its reference element, before that element's older
         // children; a reference that is deleted keeps its place, so insert at `pos`
         u32 run = 1;
@@ -554,8 +599,7 @@ static void gen_text_doc(u64 seed, u32 n_replicas, u32 base_len, u32 ops_per_rep
           u32 idx = (u32)D.ops.size();
           D.ops.push_back(o);
           c.ops.push_back(idx);
-          seq.insert(seq.begin() + pos, Elem{idx, false});
-          pos++;
+          pos = seq.insert(pos, Elem{idx, false});
           n_vis++;
           prev = D.ops[idx].id; head = false;
           made++;
@@ -567,7 +611,7 @@ static void gen_text_doc(u64 seed, u32 n_replicas, u32 base_len, u32 ops_per_rep
     }
     std::vector<u32> rows;
     rows.push_back(0);
-    for (const Elem& e : seq) rows.push_back(e.op);
+    for (const ElemSeq::Block& bl : seq.blocks) for (const Elem& e : bl.e) rows.push_back(e.op);
     outs.emplace_back();
     build_document(D, rows, outs.back());
     rep++;

@@ -305,6 +305,106 @@ static int load_trailing_chunks(amh_ctx* ctx, amh_batch* b, const amh_load_opts*
 extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts) {
   return load_staged_impl(ctx, st_c, opts, true);
 }
+// SHA-256 of one message is a serial chain: the device can only put a single lane on it (~20 MB/s), a host core does
+// it 10-50x faster.  The first chunk of inputs of AMH_HOST_SHA_MIN bytes and more is therefore hashed by host threads
+// out of the staged host copy WHILE the device pipeline runs (k_sha_doc skips those chunks); the verdict is applied
+// with the statuses.  Batches of small documents never come here: their hashes are data-parallel on the device.
+#define AMH_HOST_SHA_MIN (256u << 10)
+struct BigSha {
+  std::vector<u32> docs;
+  std::vector<u8> bad, hash;   // per entry of docs
+  std::vector<u64> chunk_len;  // per entry of docs: header + data of the first chunk (0 = header unreadable)
+  std::vector<std::thread> threads;
+  void start(const amh_staged* st) {
+    const u32 n = st->n_docs;
+    if (!st->host_ok) return;
+    for (u32 d = 0; d < n; d++)
+      if (st->h_doc_off[2 * (size_t)d + 1] - st->h_doc_off[2 * (size_t)d] >= AMH_HOST_SHA_MIN) docs.push_back(d);
+    if (docs.empty()) return;
+    bad.assign(docs.size(), 0);
+    chunk_len.assign(docs.size(), 0);
+    hash.assign(docs.size() * 32, 0);
+    auto next = std::make_shared<std::atomic<size_t>>(0);
+    unsigned nt = (unsigned)std::min<size_t>(docs.size(), 8);
+    for (unsigned t = 0; t < nt; t++)
+      threads.emplace_back([this, st, next]() {
+        for (;;) {
+          size_t k = next->fetch_add(1);
+          if (k >= docs.size()) return;
+          const u32 d = docs[k];
+          const u8* p = st->h_arena.data() + st->h_doc_off[2 * (size_t)d];
+          const size_t avail = (size_t)(st->h_doc_off[2 * (size_t)d + 1] - st->h_doc_off[2 * (size_t)d]);
+          // chunk header (chunk.rs:223-266): magic, checksum, type, uleb length; a header the device parser rejects is its business
+          if (avail < 10 || p[0] != 0x85 || p[1] != 0x6f || p[2] != 0x4a || p[3] != 0x83) continue;
+          u64 len = 0; u32 shift = 0; size_t pos = 9; bool okh = false;
+          while (pos < avail && shift < 64) { u8 b = p[pos++]; len |= (u64)(b & 0x7f) << shift; shift += 7; if (!(b & 0x80)) { okh = true; break; } }
+          if (!okh || len > avail - pos) continue;
+          chunk_len[k] = pos + len;
+          u8* h = hash.data() + 32 * k;
+          amh_host_sha256(p + 8, pos - 8, p + pos, (size_t)len, h);
+          bad[k] = (h[0] != p[4] || h[1] != p[5] || h[2] != p[6] || h[3] != p[7]) ? 1 : 0;
+        }
+      });
+  }
+  void join() { for (auto& t : threads) t.join(); threads.clear(); }
+  ~BigSha() { join(); }
+};
+
+// The re-derived changes of such a document: every change's SHA-256 is again one serial message, and a change cannot
+// be hashed before the changes it depends on (their hashes are part of its bytes).  The host takes the chunks as
+// k_chg_header left them, fills in the dep hashes and hashes level by level (the changes of a level in parallel),
+// and sends bytes and hashes back; k_chg_hash / k_chg_hash_seq skip these documents.  (change_collector.rs:163-178,
+// chunk.rs:181-193)
+template <class F> static void host_parallel_for(u32 n, F f, u32 min_items = 128, u32 grain = 32);
+static bool big_hash_changes(amh_batch* b, u32 d) {
+  amh_ctx* ctx = b->ctx;
+  const BatchDev& B = b->B;
+  u32 cb2[2];
+  DocCounts cnt;
+  if (!rt_d2h(cb2, B.chg_base + d, 8, ctx->stream) || !rt_d2h(&cnt, B.cnt + d, sizeof cnt, ctx->stream)) return false;
+  const u32 cb = cb2[0], nc = cnt.n_chg;
+  if (nc == 0) return true;
+  std::vector<u32> out_off(nc + 1), out_len(nc), body_len(nc), ndeps(nc), dep_base(nc), level(nc);
+  u32 db2[2];
+  if (!rt_d2h(out_off.data(), B.c_out_off + cb, (nc + 1) * 4, ctx->stream) || !rt_d2h(out_len.data(), B.c_out_len + cb, nc * 4, ctx->stream) ||
+      !rt_d2h(body_len.data(), B.c_body_len + cb, nc * 4, ctx->stream) || !rt_d2h(ndeps.data(), B.c_ndeps + cb, nc * 4, ctx->stream) ||
+      !rt_d2h(dep_base.data(), B.c_dep_base + cb, nc * 4, ctx->stream) || !rt_d2h(level.data(), B.c_level + cb, nc * 4, ctx->stream) ||
+      !rt_d2h(db2, B.dep_base + d, 8, ctx->stream))
+    return false;
+  std::vector<u32> dep_idx(cnt.n_deps + 1);
+  if (cnt.n_deps && !rt_d2h(dep_idx.data(), B.dep_idx + db2[0], (size_t)cnt.n_deps * 4, ctx->stream)) return false;
+  const size_t lo = out_off[0], hi = out_off[nc];
+  std::vector<u8> bytes(hi - lo + 1), hashes((size_t)nc * 32);
+  if (!rt_d2h(bytes.data(), B.out_arena + lo, hi - lo, ctx->stream)) return false;
+  // changes grouped by level (counting sort; file order inside a level)
+  u32 max_lvl = 0;
+  for (u32 i = 0; i < nc; i++) max_lvl = std::max(max_lvl, level[i]);
+  std::vector<u32> start(max_lvl + 2, 0), order(nc);
+  for (u32 i = 0; i < nc; i++) start[level[i] + 1]++;
+  for (u32 l = 0; l <= max_lvl; l++) start[l + 1] += start[l];
+  { std::vector<u32> fill(start.begin(), start.end() - 1); for (u32 i = 0; i < nc; i++) order[fill[level[i]]++] = i; }
+  auto one = [&](u32 i) {
+    u8* out = bytes.data() + (out_off[i] - lo);
+    const u32 hdr = out_len[i] - body_len[i], nd = ndeps[i];
+    u32 nb = 1; for (u32 v = nd; v >= 0x80; v >>= 7) nb++;
+    u8* deps = out + hdr + nb;
+    std::vector<std::array<u8, 32>> hs(nd);
+    for (u32 k = 0; k < nd; k++) memcpy(hs[k].data(), hashes.data() + (size_t)dep_idx[dep_base[i] - db2[0] + k] * 32, 32);
+    std::sort(hs.begin(), hs.end());
+    for (u32 k = 0; k < nd; k++) memcpy(deps + 32 * k, hs[k].data(), 32);
+    u8* h = hashes.data() + (size_t)i * 32;
+    amh_host_sha256(out + 8, hdr - 8, out + hdr, body_len[i], h);
+    memcpy(out + 4, h, 4);
+  };
+  for (u32 l = 0; l <= max_lvl; l++) {
+    const u32 a = start[l], e = start[l + 1];
+    if (e - a == 1) one(order[a]);
+    else host_parallel_for(e - a, [&](u32 k) { one(order[a + k]); }, 2, 1);
+  }
+  return rt_h2d(B.out_arena + lo, bytes.data(), hi - lo, ctx->stream) && rt_h2d(B.c_hash + (size_t)cb * 32, hashes.data(), (size_t)nc * 32, ctx->stream) &&
+         rt_sync(ctx->stream);
+}
+
 static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts, bool trailing) {
   if (!ctx || !st_c) { set_error(ctx, "invalid argument"); return nullptr; }
   amh_staged* st = const_cast<amh_staged*>(st_c);
@@ -320,7 +420,13 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   B.arena = (const u8*)st->d_arena.p;
   B.doc_off = (const u64*)st->d_doc_off.p;
   bool ok = true;
+  BigSha big;
+#ifndef AMH_EMU
+  big.start(st);
+  if (!big.docs.empty()) B.sha_host_min = AMH_HOST_SHA_MIN;
+#endif
   auto fail = [&](const std::string& m) -> amh_batch* {
+    big.join();
     set_error(ctx, m);
     rt_sync(ctx->side);   // nothing of this batch may still be running when its memory goes back to the pool
     collect_profile(ctx);
@@ -507,12 +613,35 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
     launch(ctx, AK_CHG_HASH, B, lvl_start[lvl + 1] - lvl_start[lvl]);
   }
   if (lvl_start[AMH_LEVEL_CAP_HOST + 1] > lvl_start[AMH_LEVEL_CAP_HOST]) launch(ctx, AK_CHG_HASH_SEQ, B, n);
+  if (B.sha_host_min) {   // large documents: their changes are hashed by the host
+    big.join();
+    for (size_t k = 0; k < big.docs.size(); k++) {
+      if (big.chunk_len[k] < AMH_HOST_SHA_MIN) continue;
+      i32 stt = 0;
+      if (!rt_d2h(&stt, B.status + big.docs[k], sizeof stt, ctx->stream)) return fail("device pipeline failed");
+      if (stt == 0 && !big_hash_changes(b, big.docs[k])) return fail(std::string("device pipeline failed: ") + rt_last_error());
+    }
+  }
   launch(ctx, AK_HEADS, B, n);
   rt_stream_wait(ctx->stream, &ctx->ev_join);   // visibility is in
   b->status.resize(n);
   b->fail_line.resize(n);
   if (!rt_d2h(b->status.data(), B.status, n * sizeof(i32), ctx->stream) || !rt_d2h(b->fail_line.data(), B.fail_line, n * sizeof(u32), ctx->stream) || !rt_sync(ctx->stream))
     return fail(std::string("device pipeline failed: ") + rt_last_error());
+  // the host-side checksums of the large chunks: a mismatch outranks whatever the pipeline made of the damaged bytes
+  big.join();
+  for (size_t k = 0; k < big.docs.size(); k++) {
+    const u32 d = big.docs[k];
+    if (b->status[d] == AMH_E_PARSE) continue;   // the chunk header itself did not parse: that comes first
+    rt_h2d(B.doc_hash + (size_t)d * 32, big.hash.data() + 32 * k, 32, ctx->stream);
+    if (big.bad[k]) {
+      b->status[d] = AMH_E_BAD_CHECKSUM;
+      b->fail_line[d] = __LINE__;
+      rt_h2d(B.status + d, &b->status[d], sizeof(i32), ctx->stream);
+    }
+  }
+  if (!big.docs.empty() && !rt_sync(ctx->stream)) return fail("device pipeline failed");
+  B.sha_host_min = 0;   // a property of this load, not of the batch (merge / save run the kernels with settings of their own)
   collect_profile(ctx);
   // change chunks: a first chunk that is a change, and everything behind the first chunk (automerge.rs:657-695)
   if (trailing && load_trailing_chunks(ctx, b, opts) != AMH_SUCCESS) { amh_batch_free(b); return nullptr; }
@@ -950,7 +1079,7 @@ struct RawBuf {
 
 // per-document host bookkeeping of a batch call on a few threads (documents are independent)
 template <class F>
-static void host_parallel_for(u32 n, F f, u32 min_items = 128, u32 grain = 32) {
+static void host_parallel_for(u32 n, F f, u32 min_items, u32 grain) {
   unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
   if (const char* e = getenv("OMP_NUM_THREADS")) { int v = atoi(e); if (v > 0) nt = std::min<unsigned>(nt, (unsigned)v); }
   if (n < min_items || nt < 2) { for (u32 i = 0; i < n; i++) f(i); return; }
@@ -2266,6 +2395,9 @@ extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch* bc, const amh_save_
   B.sv_body_len = balloc<u32>(b, n + 1, &ok);
   B.sv_off = balloc<u32>(b, n + 2, &ok);
   if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+#ifndef AMH_EMU
+  B.sha_host_min = AMH_HOST_SHA_MIN;   // chunks of that size and more: checksum by the host below, which receives the bytes anyway
+#endif
   launch(ctx, AK_SAVE_CHECK, B, n);
   launch(ctx, AK_SAVE_SIZE, B, n * 25);
   launch(ctx, AK_SAVE_LAYOUT, B, n);
@@ -2290,6 +2422,11 @@ extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch* bc, const amh_save_
   for (u32 d = 0; d < n; d++) {
     if (st[d] != 0) continue;   // failed to load, or a shape save does not handle: no bytes (amh_doc_status / amh_save_status)
     size_t len = 9 + body[d] + (body[d] < 0x80 ? 1 : body[d] < 0x4000 ? 2 : body[d] < 0x200000 ? 3 : body[d] < 0x10000000 ? 4 : 5);
+    if (B.sha_host_min && len >= B.sha_host_min) {   // k_save_finish left the checksum of a large chunk to the host
+      u8 h[32];
+      amh_host_sha256(host.data() + off[d] + 8, len - 8, nullptr, 0, h);
+      memcpy(host.data() + off[d] + 4, h, 4);
+    }
     const u8* src = host.data() + off[d];
     std::vector<u8> z;
     if (deflate && amh_host_deflate_document(src, len, z)) { src = z.data(); len = z.size(); }

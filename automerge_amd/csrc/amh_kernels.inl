@@ -284,6 +284,7 @@ AMH_DEV void k_sha_doc(const BatchDev& B, u32 d) {
   if (B.sha_gate ? B.sha_gate[d] : B.status[d]) return;
   const DocDesc& D = B.desc[d];
   if (D.chunk_len == 0) return;
+  if (B.sha_host_min && D.chunk_len >= B.sha_host_min) return;   // the host hashes this one (amh_host.cpp, BigSha)
   const u8* p = B.arena + D.chunk_off;
   // type byte + uleb(len) exactly as stored (strict parse => canonical) and the data: one contiguous range
   u8* h = B.doc_hash + (u64)d * 32;
@@ -1665,6 +1666,7 @@ AMH_DEV void chg_hash_one(const BatchDev& B, u32 c, u32 cb) {
 AMH_DEV u32 chg_level_bucket(const BatchDev& B, u32 c) {
   u32 d = B.c_doc[c];
   if (B.status[d] || B.doc_level[d] >= AMH_LEVEL_CAP) return AMH_LEVEL_CAP;
+  if (B.sha_host_min && B.desc[d].chunk_len >= B.sha_host_min) return AMH_LEVEL_CAP;   // hashed by the host (amh_host.cpp, big_hash_changes)
   return B.c_level[c];
 }
 AMH_DEV void k_chg_hash(const BatchDev& B, u32 i) {   // i-th change of the current level (lvl_order is grouped by level)
@@ -1673,6 +1675,7 @@ AMH_DEV void k_chg_hash(const BatchDev& B, u32 i) {   // i-th change of the curr
 }
 AMH_DEV void k_chg_hash_seq(const BatchDev& B, u32 d) {
   if (B.status[d] || B.doc_level[d] < AMH_LEVEL_CAP) return;
+  if (B.sha_host_min && B.desc[d].chunk_len >= B.sha_host_min) return;
   u32 cb = B.chg_base[d], nchg = B.cnt[d].n_chg;
   for (u32 i = 0; i < nchg; i++) chg_hash_one(B, cb + i, cb);
 }
@@ -2093,6 +2096,7 @@ AMH_DEV void k_save_finish(const BatchDev& B, u32 d) {
   out[0] = 0x85; out[1] = 0x6f; out[2] = 0x4a; out[3] = 0x83;
   out[8] = 0;
   wr_uleb(out + 9, body_len);
+  if (B.sha_host_min && hdr + body_len >= B.sha_host_min) return;   // large chunk: the host, which receives the bytes anyway, hashes it (amh_save_batch)
   u8 h[32];
   sha256_contig(out + 8, (u64)(hdr - 8) + body_len, h);
   out[4] = h[0]; out[5] = h[1]; out[6] = h[2]; out[7] = h[3];

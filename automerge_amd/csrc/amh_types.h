@@ -88,6 +88,7 @@ struct BatchDev {
   // reference checks in — and before anything is sized or decoded.  Null = the kernel fails the document itself
   // (apply's change chunks).
   const i32* sha_gate;
+  u32 sha_host_min;        // != 0: chunks of at least this many bytes are hashed by the host (one message is a serial chain: a lone lane is ~50x slower than a core)
   u8* sha_bad;
   u32 cur_level;           // start, in lvl_order, of the dependency level hashed by the current k_chg_hash launch
   u32* lvl_order;          // [tot_chg] changes grouped by dependency level
