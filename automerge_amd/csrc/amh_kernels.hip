@@ -718,9 +718,20 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
     hipLaunchKernelGGL(g_decode_seg, dim3((B.n_docs + SD_WAVES - 1) / SD_WAVES, SD_NCOLS + 2), dim3(64 * SD_WAVES), 0, s, B);
     return;
   }
-  if (k == AK_SAVE_SIZE) { hipLaunchKernelGGL((g_save_lds<false>), dim3((B.n_docs + 63) / 64, 8), dim3(64), 0, s, B); return; }
-  if (k == AK_SAVE_STORE) {
-    hipLaunchKernelGGL((g_save_lds<true>), dim3((B.n_docs + 63) / 64, 8), dim3(64), 0, s, B);
+  if (k == AK_SAVE_SIZE || k == AK_SAVE_STORE) {
+    // documents of a few hundred rows and more: a wave per (document, column group) encodes the op columns, 64 rows per
+    // step (g_save_seg); the change-metadata columns, and batches of tiny documents, stay with lane = document (g_save_lds).
+    // AMH_SAVE_FORM=seg | lane forces one form (tests).
+    const char* form = getenv("AMH_SAVE_FORM");
+    const bool seg = form ? form[0] == 's' : (u64)B.tot_rows >= (u64)B.n_docs * 256;
+    const dim3 gl((B.n_docs + 63) / 64, seg ? 1 : 8), gs((B.n_docs + SD_WAVES - 1) / SD_WAVES, SV_GROUPS);
+    if (k == AK_SAVE_SIZE) {
+      hipLaunchKernelGGL((g_save_lds<false>), gl, dim3(64), 0, s, B);
+      if (seg) hipLaunchKernelGGL((g_save_seg<false>), gs, dim3(64 * SD_WAVES), 0, s, B);
+    } else {
+      hipLaunchKernelGGL((g_save_lds<true>), gl, dim3(64), 0, s, B);
+      if (seg) hipLaunchKernelGGL((g_save_seg<true>), gs, dim3(64 * SD_WAVES), 0, s, B);
+    }
     return;
   }
   if (k == AK_ENCODE_SIZE) { launch_encode<false>(B, s); return; }

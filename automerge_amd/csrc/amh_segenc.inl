@@ -414,3 +414,159 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_encode_seg(BatchDev B) {
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// Document save (doc_op_columns.rs:104-311; device form of k_save_size / k_save_store for the op columns 9..24): one
+// wave per (document, column group), the values read straight from the row arrays in document order.  The nine
+// change-metadata columns (a handful of rows per document) stay with g_save_lds group 0.
+// Groups: 0 object id (9, 10)  1 key (11, 12, 13)  2 op id (14, 15)  3 insert / action / succ count / expand (16, 17,
+//         20, 23)  4 value (18, 19)  5 succ lists (21, 22)  6 mark names (24)
+// ------------------------------------------------------------------------------------------
+struct SvCtx { const BatchDev& B; u32 rb, ab; const u8* chunk; };
+struct SvObjSrc {
+  const SvCtx& c; bool ctr;
+  __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const {
+    const u32 r = c.rb + e, oc = c.B.r_obj_ctr[r];
+    isnull = oc == 0;
+    v = ctr ? oc : (isnull ? 0 : c.B.actor_rank[c.ab + c.B.r_obj_actor[r]]);
+  }
+};
+struct SvKeyActorSrc {
+  const SvCtx& c;
+  __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const {
+    const u32 r = c.rb + e;
+    const bool prop = c.B.r_key_len[r] != AMH_NULL32;
+    isnull = prop || c.B.r_key_ctr[r] == 0;
+    v = isnull ? 0 : c.B.actor_rank[c.ab + c.B.r_key_actor[r]];
+  }
+};
+struct SvKeyCtrSrc {   // delta over the non-null counters (HEAD = 0)
+  const SvCtx& c;
+  __device__ __forceinline__ bool ctr(u32 e, u32& k) const { const u32 r = c.rb + e; k = c.B.r_key_ctr[r]; return c.B.r_key_len[r] == AMH_NULL32; }
+  __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const {
+    u32 k, pk = 0;
+    isnull = !ctr(e, k);
+    v = 0;
+    if (isnull) return;
+    for (u32 j = e; j > 0; j--) { u32 t; if (ctr(j - 1, t)) { pk = t; break; } }
+    v = (u64)((i64)k - (i64)pk);
+  }
+};
+struct SvKeyStrSrc {
+  const SvCtx& c;
+  __device__ __forceinline__ ScStr load(u32 e) const {
+    const u32 r = c.rb + e, kl = c.B.r_key_len[r];
+    ScStr s; s.bytes = 0; s.inl = false; s.isnull = kl == AMH_NULL32; s.len = s.isnull ? 0 : kl;
+    s.p = c.chunk + (s.isnull ? 0 : c.B.r_key_off[r]);
+    return s;
+  }
+};
+struct SvIdActorSrc { const SvCtx& c; __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const { v = c.B.actor_rank[c.ab + c.B.r_id_actor[c.rb + e]]; isnull = false; } };
+struct SvIdCtrSrc {
+  const SvCtx& c;
+  __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const {
+    const i64 k = c.B.r_id_ctr[c.rb + e], pk = e ? (i64)c.B.r_id_ctr[c.rb + e - 1] : 0;
+    v = (u64)(k - pk); isnull = false;
+  }
+};
+struct SvInsertSrc { const SvCtx& c; __device__ __forceinline__ bool load(u32 e) const { return c.B.r_insert[c.rb + e] != 0; } };
+struct SvExpandSrc { const SvCtx& c; __device__ __forceinline__ bool load(u32 e) const { const u32 r = c.rb + e; return c.B.r_action[r] == 7 && c.B.r_expand[r]; } };
+struct SvActionSrc { const SvCtx& c; __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const { v = c.B.r_action[c.rb + e]; isnull = false; } };
+struct SvSuccNumSrc { const SvCtx& c; __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const { v = c.B.r_succ_cnt[c.rb + e]; isnull = false; } };
+struct SvValMetaSrc { const SvCtx& c; __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const { v = op_val(c.B, c.rb + e).meta; isnull = false; } };
+struct SvValRawSrc {
+  const SvCtx& c;
+  __device__ __forceinline__ ScRaw load(u32 e) const {
+    const OpVal v = op_val(c.B, c.rb + e);
+    ScRaw r; r.kind = (u32)v.kind; r.len = v.raw_len; r.x = (u64)v.i; r.p = v.raw;
+    if (r.kind == 1 && r.len == 0) r.kind = 0;
+    return r;
+  }
+};
+struct SvSuccActorSrc { const SvCtx& c; u32 sb; __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const { v = c.B.actor_rank[c.ab + c.B.s_actor[sb + e]]; isnull = false; } };
+struct SvSuccCtrSrc {
+  const SvCtx& c; u32 sb;
+  __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const {
+    const i64 k = c.B.s_ctr[sb + e], pk = e ? (i64)c.B.s_ctr[sb + e - 1] : 0;
+    v = (u64)(k - pk); isnull = false;
+  }
+};
+struct SvMarkSrc {
+  const SvCtx& c;
+  __device__ __forceinline__ ScStr load(u32 e) const {
+    const u32 r = c.rb + e;
+    ScStr s; s.bytes = 0; s.inl = false; s.p = c.chunk; s.len = 0;
+    s.isnull = !(c.B.r_action[r] == 7 && c.B.r_mark_len[r] != AMH_NULL32);
+    if (!s.isnull) { s.p = c.chunk + c.B.r_mark_off[r]; s.len = c.B.r_mark_len[r]; }
+    return s;
+  }
+};
+
+#define SV_GROUPS 7
+template <bool STORE>
+__global__ void __launch_bounds__(64 * SD_WAVES) g_save_seg(BatchDev B) {
+  const u32 wave = sd_uniform(threadIdx.x >> 6);
+  const u32 d = blockIdx.x * SD_WAVES + wave;
+  if (d >= B.n_docs) return;
+  const u32 lane = threadIdx.x & 63;
+  const bool live = B.status[d] == 0 && B.sv_status[d] == 0;
+  u32* cl = B.sv_col_len + (u64)d * AMH_SV_NCOLS;
+  if (STORE && !live) return;
+  const u32 n = live ? B.cnt[d].n_rows : 0, ns = live ? B.cnt[d].n_succ : 0;
+  SvCtx c{B, B.row_base[d], B.actor_base[d], B.arena + B.desc[d].chunk_off};
+  u32 clen[AMH_SV_NCOLS], coff[AMH_SV_NCOLS];
+  u8* cols = (u8*)0;
+  if (STORE) {
+    cols = B.sv_out + (u64)B.sv_off[d] + sv_data_start(B, d);
+    u32 o = 0;
+#pragma unroll
+    for (int k = 0; k < AMH_SV_NCOLS; k++) { clen[k] = cl[k]; coff[k] = o; o += clen[k]; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < AMH_SV_NCOLS; k++) { clen[k] = 0; coff[k] = 0; }
+  }
+  auto out = [&](int k) -> u8* { return cols + coff[k]; };
+  auto put = [&](int k, u32 v) { if (!STORE && lane == 0) cl[k] = v; };
+  const u32 G = blockIdx.y;
+  if (G == 0) {
+    SvObjSrc sa{c, false}, sc{c, true};
+    u32 la = sc_rle_column<false, STORE>(sa, n, out(9), clen[9], lane);
+    u32 lc = sc_rle_column<false, STORE>(sc, n, out(10), clen[10], lane);
+    put(9, la); put(10, lc);
+  } else if (G == 1) {
+    SvKeyActorSrc sa{c}; SvKeyCtrSrc sk{c}; SvKeyStrSrc ss{c};
+    u32 la = sc_rle_column<false, STORE>(sa, n, out(11), clen[11], lane);
+    u32 lk = sc_rle_column<true, STORE>(sk, n, out(12), clen[12], lane);
+    u32 ls = sc_str_column<STORE>(ss, n, out(13), clen[13], lane);
+    put(11, la); put(12, lk); put(13, ls);
+  } else if (G == 2) {
+    SvIdActorSrc sa{c}; SvIdCtrSrc sk{c};
+    u32 la = sc_rle_column<false, STORE>(sa, n, out(14), clen[14], lane);
+    u32 lk = sc_rle_column<true, STORE>(sk, n, out(15), clen[15], lane);
+    put(14, la); put(15, lk);
+  } else if (G == 3) {
+    SvInsertSrc si{c}; SvActionSrc sa{c}; SvSuccNumSrc sn{c}; SvExpandSrc se{c};
+    u32 li = sc_bool_column<false, STORE>(si, n, out(16), clen[16], lane);
+    u32 la = sc_rle_column<false, STORE>(sa, n, out(17), clen[17], lane);
+    u32 ln = sc_rle_column<false, STORE>(sn, n, out(20), clen[20], lane);
+    u32 le = sc_bool_column<true, STORE>(se, n, out(23), clen[23], lane);
+    put(16, li); put(17, la); put(20, ln); put(23, le);
+  } else if (G == 4) {
+    SvValMetaSrc sm{c}; SvValRawSrc sr{c};
+    u32 lm = sc_rle_column<false, STORE>(sm, n, out(18), clen[18], lane);
+    u32 lr = sc_raw_column<STORE>(sr, n, out(19), clen[19], lane);
+    put(18, lm); put(19, lr);
+  } else if (G == 5) {
+    SvSuccActorSrc sa{c, B.succ_base[d]}; SvSuccCtrSrc sk{c, B.succ_base[d]};
+    u32 la = sc_rle_column<false, STORE>(sa, ns, out(21), clen[21], lane);
+    u32 lk = sc_rle_column<true, STORE>(sk, ns, out(22), clen[22], lane);
+    put(21, la); put(22, lk);
+  } else {
+    u32 lm = 0;
+    if (live && B.desc[d].ocol[OC_MARK_NAME].len != 0) {
+      SvMarkSrc sm{c};
+      lm = sc_str_column<STORE>(sm, n, out(24), clen[24], lane);
+    }
+    put(24, lm);
+  }
+}

@@ -169,10 +169,14 @@ def test_sync_summaries(engine, golden_dir):
         assert rec["bloom"] == ref.bloom()
 
 
-def test_save(engine, golden_dir):
-    """save_nocompress(load(x)) is byte-identical to the oracle's; save() = same chunk with columns >= 256 bytes
+@pytest.mark.parametrize("form", ["auto", "seg", "lane"])
+def test_save(engine, golden_dir, monkeypatch, form):
+    """(both forms of the save kernels: wave per (document, column group) / lane per document)
+    save_nocompress(load(x)) is byte-identical to the oracle's; save() = same chunk with columns >= 256 bytes
     DEFLATEd (compressed bytes are zlib's: parity unpinned, so compare after loading them back)"""
     import oracle_lib as o
+    if form != "auto":
+        monkeypatch.setenv("AMH_SAVE_FORM", form)
     docs = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(golden_dir, "docs", "*.automerge")))]
     blob, offs = engine.gen_map_docs(31, 5, 4, 5, 50, 64, 2)
     docs += [blob[offs[i]:offs[i + 1]] for i in range(5)]
