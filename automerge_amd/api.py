@@ -41,7 +41,7 @@ EXPORTS = [
     "amh_changes", "amh_hydrate_json", "amh_doc_max_op", "amh_merge_batch", "amh_apply_changes", "amh_save_batch",
     "amh_sync_summaries", "amh_ctx_set_profiling", "amh_ctx_num_kernels", "amh_ctx_kernel_name", "amh_ctx_kernel_time",
     "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free", "amh_apply_batch", "amh_doc_queue_len", "amh_merge_many", "amh_save_after",
-    "amh_sync_summaries_noalloc",
+    "amh_sync_summaries_noalloc", "amh_ctx_pool_bytes",
 ]
 
 DOC_ERRORS = {
@@ -82,6 +82,7 @@ def bind(lib):
     lib.amh_ctx_kernel_name.argtypes = [C.c_int]
     lib.amh_ctx_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.amh_ctx_reset_profile.argtypes = [vp]
+    lib.amh_ctx_pool_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.amh_gen_map_docs.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                      C.POINTER(BytesOut), C.POINTER(C.POINTER(C.c_uint64))]
     lib.amh_gen_text_docs.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
@@ -444,6 +445,12 @@ class Engine:
     # --- measurement -------------------------------------------------------------------------
     def set_profiling(self, on):
         self.lib.amh_ctx_set_profiling(self.ctx, 1 if on else 0)
+
+    def pool_bytes(self):
+        """(live, pooled) device bytes of the context's caching allocator"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self.lib.amh_ctx_pool_bytes(self.ctx, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def reset_profile(self):
         self.lib.amh_ctx_reset_profile(self.ctx)

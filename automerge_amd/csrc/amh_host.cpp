@@ -206,6 +206,18 @@ static T* balloc(amh_batch* b, size_t count, bool* ok) {
   return (T*)a.p;
 }
 
+// Device memory a call takes for its own use (not part of the batch's state): handed back to the pool when the call
+// returns, on every path.  The call's stream work must have drained by then (the calls read their results back first).
+struct CallScratch {
+  amh_batch* b;
+  size_t mark;
+  explicit CallScratch(amh_batch* bb) : b(bb), mark(bb->allocs.size()) {}
+  ~CallScratch() {
+    rt_sync(b->ctx->stream);
+    while (b->allocs.size() > mark) { b->ctx->pool.release(b->allocs.back().p, b->allocs.back().cap); b->allocs.pop_back(); }
+  }
+};
+
 static bool scan_inplace(amh_batch* b, u32* data, u32 n, u32* total) {
   amh_ctx* ctx = b->ctx;
   bool ok = true;
@@ -2389,6 +2401,7 @@ extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch* bc, const amh_save_
   for (u32 d = 0; d < n; d++) { out[d].data = nullptr; out[d].len = 0; }
   if (n == 0) return AMH_SUCCESS;
   bool ok = true;
+  CallScratch scratch(b);   // everything this call allocates goes back to the pool when it returns
   B.sv_status = balloc<i32>(b, n + 1, &ok);
   B.sv_col_len = balloc<u32>(b, (size_t)n * 25 + 1, &ok);
   B.sv_wide = balloc<u32>(b, n + 1, &ok);
@@ -2452,6 +2465,7 @@ extern "C" int amh_sync_summaries(amh_ctx* ctx, const amh_batch* bc, amh_bytes_o
   out->len = 0;
   if (n == 0) return AMH_SUCCESS;
   bool ok = true;
+  CallScratch scratch(b);
   B.sync_off = balloc<u32>(b, n + 2, &ok);
   if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
   launch(ctx, AK_SYNC_SIZE, B, n);
@@ -2538,6 +2552,12 @@ extern "C" int amh_ctx_kernel_time(amh_ctx* ctx, int k, double* ms, uint64_t* la
   if (!ctx || k < 0 || k >= AK_NUM) return AMH_ERR_INVALID_ARG;
   if (ms) *ms = ctx->kernel_ms[k];
   if (launches) *launches = ctx->kernel_calls[k];
+  return AMH_SUCCESS;
+}
+extern "C" int amh_ctx_pool_bytes(const amh_ctx* ctx, uint64_t* live, uint64_t* pooled) {
+  if (!ctx) return AMH_ERR_INVALID_ARG;
+  if (live) *live = ctx->pool.live_bytes;
+  if (pooled) *pooled = ctx->pool.pooled_bytes;
   return AMH_SUCCESS;
 }
 extern "C" int amh_ctx_reset_profile(amh_ctx* ctx) {

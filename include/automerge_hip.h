@@ -218,6 +218,8 @@ const char* amh_ctx_kernel_name(int k);
 /* accumulated milliseconds and launch count since the last reset */
 int amh_ctx_kernel_time(amh_ctx*, int k, double* ms, uint64_t* launches);
 int amh_ctx_reset_profile(amh_ctx*);
+/* device memory of the context's caching allocator: bytes held by live batches / staged inputs, and bytes parked for reuse */
+int amh_ctx_pool_bytes(const amh_ctx*, uint64_t* live, uint64_t* pooled);
 
 /* Diagnostics (no counterpart in the reference): copy one named device array of a batch to the host
  * (names = fields of BatchDev, automerge_amd/csrc/amh_types.h).  *len receives the byte size; with

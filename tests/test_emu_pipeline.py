@@ -38,6 +38,19 @@ def test_golden_documents(emu, golden_dir):
         compare(batch, i, d)
 
 
+def test_reference_written_documents(emu, golden_dir):
+    """documents saved by the reference itself (tests/golden/ref_saved_docs.json): re-saved bytes == input"""
+    import json
+    fx = json.load(open(os.path.join(golden_dir, "ref_saved_docs.json")))["docs"]
+    docs = [bytes(f["bytes"]) for f in fx]
+    batch = emu.load_batch(docs)
+    saved = batch.save_all(deflate=False)
+    for i, f in enumerate(fx):
+        batch.check(i)
+        assert json.loads(batch.hydrate_json(i))[f["key"]][0]["str"] == f["value"]
+        assert saved[i] == docs[i]
+
+
 def test_bad_documents_fail_like_the_oracle(emu, golden_dir):
     """fuzz crashers (tests/test.rs:1405-1415) and invalid fixtures: same accept / reject decision; a
     bad document never poisons its neighbours in the batch."""
@@ -267,3 +280,16 @@ def test_checksum_outranks_reconstruction_errors(emu):
     blob, offs = emu.gen_map_docs(0xE770, 2, 3, 3, 20, 16, 1)
     for i in range(2):
         ac.check_error_precedence(emu, blob[offs[i]:offs[i + 1]])
+
+
+def test_repeated_save_and_summaries_do_not_grow_the_batch(emu):
+    """amh_save_batch / amh_sync_summaries take their scratch from the pool per call and give it back (a long-lived
+    batch that is saved or summarised in a loop must not grow)"""
+    blob, offs = emu.gen_map_docs(5, 8, 3, 3, 10, 16, 1)
+    b = emu.load_batch([blob[offs[i]:offs[i + 1]] for i in range(8)])
+    b.save_all(deflate=False); b.sync_summaries_raw()
+    live0 = emu.pool_bytes()[0]
+    for _ in range(50):
+        b.save_all(deflate=False)
+        b.sync_summaries_raw()
+    assert emu.pool_bytes()[0] == live0

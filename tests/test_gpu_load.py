@@ -37,6 +37,20 @@ def test_golden_documents_bit_exact(engine, golden_dir):
         _compare(batch, i, d)
 
 
+def test_reference_written_documents(engine, golden_dir):
+    """documents saved by the reference itself (tests/golden/ref_saved_docs.json): value, and re-saved bytes == input"""
+    import json
+    fx = json.load(open(os.path.join(golden_dir, "ref_saved_docs.json")))["docs"]
+    docs = [bytes(f["bytes"]) for f in fx]
+    batch = engine.load_batch(docs)
+    saved = batch.save_all(deflate=False)
+    for i, f in enumerate(fx):
+        _compare(batch, i, docs[i])
+        h = json.loads(batch.hydrate_json(i))
+        assert h[f["key"]][0]["str"] == f["value"]
+        assert saved[i] == docs[i]
+
+
 def _docs_map(engine, n, seed=0xA070):
     blob, offs = engine.gen_map_docs(seed, n, 4, 5, 50, 128, 8)
     return [blob[offs[i]:offs[i + 1]] for i in range(n)]

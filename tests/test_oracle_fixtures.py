@@ -85,3 +85,21 @@ def test_edit_trace_fixture(golden_dir):
     assert c["hash"].hex() == meta["change_hash"] and c["len"] == meta["n_ops"]
     et.check_hydrated(d.hydrate_json(), meta)
     assert d.save(deflate=False) == data
+
+
+def test_reference_written_documents_resave_identically(golden_dir):
+    """Three documents the reference itself saved (Automerge.save output quoted in rust/automerge-c/test/map_tests.c:156-162,
+    :196-202 and list_tests.c:440-446): the expected value comes out, and save_nocompress(load(x)) == x pins the document
+    ENCODER (DocOpColumns / DocChangeColumns, storage/document.rs:214-263) against bytes the reference wrote."""
+    import json
+    import os
+    import oracle_lib as o
+    fx = json.load(open(os.path.join(golden_dir, "ref_saved_docs.json")))["docs"]
+    assert len(fx) == 3
+    for f in fx:
+        raw = bytes(f["bytes"])
+        d = o.Doc.load(raw)
+        h = json.loads(d.hydrate_json())
+        assert list(h.keys()) == [f["key"]] and h[f["key"]][0]["str"] == f["value"], f["name"]
+        assert d.save(deflate=False) == raw, f["name"]
+        assert d.save(deflate=True) == raw, f["name"]   # every column is under 256 bytes: nothing is deflated
