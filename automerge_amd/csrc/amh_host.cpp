@@ -93,8 +93,8 @@ struct amh_ctx {
   u8* stage = nullptr;
   size_t stage_cap = 0;
   bool profiling = false;
-  double kernel_ms[AK_NUM] = {0};
-  uint64_t kernel_calls[AK_NUM] = {0};
+  double kernel_ms[AK_NUM + MK_NUM] = {0};      // load / save kernels, then the merge / apply kernels
+  uint64_t kernel_calls[AK_NUM + MK_NUM] = {0};
   struct Pending { int k; rt_event a, b; };
   std::vector<Pending> pending;
   std::string last_error;
@@ -187,6 +187,26 @@ static void launch_on(amh_ctx* ctx, rt_stream st, int k, const BatchDev& B, u32 
   }
 }
 static void launch(amh_ctx* ctx, int k, const BatchDev& B, u32 n) { launch_on(ctx, ctx->stream, k, B, n); }
+static const char* const MK_KERNEL_NAMES[MK_NUM] = {
+  "mg_new_flag", "mg_pair_counts", "mg_subtree", "mg_gap", "mg_inherit", "mg_extra_cnt", "mg_rows_dst", "mg_rows_new", "mg_succ_dst",
+  "mg_succ_new", "mg_succ_extra", "mg_succ_sort", "mg_doc_succ", "mg_changes", "mg_copy_chunks",
+  "ap_parse", "ap_count", "ap_verify", "ap_map", "ap_chg_meta", "ap_new_flag", "ap_link", "ap_children", "ap_sort_children", "ap_jump", "ap_weight",
+  "ap_top_place", "ap_emit", "ap_pred_cnt", "ap_succ_fill_u", "ap_succ_sort_u", "ap_succ_fill_d"};
+// a merge / apply kernel, timed like the others when the context is profiling
+static void launch_mg_timed(amh_ctx* ctx, int k, const MergeDev* G, u32 n) {
+  if (ctx->profiling) {
+    amh_ctx::Pending p;
+    p.k = AK_NUM + k;
+    rt_event_create(&p.a);
+    rt_event_create(&p.b);
+    rt_event_record(&p.a, ctx->stream);
+    amh_launch_mg(k, G, n, (void*)ctx->stream);
+    rt_event_record(&p.b, ctx->stream);
+    ctx->pending.push_back(p);
+  } else {
+    amh_launch_mg(k, G, n, (void*)ctx->stream);
+  }
+}
 static void collect_profile(amh_ctx* ctx) {
   for (auto& p : ctx->pending) {
     ctx->kernel_ms[p.k] += rt_event_ms(&p.a, &p.b);
@@ -1233,9 +1253,9 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
     if (n == 0) return true;
     if (!rt_h2d(Gdev, &G, sizeof(MergeDev), ctx->stream)) return false;
 #ifdef AMH_EMU
-    amh_launch_mg(k, &G, n, (void*)ctx->stream);
+    launch_mg_timed(ctx, k, &G, n);
 #else
-    amh_launch_mg(k, Gdev, n, (void*)ctx->stream);
+    launch_mg_timed(ctx, k, Gdev, n);
 #endif
     return true;
   };
@@ -1850,9 +1870,9 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       G0.U = U; G0.A.hdr = ap.d_hdr; G0.A.u_chg = ap.d_u_chg; G0.A.u_fill = ap.d_u_fill;
       if (!rt_h2d(G0dev, &G0, sizeof(MergeDev), ctx->stream)) return false;
 #ifdef AMH_EMU
-      amh_launch_mg(k, &G0, n, (void*)ctx->stream);
+      launch_mg_timed(ctx, k, &G0, n);
 #else
-      amh_launch_mg(k, G0dev, n, (void*)ctx->stream);
+      launch_mg_timed(ctx, k, G0dev, n);
 #endif
       return true;
     };
@@ -2546,10 +2566,10 @@ extern "C" int amh_ctx_set_profiling(amh_ctx* ctx, int enable) {
   ctx->profiling = enable != 0;
   return AMH_SUCCESS;
 }
-extern "C" int amh_ctx_num_kernels(void) { return AK_NUM; }
-extern "C" const char* amh_ctx_kernel_name(int k) { return (k >= 0 && k < AK_NUM) ? AMH_KERNEL_NAMES[k] : nullptr; }
+extern "C" int amh_ctx_num_kernels(void) { return AK_NUM + MK_NUM; }
+extern "C" const char* amh_ctx_kernel_name(int k) { return (k >= 0 && k < AK_NUM) ? AMH_KERNEL_NAMES[k] : (k >= AK_NUM && k < AK_NUM + MK_NUM) ? MK_KERNEL_NAMES[k - AK_NUM] : nullptr; }
 extern "C" int amh_ctx_kernel_time(amh_ctx* ctx, int k, double* ms, uint64_t* launches) {
-  if (!ctx || k < 0 || k >= AK_NUM) return AMH_ERR_INVALID_ARG;
+  if (!ctx || k < 0 || k >= AK_NUM + MK_NUM) return AMH_ERR_INVALID_ARG;
   if (ms) *ms = ctx->kernel_ms[k];
   if (launches) *launches = ctx->kernel_calls[k];
   return AMH_SUCCESS;
@@ -2562,6 +2582,6 @@ extern "C" int amh_ctx_pool_bytes(const amh_ctx* ctx, uint64_t* live, uint64_t* 
 }
 extern "C" int amh_ctx_reset_profile(amh_ctx* ctx) {
   if (!ctx) return AMH_ERR_INVALID_ARG;
-  for (int k = 0; k < AK_NUM; k++) { ctx->kernel_ms[k] = 0; ctx->kernel_calls[k] = 0; }
+  for (int k = 0; k < AK_NUM + MK_NUM; k++) { ctx->kernel_ms[k] = 0; ctx->kernel_calls[k] = 0; }
   return AMH_SUCCESS;
 }

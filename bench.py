@@ -92,31 +92,52 @@ def column_bytes(eng, batch, n_docs):
 
 
 def bench_merge(args, eng, rank, world, dist, torch, red_dev):
-    """configs[2]: `--docs` text documents per GPU (default there: 10k), each a 1,000-character base + `--replicas`
-    divergent replicas of 5,000 edits (70 % inserts in runs, 30 % deletes).  One step = load all replicas (one
-    batch per replica index) and merge replicas 1..R-1 into replica 0, document by document."""
+    """configs[2] (the headline line): `--docs` text documents per GPU (default 10,000), each a 1,000-character base +
+    `--replicas` divergent replicas of 5,000 edits (70 % inserts in runs, 30 % deletes).  One step = every document's
+    replicas loaded (one batch per replica index) and replicas 1..R-1 merged into replica 0.  All encoded replicas are
+    resident in HBM before the timed region; a step streams them through the pipeline `--slice` documents at a time
+    (the derived arrays of a slice are released before the next one starts), so the working set stays well inside one
+    GPU's HBM while the step still covers all `--docs` documents."""
     import ctypes as C
     R = args.replicas
     threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), 32))
+    n_slices = max(1, (args.docs + args.slice - 1) // args.slice)
+    bounds = [(k * args.docs // n_slices, (k + 1) * args.docs // n_slices) for k in range(n_slices)]
     t0 = time.time()
-    blob, offs = eng.gen_text_docs(0xB070 + rank * args.docs, args.docs, R, 1000, 5000, 500, threads)
+    staged, enc_bytes, sample = [], 0, None
+    for k, (lo, hi) in enumerate(bounds):   # generated and staged slice by slice: the host never holds more than one slice of inputs
+        blob, offs = eng.gen_text_docs(0xB070 + rank * args.docs + lo, hi - lo, R, 1000, 5000, 500, threads)
+        reps = [[blob[offs[i * R + r]:offs[i * R + r + 1]] for i in range(hi - lo)] for r in range(R)]
+        staged.append([eng.stage(reps[r]) for r in range(R)])
+        enc_bytes += len(blob)
+        if k == 0:
+            sample = [[reps[r][i] for r in range(R)] for i in range(min(hi - lo, 256))]
+        del blob, reps
     t_gen = time.time() - t0
-    reps = [[blob[offs[i * R + r]:offs[i * R + r + 1]] for i in range(args.docs)] for r in range(R)]
-    staged = [eng.stage(reps[r]) for r in range(R)]
-    pairs = [(i, i) for i in range(args.docs)]
 
-    def step():
-        batches = [eng.load_staged(s) for s in staged]
-        t_load = time.perf_counter()
-        if args.sequential_merges:
-            for r in range(1, R):
-                rc = batches[0].merge(batches[r], pairs)
+    def step(keep_stats=False):
+        ops = 0
+        stats = []
+        for k, (lo, hi) in enumerate(bounds):
+            ids = list(range(hi - lo))
+            batches = [eng.load_staged(s) for s in staged[k]]
+            if keep_stats:   # per-batch counts of the source loads for the byte model (before the merge replaces batch 0)
+                stats.append([(b.stats(), column_bytes(eng, b, hi - lo)) for b in batches])
+            if args.sequential_merges:
+                for r in range(1, R):
+                    rc = batches[0].merge(batches[r], [(i, i) for i in ids])
+                    assert rc == 0, rc
+            else:   # the same result (history order included) with one pass over the rows
+                rc = batches[0].merge_many(batches[1:], ids, [ids] * (R - 1))
                 assert rc == 0, rc
-        else:   # the same result (history order included) with one pass over the rows
-            ids = list(range(args.docs))
-            rc = batches[0].merge_many(batches[1:], ids, [ids] * (R - 1))
-            assert rc == 0, rc
-        return batches, t_load
+            st = batches[0].stats()
+            assert st["n_ok"] == hi - lo
+            ops += st["ops_loaded"]
+            if keep_stats:
+                stats[-1].append((st, column_bytes(eng, batches[0], hi - lo)))
+            for b in batches:
+                b.close()
+        return ops, stats
 
     def barrier():
         if dist is not None:
@@ -127,15 +148,143 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
         step()
     barrier()
     t0 = time.perf_counter()
-    load_s = 0.0
     for _ in range(args.steps):
-        ts = time.perf_counter()
-        batches, tl = step()
-        load_s += tl - ts
+        ops, _ = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    st = batches[0].stats()
-    assert st["n_ok"] == args.docs
+    # one more, profiled step: HIP events around every kernel launch on the pipeline's own stream
+    eng.set_profiling(True)
+    eng.reset_profile()
+    _, stats = step(keep_stats=True)
+    eng.set_profiling(False)
+    kt = eng.kernel_times()
+    tot = torch.tensor([float(elapsed), float(ops)], dtype=torch.float64, device=red_dev)
+    if dist is not None:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed_max, ops_all = float(tmax[0]), float(tot[1])
+    else:
+        elapsed_max, ops_all = elapsed, float(ops)
+    if rank == 0:
+        # bytes every load-pipeline kernel must move, summed over the document batches of a step: R source loads and
+        # the re-verification load of the merged documents per slice (the kernels of the change chunks handed to the
+        # apply path run under the same names and are in the times but not in the bytes: the fraction is a lower bound)
+        model = {}
+        for sl in stats:
+            for st, cols in sl:
+                st = dict(st)
+                st["actors"] = 2 * st["n_docs"]
+                st["actor_map"] = 2 * st["changes"]
+                for kname, v in algorithmic_bytes(st, cols).items():
+                    model[kname] = model.get(kname, 0) + v
+        OVERLAPPED = ("sha_doc", "visible")
+        ranked = sorted((k for k in kt if kt[k][1] > 0 and k not in OVERLAPPED and k in model), key=lambda k: -kt[k][0])
+        dom = ranked[0]
+        dom_ms, dom_calls = kt[dom]
+        achieved = model[dom] / (dom_ms * 1e-3) / 1e9
+        total_kernel_ms = sum(v[0] for k, v in kt.items() if k not in OVERLAPPED)
+        kernels = {k: {"ms_total": round(v[0], 3), "launches": v[1],
+                       "GBps": round(model[k] / (v[0] * 1e-3) / 1e9, 2) if k in model and v[0] > 0 else None,
+                       **({"overlapped": True} if k in OVERLAPPED else {})}
+                   for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0]) if v[1] > 0}
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            if tj.get("workload") == "merge":
+                names = {"decode_ops": ["g_decode_seg(BatchDev)"], "count": ["g_count_seg(BatchDev)"],
+                         "encode_size": ["void g_encode_seg<false>(BatchDev)"], "encode_store": ["void g_encode_seg<true>(BatchDev)"]}.get(dom, [f"g_k_{dom}(BatchDev, unsigned int)"])
+                vals = [tj["kernels"][nm]["traffic"] * tj["kernels"][nm]["launches"] for nm in names if nm in tj["kernels"]]
+                traffic = sum(vals) / dom_calls if vals else None
+        except Exception:
+            traffic = None
+        out = {"metric": "ops loaded+merged/sec (node)", "value": ops_all * args.steps / elapsed_max, "unit": "ops/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64", "data": "synthetic",
+               "config": {"workload": f"configs[2]: {args.docs} text documents x {R} divergent replicas of 5k concurrent inserts/deletes per GPU, load {R} + merge {R - 1}",
+                          "docs_per_gpu": args.docs, "replicas": R, "ops_per_merged_doc": ops / args.docs, "encoded_bytes_per_gpu": enc_bytes,
+                          "slices_per_step": n_slices, "docs_per_slice": args.slice, "sharding": f"documents x{world} (replicas of a document co-located)",
+                          "merge_call": "sequential amh_merge_batch" if args.sequential_merges else "amh_merge_many", "gen_s": round(t_gen, 2),
+                          "note": "ops counted once per merged document; every merged document is re-derived and re-verified (change hashes, heads) before it replaces the old one"},
+               "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                            "traffic": traffic, "algorithmic_bytes_per_launch": model[dom] / dom_calls, "launch_ms": dom_ms / dom_calls,
+                            "launches_per_step": dom_calls, "kernel_ms_total": total_kernel_ms},
+               "kernels": kernels}
+        if not args.no_cpu and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as o   # CPU oracle: the reported baseline only (never the measured path)
+            from concurrent.futures import ThreadPoolExecutor
+            cores = max(1, min(threads, 16))
+
+            def one(docs):   # ctypes releases the GIL inside the oracle calls: the threads run in parallel
+                d = o.Doc.load(docs[0])
+                for r in range(1, R):
+                    d.merge(o.Doc.load(docs[r]))
+                return d.num_ops()
+
+            t0 = time.perf_counter()
+            n_done, n_ops = 0, 0
+            with ThreadPoolExecutor(cores) as ex:
+                for lo in range(0, len(sample), cores):
+                    n_ops += sum(ex.map(one, sample[lo:lo + cores]))
+                    n_done += len(sample[lo:lo + cores])
+                    if time.perf_counter() - t0 > 20.0:
+                        break
+            secs = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": n_ops / secs, "unit": "ops/s", "cores": cores, "kind": "port",
+                                   "sample": f"first {n_done} documents of the same batch, load {R} + merge {R - 1}, one document per thread (CPU restatement in "
+                                             f"oracle/ with a plain O(n) sequence insert per op: a correctness oracle, not the Rust reference: no toolchain)"}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_bigdoc(args, eng, rank, world, dist, torch, red_dev):
+    """configs[3]: ONE text document of `--ops` ops (default 10M) in 1,000 changes by `--replicas` actors (default 16):
+    the actors' divergent histories are generated as replicas and merged into one document (untimed; the engine's own
+    merge, re-verified).  One step = load of that document with its bytes resident in HBM.  Does not shard: with N > 1
+    every rank loads a replica of the same document ("replicas only")."""
+    R = args.replicas
+    per_change = max(1, args.ops // 1000)
+    threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), 32))
+    t0 = time.time()
+    blob, offs = eng.gen_text_docs(0xB16D0C, 1, R, 1000, args.ops // R, per_change, threads)
+    reps = [blob[offs[r]:offs[r + 1]] for r in range(R)]
+    if R > 1:
+        bs = [eng.load_batch([x]) for x in reps]
+        rc = bs[0].merge_many(bs[1:], [0], [[0]] * (R - 1))
+        assert rc == 0, rc
+        doc = bs[0].save_all(deflate=False)[0]
+        for b in bs:
+            b.close()
+    else:
+        doc = reps[0]
+    t_gen = time.time() - t0
+    staged = eng.stage([doc])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.load_staged(staged).close()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        b = eng.load_staged(staged)
+        b.close()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.set_profiling(True)
+    eng.reset_profile()
+    batch = eng.load_staged(staged)
+    eng.set_profiling(False)
+    kt = eng.kernel_times()
+    batch.check(0)
+    st = batch.stats()
+    resaved = batch.save_all(deflate=False)[0]
+    assert resaved == doc, "save(load(x)) != x"
     ops = st["ops_loaded"]
     tot = torch.tensor([float(elapsed), float(ops)], dtype=torch.float64, device=red_dev)
     if dist is not None:
@@ -146,29 +295,35 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
     else:
         elapsed_max, ops_all = elapsed, float(ops)
     if rank == 0:
+        st["actors"] = R + 1
+        st["actor_map"] = (R + 1) * st["changes"]
+        model = algorithmic_bytes(st, column_bytes(eng, batch, 1))
+        OVERLAPPED = ("sha_doc", "visible")
+        dom = max((k for k in kt if kt[k][1] > 0 and k not in OVERLAPPED and k in model), key=lambda k: kt[k][0])
+        dom_ms, dom_calls = kt[dom]
+        achieved = model[dom] / (dom_ms * 1e-3) / 1e9
         out = {"metric": "ops loaded+merged/sec (node)", "value": ops_all * args.steps / elapsed_max, "unit": "ops/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64", "data": "synthetic",
-               "config": {"workload": f"configs[2]: text documents x {R} divergent replicas of 5k edits, load {R} + merge {R - 1}",
-                          "docs_per_gpu": args.docs, "ops_per_merged_doc": ops / args.docs, "gen_s": round(t_gen, 2),
-                          "load_ms_per_step": load_s / args.steps * 1e3, "merge_ms_per_step": (elapsed - load_s) / args.steps * 1e3,
-                          "merge_call": "sequential amh_merge_batch" if args.sequential_merges else "amh_merge_many",
-                          "note": "merge round-trips the merged documents through the host (save bytes -> reload); ops counted once per merged document"}}
+               "config": {"workload": f"configs[3]: one text document of {ops} ops, {st['changes']} changes, {R} concurrent actors (+ the base author): load",
+                          "op_rows": st["op_rows"], "encoded_bytes": len(doc), "gen_s": round(t_gen, 1), "sharding": "replicas only",
+                          "checks": "every change re-derived and hashed, heads verified, save(load(x)) == x",
+                          "note": "chunk and change SHA-256 of a document this size run on host threads beside the device pipeline (one message is a serial chain)"},
+               "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                            "traffic": None, "algorithmic_bytes_per_launch": model[dom] / dom_calls, "launch_ms": dom_ms / dom_calls,
+                            "kernel_ms_total": sum(v[0] for k, v in kt.items() if k not in OVERLAPPED)},
+               "kernels": {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0]) if v[1] > 0}}
         if not args.no_cpu and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_lib as o
-            ns = min(args.docs, 64)
+            import oracle_lib as o   # CPU oracle: the reported baseline only (never the measured path)
+            sample_ops = min(args.ops, 2000000)   # bounded: the oracle loads ~2e5 ops/s
+            sb, so = eng.gen_text_docs(0xB16D0C, 1, 1, 1000, sample_ops, max(1, sample_ops // 1000), threads)
             t0 = time.perf_counter()
-            n_ops = 0
-            for i in range(ns):
-                d = o.Doc.load(reps[0][i])
-                for r in range(1, R):
-                    d.merge(o.Doc.load(reps[r][i]))
-                n_ops += d.num_ops()
+            d = o.Doc.load(sb[so[0]:so[1]])
             secs = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": n_ops / secs, "unit": "ops/s", "cores": 1, "kind": "port",
-                                   "sample": f"first {ns} documents, load {R} + merge {R - 1} on one thread (CPU restatement in oracle/ with a plain O(n) "
-                                             f"sequence insert per op: a correctness oracle, not the Rust reference and not indicative of its speed)"}
+            out["cpu_baseline"] = {"value": d.num_ops() / secs, "unit": "ops/s", "cores": 1, "kind": "port",
+                                   "sample": f"one text document of {d.num_ops()} ops by one actor, same generator (CPU restatement in oracle/, not the Rust reference: no toolchain); "
+                                             f"a single document does not parallelise over host threads in the reference either"}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
@@ -316,18 +471,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--docs", type=int, default=None, help="documents per GPU (default: 100k for load = configs[1]; 4000 for merge, "
-                    "a 40 % share of configs[2]'s 10k documents: the 8 source batches, the merged rows and the reloaded batch of all 10k "
-                    "do not fit one GPU's HBM together)")
+    ap.add_argument("--docs", type=int, default=None, help="documents per GPU (default: 10k for merge = configs[2]; 100k for load = configs[1])")
     ap.add_argument("--cpu-sample", type=int, default=16000, help="documents of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", default="load", choices=["load", "merge", "sync", "apply"],
-                    help="load = configs[1] (the headline line); merge = configs[2]: text documents x 8 divergent replicas, load 8 + merge 7")
+    ap.add_argument("--workload", default="merge", choices=["merge", "load", "bigdoc", "sync", "apply"],
+                    help="merge = configs[2] (the headline line: BASELINE.json quotes the metric on it): 10k text documents x 8 divergent replicas, "
+                         "load 8 + merge 7; load = configs[1]: 100k JSON-map documents; bigdoc = configs[3]: one 10M-op text document")
+    ap.add_argument("--slice", type=int, default=2500, help="merge workload: documents streamed through the pipeline at a time")
+    ap.add_argument("--ops", type=int, default=10000000, help="bigdoc workload: ops of the document")
     ap.add_argument("--replicas", type=int, default=8)
     ap.add_argument("--sequential-merges", action="store_true", help="merge workload: R-1 amh_merge_batch calls instead of one amh_merge_many")
     args = ap.parse_args()
     if args.docs is None:
-        args.docs = {"load": 100000, "merge": 4000, "sync": 125000, "apply": 100000}[args.workload]
+        args.docs = {"load": 100000, "merge": 10000, "sync": 125000, "apply": 100000, "bigdoc": 1}[args.workload]
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -353,6 +509,10 @@ def main():
     eng = Engine(gpu=local_rank)
     if args.workload == "merge":
         return bench_merge(args, eng, rank, world, dist, torch, red_dev)
+    if args.workload == "bigdoc":
+        if args.replicas == 8:
+            args.replicas = 16
+        return bench_bigdoc(args, eng, rank, world, dist, torch, red_dev)
     if args.workload == "sync":
         return bench_sync(args, eng, rank, world, dist, torch, red_dev)
     if args.workload == "apply":
