@@ -5,6 +5,7 @@ get_changes :1306, hydrate :1415) over batches of documents.
 There is no CPU fallback: if the HIP library is missing, importing the engine raises."""
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libautomerge_hip.so")
@@ -106,7 +107,32 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback for the engine.")
+    _share_torch_hip_runtime()
     return bind(C.CDLL(path))
+
+
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  The PyTorch ROCm wheel carries its own libamdhip64.so.7 / libhsa-runtime64.so.1; if
+    this library is loaded first it pulls in /opt/rocm's copies, and a later `import torch` in the same process then
+    finds no GPU.  Loading the wheel's copies first (same sonames, so this library's DT_NEEDED entries bind to them) makes
+    the order of imports irrelevant.  torch itself is not imported; without a torch wheel nothing happens."""
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        cand = os.path.join(libdir, name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
 
 
 class AutomergeError(Exception):

@@ -312,6 +312,41 @@ def test_edit_trace(engine, golden_dir):
     et.check_engine(engine, golden_dir)
 
 
+def test_million_op_documents(engine):
+    """BASELINE.json configs[3] at a size the oracle still loads in seconds: one text document of 1M ops in ~1000
+    changes (columns of megabytes: the wave-per-column forms, host-side SHA of large chunks), and a 4-actor document of
+    1M ops merged on the device.  Change hashes, heads, the text, and the re-saved bytes against the oracle."""
+    import hashlib
+    import oracle_lib as o
+    blob, offs = engine.gen_text_docs(0xB16, 1, 1, 1000, 1000000, 1000, 8)
+    doc = bytes(blob[offs[0]:offs[1]])
+    batch = engine.load_batch([doc])
+    batch.check(0)
+    assert batch.stats()["ops_loaded"] >= 1000000
+    ref = o.Doc.load(doc)
+    assert [c["hash"] for c in batch.get_changes(0)] == [c["hash"] for c in ref.changes()]
+    assert batch.get_heads(0) == ref.get_heads() and batch.max_op(0) == ref.max_op()
+    mine, theirs = batch.hydrate_json(0), ref.hydrate_json()
+    assert hashlib.sha256(mine.encode()).digest() == hashlib.sha256(theirs.encode()).digest()
+    assert batch.save_all(deflate=False)[0] == ref.save(deflate=False) == doc
+    batch.close()
+    # four divergent replicas of 250k ops each, merged in one pass; the oracle loads what the device saved
+    blob, offs = engine.gen_text_docs(0xB17, 1, 4, 1000, 250000, 1000, 8)
+    bs = [engine.load_batch([bytes(blob[offs[r]:offs[r + 1]])]) for r in range(4)]
+    assert bs[0].merge_many(bs[1:], [0], [[0]] * 3) == 0
+    merged = bs[0].save_all(deflate=False)[0]
+    ref = o.Doc.load(merged)
+    assert ref.num_ops() >= 1000000
+    assert [c["hash"] for c in bs[0].get_changes(0)] == [c["hash"] for c in ref.changes()]
+    assert bs[0].get_heads(0) == ref.get_heads()
+    assert len(ref.get_heads()) == 4 and all(b.get_heads(0)[0] in ref.get_heads() for b in bs[1:])
+    assert hashlib.sha256(bs[0].hydrate_json(0).encode()).digest() == hashlib.sha256(ref.hydrate_json().encode()).digest()
+    assert ref.save(deflate=False) == merged
+    again = engine.load_batch([merged])
+    again.check(0)
+    assert again.hydrate_json(0) == bs[0].hydrate_json(0)
+
+
 def test_hash_id_tables(engine, golden_dir, monkeypatch):
     """documents whose op ids are sparse use an open-addressing id table instead of the direct one: force that form"""
     monkeypatch.setenv("AMH_HT_HASH", "1")
