@@ -1626,6 +1626,11 @@ struct ApplyItem {
   bool first_was_doc = true;
   bool one_call = false;       // all buffers together are one apply_changes call (else: one call per buffer)
   std::vector<std::pair<const u8*, size_t>> bufs;   // each: one or more concatenated chunks
+  // change chunks that are already in device memory (merge: the re-derived chunks of the source batches): each entry is
+  // one whole uncompressed change chunk; entries with the same `buf` form one apply_changes call.  They are gathered
+  // into the staged arena by a device copy and never cross to the host as a batch's change bytes.
+  struct DevChunk { const u8* d; u32 len; u32 buf; };
+  std::vector<DevChunk> dev;
 };
 struct HostChunk {
   u32 pair = 0;
@@ -1636,6 +1641,7 @@ struct HostChunk {
   bool from_queue = false;
   bool is_doc = false;         // a document chunk: replaced by the changes it holds before staging
   u32 buf = 0;                 // which of the item's buffers it came from (one buffer = one apply_changes call)
+  const u8* dev = nullptr;     // the chunk lies in device memory (p is set once the staged arena is back on the host)
   u32 staged = AMH_NULL32;     // index in U
 };
 static bool host_uleb(const u8* p, size_t& pos, size_t end, u64& out) {
@@ -1717,6 +1723,11 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
         if (!items[p].one_call) bi++;
         if (out.size() > before && out.back().bad) break;   // nothing behind a bad position is looked at
       }
+      for (auto& dc : items[p].dev) {
+        HostChunk hc;
+        hc.pair = p; hc.dev = dc.d; hc.len = dc.len; hc.buf = bi + dc.buf;
+        out.push_back(std::move(hc));
+      }
       auto qit = dst->queue.find(items[p].doc);
       if (qit != dst->queue.end())
         for (auto& qb : qit->second) {
@@ -1788,7 +1799,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     }
   }
   pc_base[P] = (u32)chunks.size();
-  for (auto& hc : chunks) if (!hc.p && !hc.bad) hc.p = hc.owned.data();
+  for (auto& hc : chunks) if (!hc.p && !hc.bad && !hc.dev) hc.p = hc.owned.data();
   // ---- stage the good ones -----------------------------------------------------------------------
   std::unique_ptr<amh_batch, void (*)(amh_batch*)> holder(new amh_batch(), amh_batch_free);
   amh_batch* hb = holder.get();
@@ -1830,9 +1841,19 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     memset(h_arena.data() + off, 0, 256);
     host_parallel_for((u32)staged_of.size(), [&](u32 u) {   // chunk bytes + the alignment gap behind them
       u64 o0 = doc_off[2 * (size_t)u], o1 = doc_off[2 * (size_t)u + 1], next = (o1 + 15) & ~(u64)15;
-      memcpy(h_arena.data() + o0, chunks[staged_of[u]].p, chunks[staged_of[u]].len);
+      HostChunk& hc = chunks[staged_of[u]];
+      if (hc.dev) { hc.p = h_arena.data() + o0; return; }   // filled by the copy back from the device arena below
+      memcpy(h_arena.data() + o0, hc.p, hc.len);
       memset(h_arena.data() + o1, 0, (size_t)(next - o1));
     });
+  }
+  std::vector<u64> seg_src, seg_dst;
+  std::vector<u32> seg_len;
+  size_t n_host_staged = 0;
+  for (u32 u = 0; u < staged_of.size(); u++) {
+    const HostChunk& hc = chunks[staged_of[u]];
+    if (!hc.dev) { n_host_staged++; continue; }
+    seg_src.push_back((u64)(uintptr_t)hc.dev); seg_len.push_back((u32)hc.len); seg_dst.push_back(doc_off[2 * (size_t)u]);
   }
   u32 NCH = (u32)staged_of.size();
   ap.n_chunks = NCH;
@@ -1861,7 +1882,25 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     G0dev = (MergeDev*)balloc<u8>(hb, sizeof(MergeDev), &ok);
     if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
     U.arena = d_arena; U.doc_off = d_off;
-    if (!rt_h2d(d_arena, h_arena.data(), h_arena.size(), ctx->stream) || !rt_h2d(d_off, doc_off.data(), doc_off.size() * sizeof(u64), ctx->stream)) return faild("H2D copy failed");
+    if (!rt_h2d(d_off, doc_off.data(), doc_off.size() * sizeof(u64), ctx->stream)) return faild("H2D copy failed");
+    if (n_host_staged || seg_src.empty()) { if (!rt_h2d(d_arena, h_arena.data(), h_arena.size(), ctx->stream)) return faild("H2D copy failed"); }
+    else rt_memset(d_arena, 0, h_arena.size(), ctx->stream);   // alignment gaps and the tail read as zero
+    if (!seg_src.empty()) {
+      // device-resident chunks: gathered into the arena on the device; the host's copy of the arena (actor ids and
+      // dependency hashes are read from it when the decisions are made) comes back on the side stream while the
+      // chunks are being decoded
+      u32 ns = (u32)seg_src.size();
+      u64* d_src = balloc<u64>(hb, ns + 1, &ok); u64* d_dst = balloc<u64>(hb, ns + 1, &ok); u32* d_len = balloc<u32>(hb, ns + 1, &ok);
+      if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+      if (!rt_h2d(d_src, seg_src.data(), ns * sizeof(u64), ctx->stream) || !rt_h2d(d_dst, seg_dst.data(), ns * sizeof(u64), ctx->stream) ||
+          !rt_h2d(d_len, seg_len.data(), ns * sizeof(u32), ctx->stream))
+        return faild("H2D copy failed");
+      amh_copy_segments(d_src, d_len, d_dst, d_arena, ns, (void*)ctx->stream);
+      rt_event_record(&ctx->ev_fork, ctx->stream);
+      rt_stream_wait(ctx->side, &ctx->ev_fork);
+      if (!rt_d2h(h_arena.data(), d_arena, h_arena.size(), ctx->side)) return faild("D2H copy failed");
+      rt_event_record(&ctx->ev_join, ctx->side);
+    }
     rt_memset(U.status, 0, (NCH + 1) * sizeof(i32), ctx->stream);
     rt_memset(U.fail_line, 0, (NCH + 1) * sizeof(u32), ctx->stream);
     rt_memset(U.doc_max_op, 0, (NCH + 1) * sizeof(u32), ctx->stream);
@@ -1903,6 +1942,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     rt_memset(U.s_row, 0xFF, NS * 4, ctx->stream);
     launch(ctx, AK_DECODE_OPS, U, NCH * OC_COUNT);
     mg0(MK_AP_VERIFY, tot_rows);
+    if (!seg_src.empty()) rt_stream_wait(ctx->stream, &ctx->ev_join);
     if (!rt_d2h(u_status.data(), U.status, NCH * sizeof(i32), ctx->stream) || !rt_d2h(hdr.data(), ap.d_hdr, NCH * sizeof(ChgHdr), ctx->stream) ||
         !rt_d2h(u_cnt.data(), U.cnt, NCH * sizeof(DocCounts), ctx->stream) ||
         !rt_d2h(u_hash.data(), U.doc_hash, (size_t)NCH * 32, ctx->stream) || !rt_d2h(u_row_base.data(), U.row_base, (NCH + 1) * sizeof(u32), ctx->stream) ||
@@ -2291,18 +2331,12 @@ extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* con
     const amh_batch* sb = srcs[s];
     if (!sb || sb == dst) { set_error(ctx, "amh_merge_many: invalid source batch"); return AMH_ERR_INVALID_ARG; }
     if (!ensure_chg(sb)) { set_error(ctx, "amh_merge_many: D2H copy failed"); return AMH_ERR_DEVICE; }
-    HostView& hv = sb->hv;
-    if (!hv.out_ok) {
-      if (!fetch(sb, hv.out_arena, sb->B.out_arena, (size_t)sb->tot_out) || !rt_sync(ctx->stream)) { set_error(ctx, "amh_merge_many: D2H copy failed"); return AMH_ERR_DEVICE; }
-      hv.out_ok = true;
-    }
   }
   if (!rt_sync(ctx->stream)) return AMH_ERR_DEVICE;
   const HostView& ha = dst->hv;
   u32 P = (u32)n_pairs;
   PhaseTimer pt("amh_merge_many");
   std::vector<ApplyItem> items(P);
-  std::vector<std::vector<std::vector<u8>>> owned(P);
   std::vector<i32> pre_fail(P, 0);
   std::vector<u8> seen_doc(dst->B.n_docs, 0);
   for (u32 p = 0; p < P; p++) {
@@ -2323,6 +2357,7 @@ extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* con
     std::unordered_map<Hash32, u32, Hash32Hasher> known;
     known.reserve((size_t)nca * 2 + 16);
     for (u32 i = 0; i < nca; i++) { Hash32 h; memcpy(h.b, ha.c_hash.data() + (size_t)(cba + i) * 32, 32); known.emplace(h, i); }
+    u32 n_calls = 0;
     for (size_t s = 0; s < n_srcs; s++) {
       u32 b = src_idx[s * n_pairs + p];
       if (b == AMH_NULL32) continue;
@@ -2349,17 +2384,16 @@ extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* con
       }
       std::reverse(added.begin(), added.end());
       if (added.empty()) continue;
-      std::vector<u8> buf;
+      // the added changes of one source = one apply_changes call; their re-derived chunks stay where they are, in the
+      // source batch's device memory
       for (u32 j : added) {
-        const u8* q = hb.out_arena.data() + hb.c_out_off[cbb + j];
-        buf.insert(buf.end(), q, q + hb.c_out_len[cbb + j]);
+        items[p].dev.push_back({sb->B.out_arena + hb.c_out_off[cbb + j], hb.c_out_len[cbb + j], n_calls});
         Hash32 h; memcpy(h.b, bhash(j), 32);
         known.emplace(h, 0);   // every added change applies (the source's history is causally closed)
       }
-      owned[p].push_back(std::move(buf));
+      n_calls++;
     }
-    if (pre_fail[p]) owned[p].clear();
-    for (auto& buf : owned[p]) items[p].bufs.push_back({buf.data(), buf.size()});
+    if (pre_fail[p]) items[p].dev.clear();
     });
   pt.mark("added changes (host)");
   std::vector<i32> results;

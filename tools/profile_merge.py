@@ -8,11 +8,20 @@ blob, offs = e.gen_text_docs(0xB070, N, R, 1000, 5000, 500, 16)
 reps = [[blob[offs[i * R + r]:offs[i * R + r + 1]] for i in range(N)] for r in range(R)]
 staged = [e.stage(reps[r]) for r in range(R)]
 ids = list(range(N))
-def step():
+def step(verbose=False):
+    t0 = time.time()
     bs = [e.load_staged(s) for s in staged]
+    t1 = time.time()
     assert bs[0].merge_many(bs[1:], ids, [ids] * (R - 1)) == 0
+    t2 = time.time()
+    if verbose:
+        print("load x%d %.1f ms, merge_many %.1f ms" % (R, (t1 - t0) * 1e3, (t2 - t1) * 1e3))
     return bs
-step()
+for b in step(): b.close()
+t = time.time(); bs = step(True); print("unprofiled step %.1f ms" % ((time.time() - t) * 1e3))
+t = time.time()
+for b in bs: b.close()
+print("close %.1f ms" % ((time.time() - t) * 1e3))
 e.set_profiling(True); e.reset_profile()
 t = time.time(); bs = step(); dt = time.time() - t
 print("step %.1f ms" % (dt * 1e3))
