@@ -391,12 +391,22 @@ AMH_DEV u32 ap_sort_list(const MergeDev& G, u32 p, u32 head, bool desc) {
   }
   return sorted;
 }
+AMH_DEV bool ap_list_longer(const MergeDev& G, u32 head, u32 limit) {
+  u32 n = 0;
+  for (u32 q = head; q != AMH_NULL32 && n <= limit; q = G.A.o_next[q]) n++;
+  return n > limit;
+}
 AMH_DEV void k_ap_sort_children(const MergeDev& G, u32 r) {
   const ApplyDev& A = G.A;
   u32 hu = A.o_head_upd[r], hi = A.o_head_ins[r];
   if (hu == AMH_NULL32 && hi == AMH_NULL32) return;
   u32 p = G.S.r_doc[r];
   if (p >= G.n_pairs || !mg_pair_ok(G, p)) return;
+#ifndef AMH_EMU
+  // a list of more than AMH_BIG_LIST entries is left to a block (g_big_mg<BIGK_CHILDREN>)
+  if (ap_list_longer(G, hu, AMH_BIG_LIST)) { big_push(G.big_n + BIGK_CHILDREN, G.big_items + 2 * (size_t)BIGK_CHILDREN * G.big_cap, G.big_cap, r, 0); hu = AMH_NULL32; }
+  if (ap_list_longer(G, hi, AMH_BIG_LIST)) { big_push(G.big_n + BIGK_CHILDREN, G.big_items + 2 * (size_t)BIGK_CHILDREN * G.big_cap, G.big_cap, r, 1); hi = AMH_NULL32; }
+#endif
   if (hu != AMH_NULL32 && A.o_next[hu] != AMH_NULL32) A.o_head_upd[r] = ap_sort_list(G, p, hu, false);
   if (hi != AMH_NULL32 && A.o_next[hi] != AMH_NULL32) A.o_head_ins[r] = ap_sort_list(G, p, hi, true);
 }
@@ -429,6 +439,24 @@ AMH_DEV void k_ap_top_place(const MergeDev& G, u32 r) {
   amh_atomic_add(&G.gap_cnt[slot], A.o_tmp[r]);
   A.o_next[r] = amh_atomic_exch(&A.g_head[slot], r);
 }
+// A6e'  gaps shared by more than AMH_BIG_LIST top rows: the list's head row records the gap; a block then sorts its
+//       top rows and leaves, in o_top of each (unused for a top row otherwise), the rows that go in front of it within
+//       the gap (g_big_mg<BIGK_TIES>).  Thread per row of U.
+AMH_DEV void k_ap_tie_find(const MergeDev& G, u32 r) {
+#ifndef AMH_EMU
+  const ApplyDev& A = G.A;
+  if (!ap_row_new(G, r) || A.parent[r] != AMH_NULL32) return;
+  u32 p = G.S.r_doc[r];
+  if (!mg_pair_ok(G, p)) return;
+  u32 g = A.gap[r];
+  if (g == AMH_NULL32) return;
+  u32 slot = G.gap_base[p] + g;
+  if (A.g_head[slot] != r || !ap_list_longer(G, r, AMH_BIG_LIST)) return;
+  big_push(G.big_n + BIGK_TIES, G.big_items + 2 * (size_t)BIGK_TIES * G.big_cap, G.big_cap, slot, p);
+#else
+  (void)G; (void)r;
+#endif
+}
 // A6f  emit: a top row starts behind the new rows of smaller gaps (scanned gap_cnt) and behind the top rows of its
 //      own gap that sort in front of it (with their subtrees); its subtree follows in preorder.  Thread per top row.
 AMH_DEV void k_ap_emit(const MergeDev& G, u32 r) {
@@ -440,6 +468,8 @@ AMH_DEV void k_ap_emit(const MergeDev& G, u32 r) {
   u32 g = A.gap[r];
   const u32* pre = G.gap_cnt + G.gap_base[p];
   u32 k = G.new_idx[S.row_base[p]] + (pre[g] - pre[0]);
+  if (A.o_top[r] != AMH_NULL32) k += A.o_top[r];   // a long list: ranked by g_big_mg<BIGK_TIES>
+  else
   for (u32 m = A.g_head[G.gap_base[p] + g]; m != AMH_NULL32; m = A.o_next[m])
     if (m != r && ap_top_less(G, p, m, r)) k += A.o_tmp[m];
   u32* stack = A.o_stack + k;   // at most weight - 1 entries: the rows this thread emits
@@ -501,6 +531,9 @@ AMH_DEV void k_ap_succ_sort_u(const MergeDev& G, u32 r) {   // ascending lamport
   if (p >= G.n_pairs || !mg_pair_ok(G, p)) return;
   const u32* mb = G.map_b + G.mapb_base[p];
   u32 o = S.r_succ_base[r];
+#ifndef AMH_EMU
+  if (n > AMH_BIG_LIST) { big_push(G.big_n + BIGK_SUCC_U, G.big_items + 2 * (size_t)BIGK_SUCC_U * G.big_cap, G.big_cap, r, p); return; }
+#endif
   for (u32 i = 1; i < n; i++) {
     u32 xa = S.s_actor[o + i], xc = S.s_ctr[o + i];
     u32 j = i;

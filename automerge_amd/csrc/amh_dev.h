@@ -52,6 +52,12 @@ AMH_DEV u64 amh_atomic_cas64(u64* p, u64 cmp, u64 val) {
 }
 AMH_DEV i32 amh_atomic_cas_i32(i32* p, i32 cmp, i32 val) { return atomicCAS(p, cmp, val); }
 #endif
+// a list too long for its thread: recorded for the block-per-list kernels (device build; the emulation sorts in place)
+AMH_DEV void big_push(u32* n, u32* items, u32 cap, u32 a, u32 b) {
+  u32 i = amh_atomic_add(n, 1);
+  if (i < cap) { items[2 * (size_t)i] = a; items[2 * (size_t)i + 1] = b; }
+}
+
 
 // first error wins; any non-zero status makes every later stage skip the document
 AMH_DEV void amh_fail_at(const BatchDev& B, u32 doc, i32 code, u32 line) {

@@ -191,7 +191,7 @@ static const char* const MK_KERNEL_NAMES[MK_NUM] = {
   "mg_new_flag", "mg_pair_counts", "mg_subtree", "mg_gap", "mg_inherit", "mg_extra_cnt", "mg_rows_dst", "mg_rows_new", "mg_succ_dst",
   "mg_succ_new", "mg_succ_extra", "mg_succ_sort", "mg_doc_succ", "mg_changes", "mg_copy_chunks",
   "ap_parse", "ap_count", "ap_verify", "ap_map", "ap_chg_meta", "ap_new_flag", "ap_link", "ap_children", "ap_sort_children", "ap_jump", "ap_weight",
-  "ap_top_place", "ap_emit", "ap_pred_cnt", "ap_succ_fill_u", "ap_succ_sort_u", "ap_succ_fill_d"};
+  "ap_top_place", "ap_emit", "ap_pred_cnt", "ap_succ_fill_u", "ap_succ_sort_u", "ap_succ_fill_d", "ap_ties"};
 // a merge / apply kernel, timed like the others when the context is profiling
 static void launch_mg_timed(amh_ctx* ctx, int k, const MergeDev* G, u32 n) {
   if (ctx->profiling) {
@@ -602,6 +602,10 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   if (!scan_inplace(b, B.j_pred_base, tot_ops, nullptr)) return fail("scan failed");
   launch(ctx, AK_PRED_SLOT_BASE, B, tot_ops);
   launch(ctx, AK_PRED_FILL, B, B.tot_succ);
+  B.big_cap = B.tot_succ / AMH_BIG_LIST + 8;
+  B.big_n = balloc<u32>(b, 4, &ok); B.big_items = balloc<u32>(b, 2 * (size_t)B.big_cap, &ok);
+  if (!ok) return fail("device out of memory");
+  rt_memset(B.big_n, 0, 4 * sizeof(u32), ctx->stream);
   launch(ctx, AK_PRED_SORT, B, T);   // + the actors each op refers to (k_actor_mark), in the same pass over the pred lists
   launch(ctx, AK_ACTOR_RANK, B, B.tot_chg);
   for (int k = 0; k < 12; k++) B.cv[k] = nullptr;   // one interleaved array per column group: obj (2 fields), key (4), misc (2), value (4)
@@ -1241,7 +1245,13 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   G.sub_end = balloc<u32>(mb, NRD, &ok); G.upd_end = balloc<u32>(mb, NRD, &ok); G.stack = balloc<u32>(mb, NRD, &ok);
   G.x_cnt = balloc<u32>(mb, NRD, &ok); G.x_fill = balloc<u32>(mb, NRD, &ok); G.d_to_m = balloc<u32>(mb, NRD, &ok);
   MergeDev* Gdev = (MergeDev*)balloc<u8>(mb, sizeof(MergeDev), &ok);
+  {   // lists too long for one thread (amh_types.h, big_*): a list has more than AMH_BIG_LIST entries, so there are few
+    u64 entries = (u64)DB.tot_rows + DB.tot_succ + 2 * ((u64)SB.tot_rows + SB.tot_succ) + (ap ? 2 * ((u64)ap->U.tot_rows + ap->U.tot_succ) : 0);
+    G.big_cap = (u32)(entries / AMH_BIG_LIST + 64);
+    G.big_n = balloc<u32>(mb, 8, &ok); G.big_items = balloc<u32>(mb, 4 * 2 * (size_t)G.big_cap, &ok);
+  }
   if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+  rt_memset(G.big_n, 0, 8 * sizeof(u32), ctx->stream);
   {
     std::vector<i32> mst(P);
     for (u32 p = 0; p < P; p++) mst[p] = p_status[p];   // documents of pairs that are not merged are skipped by the save kernels
@@ -1323,6 +1333,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
     }
     mg(MK_AP_WEIGHT, nr);
     mg(MK_AP_TOP_PLACE, nr);
+    mg(MK_AP_TIES, nr);
     pt.mark("exec: ap link .. top_place", &ctx->stream);
   } else {
     mg(MK_GAP, SB.tot_rows);

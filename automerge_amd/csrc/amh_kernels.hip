@@ -710,6 +710,44 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
   (void)wide;
 }
 
+// ------------------------------------------------------------------------------------------
+// Lists of more than AMH_BIG_LIST entries (the children of one new element, the top rows of one gap, the succ list
+// of one op, the preds of one op).  The thread-per-item kernels sort what fits one thread and record the rest; here a
+// block takes one recorded list at a time and sorts it with a bitonic network over global memory.  All
+// compare-exchanges put the smaller entry at the lower index, so positions at and beyond n stand for +infinity and
+// are never touched (any n, not only powers of two).  O(n log^2 n / 256) steps per list instead of O(n^2) on one lane.
+// ------------------------------------------------------------------------------------------
+#define BIG_GRID 64u
+template <class Less, class Swap> __device__ void blk_bitonic(u32 n, Less less, Swap swp) {
+  u32 np = 1;
+  while (np < n) np <<= 1;
+  for (u32 k = 2; k <= np; k <<= 1) {
+    for (u32 t = threadIdx.x; t < np / 2; t += AMH_BLOCK) {   // halves of a k-block, mirrored
+      u32 blk = t / (k / 2), off = t % (k / 2);
+      u32 i = blk * k + off, j = blk * k + k - 1 - off;
+      if (j < n && less(j, i)) swp(i, j);
+    }
+    __syncthreads();
+    for (u32 jj = k >> 2; jj > 0; jj >>= 1) {
+      for (u32 t = threadIdx.x; t < np / 2; t += AMH_BLOCK) {
+        u32 i = (t / jj) * 2 * jj + (t % jj), j = i + jj;
+        if (j < n && less(j, i)) swp(i, j);
+      }
+      __syncthreads();
+    }
+  }
+}
+__global__ void __launch_bounds__(AMH_BLOCK) g_big_pred(const BatchDev B) {
+  u32 cnt = *B.big_n;
+  if (cnt > B.big_cap) cnt = B.big_cap;
+  for (u32 w = blockIdx.x; w < cnt; w += gridDim.x) {
+    u32 t = B.big_items[2 * (size_t)w], d = B.big_items[2 * (size_t)w + 1];
+    u64* v = B.pred_ids + B.t_pred_base[t];
+    blk_bitonic(B.t_pred_cnt[t],
+                [&](u32 i, u32 j) { return lamport_cmp(B, d, (u32)(v[i] >> 32), (u32)v[i], (u32)(v[j] >> 32), (u32)v[j]) < 0; },
+                [&](u32 i, u32 j) { u64 x = v[i]; v[i] = v[j]; v[j] = x; });
+  }
+}
 void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
   if (n == 0) return;
   hipStream_t s = (hipStream_t)stream;
@@ -740,6 +778,11 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
     return;
   }
   dim3 grid((n + AMH_BLOCK - 1) / AMH_BLOCK), gridx(amh_xcd_grid(n)), block(AMH_BLOCK);
+  if (k == AK_PRED_SORT) {   // the thread-per-op kernel, then a block per pred list it found too long for one thread
+    hipLaunchKernelGGL(g_k_pred_sort, grid, block, 0, s, B, n);
+    hipLaunchKernelGGL(g_big_pred, dim3(BIG_GRID), block, 0, s, B);
+    return;
+  }
   switch (k) {
 #define LX(id, name) case id: hipLaunchKernelGGL(g_##name, gridx, block, 0, s, B, n); return;
     LX(AK_PLACE, k_place) LX(AK_PRED_FILL, k_pred_fill) LX(AK_SUCC_LINK, k_succ_link) LX(AK_CHANGE_VIEW, k_change_view) LX(AK_PRED_SLOT_BASE, k_pred_slot_base)
@@ -914,6 +957,72 @@ AMH_GLOBAL_MG(k_ap_pred_cnt)
 AMH_GLOBAL_MG(k_ap_succ_fill_u)
 AMH_GLOBAL_MG(k_ap_succ_sort_u)
 AMH_GLOBAL_MG(k_ap_succ_fill_d)
+AMH_GLOBAL_MG(k_ap_tie_find)
+
+template <int KIND> __global__ void __launch_bounds__(AMH_BLOCK) g_big_mg(const MergeDev* Gp) {
+  const MergeDev& G = *Gp;
+  const ApplyDev& A = G.A;
+  __shared__ u32 sh_n, sh_off, sh_part[AMH_BLOCK];
+  u32 cnt = G.big_n[KIND];
+  if (cnt > G.big_cap) cnt = G.big_cap;
+  const u32* items = G.big_items + 2 * (size_t)KIND * G.big_cap;
+  for (u32 w = blockIdx.x; w < cnt; w += gridDim.x) {
+    u32 a = items[2 * (size_t)w], b = items[2 * (size_t)w + 1];
+    if (KIND == BIGK_SUCC_U) {   // a = row of U, b = pair
+      const BatchDev& S = G.S;
+      const u32* mb = G.map_b + G.mapb_base[b];
+      u32 o = S.r_succ_base[a];
+      blk_bitonic(S.r_succ_cnt[a],
+                  [&](u32 i, u32 j) { return mg_lam(S.s_ctr[o + i], mb[S.s_actor[o + i]], S.s_ctr[o + j], mb[S.s_actor[o + j]]) < 0; },
+                  [&](u32 i, u32 j) { u32 x = S.s_ctr[o + i]; S.s_ctr[o + i] = S.s_ctr[o + j]; S.s_ctr[o + j] = x;
+                                      x = S.s_actor[o + i]; S.s_actor[o + i] = S.s_actor[o + j]; S.s_actor[o + j] = x; });
+    } else if (KIND == BIGK_SUCC_M) {   // a = merged row
+      const BatchDev& M = G.M;
+      u32 o = M.r_succ_base[a];
+      blk_bitonic(M.r_succ_cnt[a],
+                  [&](u32 i, u32 j) { return mg_lam(M.s_ctr[o + i], M.s_actor[o + i], M.s_ctr[o + j], M.s_actor[o + j]) < 0; },
+                  [&](u32 i, u32 j) { u32 x = M.s_ctr[o + i]; M.s_ctr[o + i] = M.s_ctr[o + j]; M.s_ctr[o + j] = x;
+                                      x = M.s_actor[o + i]; M.s_actor[o + i] = M.s_actor[o + j]; M.s_actor[o + j] = x; });
+    } else {
+      // linked lists: gathered into a stretch of A.o_stack (unused between k_ap_children and k_ap_emit), sorted there.
+      // BIGK_CHILDREN: a = parent row, b = 0 its updates (ascending id) / 1 its child elements (descending id)
+      // BIGK_TIES: a = gap counter slot, b = pair
+      u32 head = KIND == BIGK_CHILDREN ? (b ? A.o_head_ins[a] : A.o_head_upd[a]) : A.g_head[a];
+      u32 p = KIND == BIGK_CHILDREN ? G.S.r_doc[a] : b;
+      if (threadIdx.x == 0) {
+        u32 n = 0;
+        for (u32 q = head; q != AMH_NULL32; q = A.o_next[q]) n++;
+        u32 off = atomicAdd(&G.big_n[4 + KIND], n);
+        n = 0;
+        for (u32 q = head; q != AMH_NULL32; q = A.o_next[q]) A.o_stack[off + n++] = q;
+        sh_n = n; sh_off = off;
+      }
+      __syncthreads();
+      u32 n = sh_n;
+      u32* v = A.o_stack + sh_off;
+      if (KIND == BIGK_CHILDREN) {
+        blk_bitonic(n, [&](u32 i, u32 j) { int c = ap_id_cmp(G, p, v[i], v[j]); return b ? c > 0 : c < 0; },
+                    [&](u32 i, u32 j) { u32 x = v[i]; v[i] = v[j]; v[j] = x; });
+        for (u32 i = threadIdx.x; i < n; i += AMH_BLOCK) A.o_next[v[i]] = i + 1 < n ? v[i + 1] : AMH_NULL32;
+        if (threadIdx.x == 0) { if (b) A.o_head_ins[a] = v[0]; else A.o_head_upd[a] = v[0]; }
+      } else {
+        blk_bitonic(n, [&](u32 i, u32 j) { return ap_top_less(G, p, v[i], v[j]); },
+                    [&](u32 i, u32 j) { u32 x = v[i]; v[i] = v[j]; v[j] = x; });
+        // rows in front of each top row inside the gap = exclusive prefix sum of the subtree weights in sorted order
+        u32 per = (n + AMH_BLOCK - 1) / AMH_BLOCK, i0 = threadIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+        u32 sum = 0;
+        for (u32 i = i0; i < i1; i++) sum += A.o_tmp[v[i]];
+        sh_part[threadIdx.x] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) { u32 run = 0; for (u32 t = 0; t < AMH_BLOCK; t++) { u32 x = sh_part[t]; sh_part[t] = run; run += x; } }
+        __syncthreads();
+        sum = sh_part[threadIdx.x];
+        for (u32 i = i0; i < i1; i++) { u32 row = v[i]; A.o_top[row] = sum; sum += A.o_tmp[row]; }
+      }
+    }
+    __syncthreads();
+  }
+}
 // wave-per-pair forms of the two merge kernels that are serial per document: the wave streams the
 // rows through LDS with coalesced loads and one lane walks them (no memory round trip per step).
 #define MGS_STACK 2048u
@@ -1006,6 +1115,11 @@ void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream) {
   if (k == MK_COPY_CHUNKS) { hipLaunchKernelGGL(g_mg_copy_chunks_blk, dim3(n), dim3(AMH_BLOCK), 0, s, G); return; }
   dim3 grid((n + AMH_BLOCK - 1) / AMH_BLOCK), block(AMH_BLOCK);
 #define M(id, name) case id: hipLaunchKernelGGL(g_##name, grid, block, 0, s, G, n); break;
+  // the thread-per-item kernel, then a block per list it found too long for one thread
+  if (k == MK_AP_SORT_CHILDREN) { hipLaunchKernelGGL(g_k_ap_sort_children, grid, block, 0, s, G, n); hipLaunchKernelGGL(g_big_mg<BIGK_CHILDREN>, dim3(BIG_GRID), block, 0, s, G); return; }
+  if (k == MK_AP_TIES) { hipLaunchKernelGGL(g_k_ap_tie_find, grid, block, 0, s, G, n); hipLaunchKernelGGL(g_big_mg<BIGK_TIES>, dim3(BIG_GRID), block, 0, s, G); return; }
+  if (k == MK_AP_SUCC_SORT_U) { hipLaunchKernelGGL(g_k_ap_succ_sort_u, grid, block, 0, s, G, n); hipLaunchKernelGGL(g_big_mg<BIGK_SUCC_U>, dim3(BIG_GRID), block, 0, s, G); return; }
+  if (k == MK_SUCC_SORT) { hipLaunchKernelGGL(g_k_mg_succ_sort, grid, block, 0, s, G, n); hipLaunchKernelGGL(g_big_mg<BIGK_SUCC_M>, dim3(BIG_GRID), block, 0, s, G); return; }
   switch (k) {
     M(MK_NEW_FLAG, k_mg_new_flag) M(MK_PAIR_COUNTS, k_mg_pair_counts) M(MK_SUBTREE, k_mg_subtree) M(MK_GAP, k_mg_gap)
     M(MK_INHERIT, k_mg_inherit) M(MK_EXTRA_CNT, k_mg_extra_cnt) M(MK_ROWS_DST, k_mg_rows_dst) M(MK_ROWS_NEW, k_mg_rows_new)

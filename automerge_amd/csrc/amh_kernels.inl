@@ -954,6 +954,10 @@ AMH_DEV void k_pred_sort(const BatchDev& B, u32 t) {
     u32 d = op_doc(B, t);
     if (B.status[d]) return;
     u64* v = B.pred_ids + B.t_pred_base[t];
+#ifndef AMH_EMU
+    if (n > AMH_BIG_LIST) big_push(B.big_n, B.big_items, B.big_cap, t, d);   // sorted by a block afterwards (g_big_pred)
+    else
+#endif
     for (u32 i = 1; i < n; i++) {
       u64 x = v[i];
       u32 j = i;

@@ -294,6 +294,9 @@ AMH_DEV void k_mg_succ_sort(const MergeDev& G, u32 r) {   // rows that gained en
   u32 p = G.d_pair[a];
   if (p == AMH_NULL32 || !mg_pair_ok(G, p)) return;
   u32 m = G.d_to_m[r], o = G.M.r_succ_base[m], n = G.M.r_succ_cnt[m];
+#ifndef AMH_EMU
+  if (n > AMH_BIG_LIST) { big_push(G.big_n + BIGK_SUCC_M, G.big_items + 2 * (size_t)BIGK_SUCC_M * G.big_cap, G.big_cap, m, p); return; }
+#endif
   for (u32 i = 1; i < n; i++) {
     u32 xa = G.M.s_actor[o + i], xc = G.M.s_ctr[o + i];
     u32 j = i;

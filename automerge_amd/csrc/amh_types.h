@@ -183,6 +183,11 @@ struct BatchDev {
   u32* sync_off;                 // [n_docs + 1] record offsets of the sync summaries
   u8* sync_out;
   u32 sync_cap;                  // 0 = sync_out holds every record; else its capacity: records that end beyond it are not written
+  // lists too long for the thread that owns them (more than AMH_BIG_LIST entries): the thread-per-item kernel records
+  // them here and a block per list sorts them afterwards (amh_kernels.hip, g_big_*)
+  u32* big_n;                    // [1] recorded lists
+  u32* big_items;                // [big_cap] op t of a long pred list
+  u32 big_cap;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -252,4 +257,12 @@ struct MergeDev {
   u32* x_cnt;                      // [D.tot_rows] succ entries a dst row gains
   u32* x_fill;                     // [D.tot_rows]
   u32* d_to_m;                     // [D.tot_rows] merged row of a dst row
+  // lists of more than AMH_BIG_LIST entries (children of one new element, top rows sharing a gap, succ lists): recorded
+  // by the thread-per-row kernels, then sorted by a block each (amh_kernels.hip, g_big_mg).  big_n[kind] = lists
+  // recorded, big_n[4 + kind] = scratch taken from A.o_stack; items of kind k start at big_items + 2 * k * big_cap.
+  u32* big_n;                      // [8]
+  u32* big_items;                  // [4 * 2 * big_cap] pairs (a, b)
+  u32 big_cap;
 };
+enum { BIGK_CHILDREN = 0, BIGK_TIES = 1, BIGK_SUCC_U = 2, BIGK_SUCC_M = 3 };
+#define AMH_BIG_LIST 48u

@@ -1,0 +1,30 @@
+"""GPU: shapes that make a per-list step the whole job (tests/adversarial_cases.py) at the sizes where a quadratic or
+one-lane path shows: results against the oracle (change-only load, apply, document load, save), and every phase
+inside a time budget that an O(n^2) step on one lane would miss by an order of magnitude."""
+import pytest
+
+import adversarial_cases as adv
+
+pytestmark = pytest.mark.gpu
+
+BUDGET_S = 2.0
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from automerge_amd import Engine
+    return Engine(gpu=0)
+
+
+@pytest.mark.parametrize("name,args", [
+    ("overwritten_key", (50000,)),              # one map key overwritten 50k times
+    ("new_map_keys", (20000,)),                 # a change-only load of 20k new map keys (one gap)
+    ("head_siblings", (8, 1250)),               # 10k siblings inserted at HEAD by different actors
+    ("typed_run", (5000, 100)),                 # a 5k-character typed run applied as one change
+    ("siblings_behind_one_element", (8, 1250)), # 10k children of one element that arrives in the same call
+    ("counter_increments", (20000,)),           # one op gaining 20k successors
+    ("wide_overwrite", (3000, 4)),              # one op with 3k preds
+])
+def test_adversarial_shape(engine, name, args):
+    chunks = adv.CASES[name](*args)
+    adv.check_case(engine, chunks, budget_s=BUDGET_S)
