@@ -42,7 +42,7 @@ EXPORTS = [
     "amh_changes", "amh_hydrate_json", "amh_doc_max_op", "amh_merge_batch", "amh_apply_changes", "amh_save_batch",
     "amh_sync_summaries", "amh_ctx_set_profiling", "amh_ctx_num_kernels", "amh_ctx_kernel_name", "amh_ctx_kernel_time",
     "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free", "amh_apply_batch", "amh_doc_queue_len", "amh_merge_many", "amh_save_after",
-    "amh_sync_summaries_noalloc", "amh_ctx_pool_bytes",
+    "amh_sync_summaries_noalloc", "amh_ctx_pool_bytes", "amh_ctx_set_limits",
 ]
 
 DOC_ERRORS = {
@@ -84,6 +84,7 @@ def bind(lib):
     lib.amh_ctx_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.amh_ctx_reset_profile.argtypes = [vp]
     lib.amh_ctx_pool_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.amh_ctx_set_limits.argtypes = [vp, C.c_uint64, C.c_uint64]
     lib.amh_gen_map_docs.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                      C.POINTER(BytesOut), C.POINTER(C.POINTER(C.c_uint64))]
     lib.amh_gen_text_docs.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
@@ -471,6 +472,12 @@ class Engine:
     # --- measurement -------------------------------------------------------------------------
     def set_profiling(self, on):
         self.lib.amh_ctx_set_profiling(self.ctx, 1 if on else 0)
+
+    def set_limits(self, max_doc_rows=0, max_batch_bytes=0):
+        """per-document row limit and per-batch byte budget of the derived device arrays (0 = defaults): documents over
+        them fail with AMH_DOC_TOO_LARGE, the rest of their batch loads"""
+        if self.lib.amh_ctx_set_limits(self.ctx, max_doc_rows, max_batch_bytes) != 0:
+            raise ValueError("amh_ctx_set_limits: invalid argument")
 
     def pool_bytes(self):
         """(live, pooled) device bytes of the context's caching allocator"""

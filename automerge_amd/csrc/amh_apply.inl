@@ -81,6 +81,8 @@ AMH_DEV void k_ap_parse(const MergeDev& G, u32 c) {
 // ------------------------------------------------------------------------------------------
 AMH_DEV void k_ap_count(const MergeDev& G, u32 c) {
   const BatchDev& U = G.U;
+  U.cnt[c].n_rows = 0; U.cnt[c].n_succ = 0;
+  U.row_base[c] = 0; U.succ_base[c] = 0;
   if (U.status[c]) return;
   const DocDesc& D = U.desc[c];
   const u8* p = U.arena + D.chunk_off;
@@ -105,7 +107,7 @@ AMH_DEV void k_ap_count(const MergeDev& G, u32 c) {
       if (!rd_uleb_lenient(r.p, r.pos, r.end, nulls)) { amh_fail(U, c, AMH_E_READ_OP); return; }
       if (nulls) { amh_fail(U, c, AMH_E_READ_OP); return; }   // "unexpected null action"
     }
-    if (rows > AMH_MAX_ROWS_PER_DOC) { amh_fail(U, c, AMH_E_TOO_LARGE); return; }
+    if (rows > U.max_doc_rows) { amh_fail(U, c, AMH_E_TOO_LARGE); return; }
   }
   // OpId::new takes a u32 counter (types.rs:502-504)
   if (G.A.hdr[c].start_op + rows > 0xFFFFFFFEull) { amh_fail(U, c, AMH_E_READ_OP); return; }
@@ -115,7 +117,7 @@ AMH_DEV void k_ap_count(const MergeDev& G, u32 c) {
     int rc = rle_next<0>(r, v, aux, isnull);
     if (rc != 0 || isnull) { amh_fail(U, c, AMH_E_READ_OP); return; }
     preds += v;
-    if (v > AMH_MAX_ROWS_PER_DOC || preds > AMH_MAX_ROWS_PER_DOC) { amh_fail(U, c, AMH_E_TOO_LARGE); return; }
+    if (v > U.max_doc_rows || preds > U.max_doc_rows) { amh_fail(U, c, AMH_E_TOO_LARGE); return; }
   }
   U.cnt[c].n_rows = (u32)rows;
   U.cnt[c].n_succ = (u32)preds;

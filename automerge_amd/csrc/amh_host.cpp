@@ -93,6 +93,10 @@ struct amh_ctx {
   u8* stage = nullptr;
   size_t stage_cap = 0;
   bool profiling = false;
+  // limits (amh_ctx_set_limits): a document over the per-document limit, or the largest documents of a batch whose
+  // derived arrays would not fit the byte budget, fail with AMH_DOC_TOO_LARGE and the rest of the batch goes on
+  u32 max_doc_rows = AMH_MAX_ROWS_PER_DOC;
+  u64 max_batch_bytes = 0;   // 0 = what the device has free (plus what the pool holds) when the batch is sized
   double kernel_ms[AK_NUM + MK_NUM] = {0};      // load / save kernels, then the merge / apply kernels
   uint64_t kernel_calls[AK_NUM + MK_NUM] = {0};
   struct Pending { int k; rt_event a, b; };
@@ -437,6 +441,16 @@ static bool big_hash_changes(amh_batch* b, u32 d) {
          rt_sync(ctx->stream);
 }
 
+// bytes of derived arrays a batch with these totals takes on the device through load (rows: the op columns, the
+// change view, the id tables; succ: entries, preds and the delete table; changes: metadata and column lengths), a
+// little on the high side
+static u64 derived_bytes(u64 rows, u64 succ, u64 chg, u64 deps, u64 map) { return rows * 224 + succ * 72 + chg * 420 + deps * 8 + map * 4; }
+static u64 batch_byte_budget(amh_ctx* ctx) {
+  if (ctx->max_batch_bytes) return ctx->max_batch_bytes;
+  size_t free_b = 0, total_b = 0;
+  if (!rt_mem_info(&free_b, &total_b)) return (u64)16 << 30;
+  return ((u64)free_b + ctx->pool.pooled_bytes) / 10 * 9;
+}
 static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts, bool trailing) {
   if (!ctx || !st_c) { set_error(ctx, "invalid argument"); return nullptr; }
   amh_staged* st = const_cast<amh_staged*>(st_c);
@@ -449,6 +463,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   u32 n = st->n_docs;
   B.n_docs = n;
   B.check_heads = opts ? (opts->verify_heads != 0) : 1;
+  B.max_doc_rows = ctx->max_doc_rows;
   B.arena = (const u8*)st->d_arena.p;
   B.doc_off = (const u64*)st->d_doc_off.p;
   bool ok = true;
@@ -503,10 +518,37 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   rt_stream_wait(ctx->stream, &ctx->ev_join);   // k_extract applies the checksum verdicts
   launch(ctx, AK_EXTRACT, B, n);
   u32 totals[8] = {0};
-  for (int i = 0; i < 8; i++)
-    if (!scan_inplace(b, *bases[i], n, &totals[i])) return fail(std::string("scan failed: ") + rt_last_error());
-  for (int i = 0; i < 8; i++)
-    if (totals[i] == 0xFFFFFFFFu) return fail("batch too large: a derived count exceeds 2^32-1");
+  for (int attempt = 0;; attempt++) {
+    for (int i = 0; i < 8; i++)
+      if (!scan_inplace(b, *bases[i], n, &totals[i])) return fail(std::string("scan failed: ") + rt_last_error());
+    bool overflow = false;
+    for (int i = 0; i < 8; i++) overflow = overflow || totals[i] == 0xFFFFFFFFu;
+    const u64 budget = batch_byte_budget(ctx);
+    if (!overflow && derived_bytes(totals[0], totals[1], totals[2], totals[3], totals[7]) <= budget) break;
+    if (attempt) return fail("batch too large: a derived count exceeds 2^32-1 or the device's memory");
+    // The batch does not fit.  Its largest documents are failed (AMH_DOC_TOO_LARGE) until the rest does, and the counts
+    // are taken again: a few hostile inputs (a 2^28-row run header is a handful of bytes) must not take the other
+    // documents of the batch down with them.
+    launch(ctx, AK_EXTRACT, B, n);   // the per-document counts again (the scans replaced them)
+    std::vector<u32> per[5];
+    u32* src[5] = {B.row_base, B.succ_base, B.chg_base, B.dep_base, B.map_base};
+    std::vector<i32> st(n);
+    std::vector<u32> fl(n);
+    bool cok = rt_d2h(st.data(), B.status, (size_t)n * sizeof(i32), ctx->stream) && rt_d2h(fl.data(), B.fail_line, (size_t)n * sizeof(u32), ctx->stream);
+    for (int i = 0; i < 5; i++) { per[i].resize(n); cok = cok && rt_d2h(per[i].data(), src[i], (size_t)n * sizeof(u32), ctx->stream); }
+    if (!cok || !rt_sync(ctx->stream)) return fail("D2H copy failed");
+    std::vector<std::pair<u64, u32>> weight(n);
+    u64 total = 0;
+    for (u32 d = 0; d < n; d++) { weight[d] = {derived_bytes(per[0][d], per[1][d], per[2][d], per[3][d], per[4][d]), d}; total += weight[d].first; }
+    std::sort(weight.begin(), weight.end(), [](const std::pair<u64, u32>& x, const std::pair<u64, u32>& y) { return x.first > y.first; });
+    for (u32 k = 0; k < n && total > budget; k++) {
+      total -= weight[k].first;
+      st[weight[k].second] = AMH_E_TOO_LARGE; fl[weight[k].second] = __LINE__;
+    }
+    if (!rt_h2d(B.status, st.data(), (size_t)n * sizeof(i32), ctx->stream) || !rt_h2d(B.fail_line, fl.data(), (size_t)n * sizeof(u32), ctx->stream) || !rt_sync(ctx->stream))
+      return fail("H2D copy failed");
+    launch(ctx, AK_EXTRACT, B, n);
+  }
   B.tot_rows = totals[0]; B.tot_succ = totals[1]; B.tot_chg = totals[2]; B.tot_deps = totals[3];
   B.tot_actors = totals[4]; b->tot_ht = totals[5]; B.tot_dt = totals[6]; b->tot_map = totals[7];
   size_t NA = B.tot_actors + 1, NC = B.tot_chg + 2, NR = B.tot_rows + 1, NS = B.tot_succ + 1;
@@ -1492,6 +1534,24 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
 extern "C" int amh_merge_batch(amh_ctx* ctx, amh_batch* dst, const amh_batch* src, const uint32_t* dst_idx, const uint32_t* src_idx, size_t n_pairs) {
   if (!ctx || !dst || !src || dst == src || (n_pairs && (!dst_idx || !src_idx)) || n_pairs >= 0x7FFFFFFFull) { set_error(ctx, "amh_merge_batch: invalid argument"); return AMH_ERR_INVALID_ARG; }
   if (n_pairs == 0) return AMH_SUCCESS;
+  // A document with queued changes (orphans waiting for their dependencies) goes through the apply path, which offers
+  // the queue again once the source's changes are in, as the reference's merge does (automerge.rs:821-825, 938).
+  if (!dst->queue.empty()) {
+    std::vector<u32> qd, qs, rd, rs;
+    for (size_t p = 0; p < n_pairs; p++) {
+      bool queued = dst->queue.count(dst_idx[p]) != 0;
+      (queued ? qd : rd).push_back(dst_idx[p]);
+      (queued ? qs : rs).push_back(src_idx[p]);
+    }
+    if (!qd.empty()) {
+      int rc_q = amh_merge_many(ctx, dst, &src, 1, qd.data(), qs.data(), qd.size());
+      if (rc_q != AMH_SUCCESS && rc_q != AMH_ERR_DOC_FAILED) return rc_q;
+      std::string msg_q = rc_q ? ctx->last_error : std::string();
+      int rc_r = rd.empty() ? AMH_SUCCESS : amh_merge_batch(ctx, dst, src, rd.data(), rs.data(), rd.size());
+      if (rc_r == AMH_SUCCESS && rc_q != AMH_SUCCESS) set_error(ctx, msg_q);
+      return rc_r != AMH_SUCCESS ? rc_r : rc_q;
+    }
+  }
   if (!ensure_chg(dst) || !ensure_chg(src) || !ensure_host_arena(dst->staged) || !ensure_host_arena(src->staged)) { set_error(ctx, "amh_merge_batch: D2H copy failed"); return AMH_ERR_DEVICE; }
   const HostView &ha = dst->hv, &hb = src->hv;
   const BatchDev &DB = dst->B, &SB = src->B;
@@ -1883,6 +1943,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   if (NCH) {
     U.n_docs = NCH;
     U.no_checksum = items[0].mode == APM_STRICT;
+    U.max_doc_rows = ctx->max_doc_rows;
     u8* d_arena = balloc<u8>(hb, h_arena.size(), &ok);
     u64* d_off = balloc<u64>(hb, doc_off.size() + 2, &ok);
     U.status = balloc<i32>(hb, NCH + 1, &ok); U.fail_line = balloc<u32>(hb, NCH + 1, &ok);
@@ -1930,8 +1991,24 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     launch(ctx, AK_SHA_DOC, U, NCH);
     mg0(MK_AP_COUNT, NCH);
     u32 tot_rows = 0, tot_preds = 0;
-    if (!scan_inplace(hb, U.row_base, NCH, &tot_rows) || !scan_inplace(hb, U.succ_base, NCH, &tot_preds)) return faild("scan failed");
-    if (tot_rows >= 0x7FFFFFF0u || tot_preds >= 0x7FFFFFF0u) { set_error(ctx, std::string(who) + ": batch too large"); return AMH_ERR_BATCH_TOO_LARGE; }
+    for (int attempt = 0;; attempt++) {
+      if (!scan_inplace(hb, U.row_base, NCH, &tot_rows) || !scan_inplace(hb, U.succ_base, NCH, &tot_preds)) return faild("scan failed");
+      const u64 budget = batch_byte_budget(ctx);
+      if (tot_rows < 0x7FFFFFF0u && tot_preds < 0x7FFFFFF0u && 2 * derived_bytes(tot_rows, tot_preds, 0, 0, 0) <= budget) break;
+      if (attempt) { set_error(ctx, std::string(who) + ": batch too large"); return AMH_ERR_BATCH_TOO_LARGE; }
+      // the largest chunks are failed (TooLarge) until the rest fits; the counts are taken again (k_ap_count skips them)
+      std::vector<DocCounts> cn(NCH);
+      std::vector<i32> st(NCH);
+      if (!rt_d2h(cn.data(), U.cnt, (size_t)NCH * sizeof(DocCounts), ctx->stream) || !rt_d2h(st.data(), U.status, (size_t)NCH * sizeof(i32), ctx->stream) || !rt_sync(ctx->stream))
+        return faild("D2H copy failed");
+      std::vector<std::pair<u64, u32>> weight(NCH);
+      u64 total = 0;
+      for (u32 c = 0; c < NCH; c++) { weight[c] = {st[c] ? 0 : 2 * derived_bytes(cn[c].n_rows, cn[c].n_succ, 0, 0, 0), c}; total += weight[c].first; }
+      std::sort(weight.begin(), weight.end(), [](const std::pair<u64, u32>& x, const std::pair<u64, u32>& y) { return x.first > y.first; });
+      for (u32 k = 0; k < NCH && (total > budget || total / 448 >= 0x7FFFFFF0ull); k++) { total -= weight[k].first; st[weight[k].second] = AMH_E_TOO_LARGE; }
+      if (!rt_h2d(U.status, st.data(), (size_t)NCH * sizeof(i32), ctx->stream) || !rt_sync(ctx->stream)) return faild("H2D copy failed");
+      mg0(MK_AP_COUNT, NCH);
+    }
     U.tot_rows = tot_rows; U.tot_succ = tot_preds;
     size_t NR = (size_t)tot_rows + 2, NS = (size_t)tot_preds + 2;
     u32** rcols[] = {&U.r_id_actor, &U.r_id_ctr, &U.r_obj_actor, &U.r_obj_ctr, &U.r_key_actor, &U.r_key_ctr, &U.r_key_off, &U.r_key_len,
@@ -2606,6 +2683,12 @@ extern "C" void amh_ctx_destroy(amh_ctx* ctx) {
   delete ctx;
 }
 extern "C" const char* amh_last_error(const amh_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_last_error.c_str(); }
+extern "C" int amh_ctx_set_limits(amh_ctx* ctx, uint64_t max_doc_rows, uint64_t max_batch_bytes) {
+  if (!ctx || max_doc_rows > AMH_MAX_ROWS_PER_DOC) return AMH_ERR_INVALID_ARG;
+  ctx->max_doc_rows = max_doc_rows ? (u32)max_doc_rows : AMH_MAX_ROWS_PER_DOC;
+  ctx->max_batch_bytes = max_batch_bytes;
+  return AMH_SUCCESS;
+}
 extern "C" int amh_ctx_set_profiling(amh_ctx* ctx, int enable) {
   if (!ctx) return AMH_ERR_INVALID_ARG;
   ctx->profiling = enable != 0;

@@ -327,7 +327,7 @@ AMH_DEV void k_count(const BatchDev& B, u32 d) {
         if (!rd_uleb_lenient(r.p, r.pos, r.end, nulls)) { amh_fail(B, d, AMH_E_READ_OP); return; }
         if (nulls) { amh_fail(B, d, AMH_E_READ_OP); return; }  // a null id is "unexpected null" (opid.rs:114-117)
       }
-      if (rows > AMH_MAX_ROWS_PER_DOC) { amh_fail(B, d, AMH_E_TOO_LARGE); return; }
+      if (rows > B.max_doc_rows) { amh_fail(B, d, AMH_E_TOO_LARGE); return; }
     }
     C.n_rows = (u32)rows;
     rle_init(r, p, D.ocol[OC_SUCC_NUM].off, D.ocol[OC_SUCC_NUM].len);
@@ -336,7 +336,7 @@ AMH_DEV void k_count(const BatchDev& B, u32 d) {
       int rc = rle_next<0>(r, v, aux, isnull);
       if (rc != 0 || isnull) { amh_fail(B, d, AMH_E_READ_OP); return; }
       succ += v;
-      if (v > AMH_MAX_ROWS_PER_DOC || succ > AMH_MAX_ROWS_PER_DOC) { amh_fail(B, d, AMH_E_TOO_LARGE); return; }
+      if (v > B.max_doc_rows || succ > B.max_doc_rows) { amh_fail(B, d, AMH_E_TOO_LARGE); return; }
     }
     C.n_succ = (u32)succ;
   }
@@ -353,7 +353,7 @@ AMH_DEV void k_count(const BatchDev& B, u32 d) {
       rc = rle_next<0>(dn, v, aux, isnull);
       if (rc != 0 || isnull) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
       deps += v;
-      if (chg > AMH_MAX_ROWS_PER_DOC || v > AMH_MAX_ROWS_PER_DOC || deps > AMH_MAX_ROWS_PER_DOC) { amh_fail(B, d, AMH_E_TOO_LARGE); return; }
+      if (chg > B.max_doc_rows || v > B.max_doc_rows || deps > B.max_doc_rows) { amh_fail(B, d, AMH_E_TOO_LARGE); return; }
     }
     C.n_chg = (u32)chg;
     C.n_deps = (u32)deps;

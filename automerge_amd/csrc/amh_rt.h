@@ -23,6 +23,7 @@ inline bool rt_h2d(void* d, const void* h, size_t n, rt_stream) { if (n) memcpy(
 inline bool rt_d2h(void* h, const void* d, size_t n, rt_stream) { if (n) memcpy(h, d, n); return true; }
 inline bool rt_memset(void* d, int v, size_t n, rt_stream) { if (n) memset(d, v, n); return true; }
 inline bool rt_sync(rt_stream) { return true; }
+inline bool rt_mem_info(size_t* free_b, size_t* total_b) { *free_b = *total_b = (size_t)64 << 30; return true; }
 inline void rt_event_create(rt_event*) {}
 inline void rt_event_destroy(rt_event*) {}
 inline void rt_event_record(rt_event* e, rt_stream) { e->t = std::chrono::steady_clock::now(); }
@@ -56,6 +57,7 @@ inline bool rt_d2h(void* h, const void* d, size_t n, rt_stream s) {
 }
 inline bool rt_memset(void* d, int v, size_t n, rt_stream s) { return n == 0 || hipMemsetAsync(d, v, n, s) == hipSuccess; }
 inline bool rt_sync(rt_stream s) { return hipStreamSynchronize(s) == hipSuccess; }
+inline bool rt_mem_info(size_t* free_b, size_t* total_b) { return hipMemGetInfo(free_b, total_b) == hipSuccess; }
 inline void rt_event_create(rt_event* e) { (void)hipEventCreate(&e->e); }
 inline void rt_event_destroy(rt_event* e) { (void)hipEventDestroy(e->e); }
 inline void rt_event_record(rt_event* e, rt_stream s) { (void)hipEventRecord(e->e, s); }

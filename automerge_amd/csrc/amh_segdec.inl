@@ -545,6 +545,7 @@ template <int MODE> struct SdCountF {
   i32 err;            // what a malformed token is called here (ReadOp / ReadChange)
   u64 sum;            // SD_CNT_SUM: per lane
   bool stopped;       // SD_CNT_UNTIL_NULL: the first null ended the column
+  u64 limit;          // per-document limit on a count (BatchDev::max_doc_rows)
   __device__ __forceinline__ bool wide(const SdStream&) const { return false; }
   template <bool WIDE>
   __device__ __forceinline__ u32 group(SdWave& W, SdStream& S, u32 lane, u32 m, u32 b0, u32 nb, i32& fail) {
@@ -563,7 +564,7 @@ template <int MODE> struct SdCountF {
     } else if (MODE == SD_CNT_SUM) {
       if (!ecode && reach) {
         if (I.isnull) ecode = err;
-        else if ((u64)I.u > AMH_MAX_ROWS_PER_DOC) ecode = AMH_E_TOO_LARGE;
+        else if ((u64)I.u > limit) ecode = AMH_E_TOO_LARGE;
         else sum += (u64)I.u * reach;
       }
     } else {
@@ -591,7 +592,7 @@ __device__ __forceinline__ i32 sd_count_column(const BatchDev& B, u32 d, SdWave&
   S.src = B.arena + B.desc[d].chunk_off;
   S.pos = cr.off; S.end = cr.off + cr.len;
   S.want = want; S.row = 0; S.lit = 0; S.btok = 0; S.acc = 0;
-  SdCountF<MODE> f{err, 0, false};
+  SdCountF<MODE> f{err, 0, false, (u64)B.max_doc_rows};
   out = 0;
   if (want == 0) return 0;
   i32 fail = sd_walk(W, S, lane, f, err);
@@ -599,10 +600,10 @@ __device__ __forceinline__ i32 sd_count_column(const BatchDev& B, u32 d, SdWave&
   if (MODE == SD_CNT_SUM) {
     if (S.row < want) return err;   // fewer values than rows
     u64 tot = sd_bcast64(sd_scan_add64(f.sum), 63);
-    if (tot > AMH_MAX_ROWS_PER_DOC) return AMH_E_TOO_LARGE;
+    if (tot > B.max_doc_rows) return AMH_E_TOO_LARGE;
     out = (u32)tot;
   } else {
-    if (S.row > AMH_MAX_ROWS_PER_DOC) return AMH_E_TOO_LARGE;   // want = the limit + 1
+    if (S.row > B.max_doc_rows) return AMH_E_TOO_LARGE;   // want = the limit + 1
     if (!f.stopped && S.lit != 0) return err;                    // the column ends inside a literal run
     out = S.row;
   }
@@ -620,10 +621,10 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_count_seg(BatchDev B) {
   u32 a = 0, b = 0;
   i32 fail;
   if (blockIdx.y == 0) {
-    fail = sd_count_column<SD_CNT_ITEMS>(B, d, w, D.ocol[OC_ID_CTR], AMH_MAX_ROWS_PER_DOC + 1, AMH_E_READ_OP, a);
+    fail = sd_count_column<SD_CNT_ITEMS>(B, d, w, D.ocol[OC_ID_CTR], B.max_doc_rows + 1, AMH_E_READ_OP, a);
     if (!fail) fail = sd_count_column<SD_CNT_SUM>(B, d, w, D.ocol[OC_SUCC_NUM], a, AMH_E_READ_OP, b);
   } else {
-    fail = sd_count_column<SD_CNT_UNTIL_NULL>(B, d, w, D.ccol[CC_ACTOR], AMH_MAX_ROWS_PER_DOC + 1, AMH_E_READ_CHANGE, a);
+    fail = sd_count_column<SD_CNT_UNTIL_NULL>(B, d, w, D.ccol[CC_ACTOR], B.max_doc_rows + 1, AMH_E_READ_CHANGE, a);
     if (!fail) fail = sd_count_column<SD_CNT_SUM>(B, d, w, D.ccol[CC_DEPS_NUM], a, AMH_E_READ_CHANGE, b);
   }
   if (lane == 0) {

@@ -121,6 +121,11 @@ const char* amh_last_error(const amh_ctx*);   /* message of the last failed call
  * An input is what the reference's load accepts: a document chunk, optionally followed by change chunks
  * (save_incremental output), or change chunks alone; the change chunks go through the apply path with the
  * reference's policies (MissingDeps when the first chunk is not a document, on_partial_load). */
+/* Limits against hostile inputs (no counterpart in the reference, which loads one document at a time and loses only
+ * that document): a document whose op rows, succ entries, changes or deps exceed max_doc_rows (0 = the built-in
+ * 2^28), and the largest documents of a batch whose derived device arrays would exceed max_batch_bytes (0 = what the
+ * device has free), fail with AMH_DOC_TOO_LARGE; the other documents of the batch load. */
+int amh_ctx_set_limits(amh_ctx*, uint64_t max_doc_rows, uint64_t max_batch_bytes);
 amh_staged* amh_stage_batch(amh_ctx*, const uint8_t* const* docs, const size_t* lens, size_t n);
 void amh_staged_free(amh_staged*);
 amh_batch* amh_load_staged(amh_ctx*, const amh_staged*, const amh_load_opts*);

@@ -131,3 +131,64 @@ def check_case(engine, chunks, budget_s=None, log=None):
     if budget_s is not None:
         assert max(times.values()) < budget_s, times
     return times
+
+
+def hostile_document(rows):
+    """a well-formed document chunk of about 60 bytes (valid checksum) whose op id and succ-count columns are one run
+    of `rows` values each: the count pass accepts it, and everything sized from the counts is sized for `rows` ops"""
+    import hashlib
+    from change_builder import sleb, uleb
+    id_ctr = sleb(rows) + sleb(1)          # delta column: one run of +1
+    succ_num = sleb(rows) + uleb(0)        # no op has a successor
+    actor = bytes(range(16))
+    body = uleb(1) + uleb(len(actor)) + actor + uleb(0)            # actors, heads
+    body += uleb(0)                                                # change columns: none
+    body += uleb(2) + uleb(35) + uleb(len(id_ctr)) + uleb(128) + uleb(len(succ_num))
+    body += id_ctr + succ_num
+    tail = bytes([0]) + uleb(len(body)) + body
+    return b"\x85\x6f\x4a\x83" + hashlib.sha256(tail).digest()[:4] + tail
+
+
+def check_hostile_documents(engine, good_docs, rows_hostile, max_doc_rows):
+    """hostile documents between good ones: with a per-document limit they fail alone (TooLarge) and the others load;
+    with a byte budget the largest documents of an oversized batch fail and the rest loads"""
+    import oracle_lib as o
+    engine.set_limits(max_doc_rows=max_doc_rows)
+    try:
+        docs = []
+        for g in good_docs:
+            docs += [hostile_document(rows_hostile), g]
+        b = engine.load_batch(docs)
+        for i, d in enumerate(docs):
+            kind, _ = b.status(i)
+            if i % 2 == 0:
+                assert kind == 90, (i, kind)      # AMH_DOC_TOO_LARGE
+            else:
+                assert kind == 0, (i, kind)
+                assert b.hydrate_json(i) == o.Doc.load(d).hydrate_json()
+        b.close()
+        # byte budget: room for the small documents only
+        sizes = sorted(len(g) for g in good_docs)
+        engine.set_limits(max_doc_rows=max_doc_rows, max_batch_bytes=1)
+        b = engine.load_batch(list(good_docs))
+        assert all(b.status(i)[0] == 90 for i in range(len(good_docs)))
+        b.close()
+        big = max(range(len(good_docs)), key=lambda i: len(good_docs[i]))
+        engine.set_limits(max_doc_rows=max_doc_rows)
+
+        def estimate(docs):   # the engine's own sizing rule (amh_host.cpp, derived_bytes), from the loaded counts
+            bb = engine.load_batch(docs)
+            st = bb.stats()
+            bb.close()
+            return st["op_rows"] * 224 + st["succ_entries"] * 72 + st["changes"] * (420 + 4 * 8)
+        budget = estimate([g for i, g in enumerate(good_docs) if i != big]) + estimate([good_docs[big]]) // 2
+        engine.set_limits(max_doc_rows=max_doc_rows, max_batch_bytes=budget)
+        b = engine.load_batch(list(good_docs))
+        st = [b.status(i)[0] for i in range(len(good_docs))]
+        assert st[big] == 90 and sum(1 for s in st if s == 0) >= 1, st
+        for i, g in enumerate(good_docs):
+            if st[i] == 0:
+                assert b.hydrate_json(i) == o.Doc.load(g).hydrate_json()
+        b.close()
+    finally:
+        engine.set_limits(0, 0)

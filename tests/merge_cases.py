@@ -68,3 +68,38 @@ def check_merge_many(engine, reps):
         assert [c["hash"] for c in bd.get_changes(i)] == [c["hash"] for c in ref.changes()], i
         assert saved[i] == ref.save(deflate=False), i
     return bd
+
+
+def check_merge_into_queued(engine, docs_pairs):
+    """docs_pairs: [(base, other)] replicas of one document each.  dst = base with all but the first of other's new
+    changes delivered early (they wait in the queue); src = base + that first change.  The merge brings the missing
+    dependency, so the queue drains inside the merge (automerge.rs:821-825, 938).  One pair is left without a queue so
+    that one call covers both routes."""
+    dst_docs, src_docs, refs, early = [], [], [], []
+    for k, (base, other) in enumerate(docs_pairs):
+        have = {c["hash"] for c in o.Doc.load(base).changes()}
+        new = [c["raw"] for c in o.Doc.load(other).changes() if c["hash"] not in have]
+        assert len(new) >= 2
+        src = o.Doc.load(base)
+        src.apply_changes(new[:1])
+        dst_docs.append(base)
+        src_docs.append(src.save(deflate=False))
+        early.append(new[1:] if k != 1 else [])
+    bd, bs = engine.load_batch(dst_docs), engine.load_batch(src_docs)
+    for i, e in enumerate(early):
+        ref = o.Doc.load(dst_docs[i])
+        if e:
+            bd.apply_changes(i, e)
+            ref.apply_changes(e)
+            assert bd.queue_len(i) == len(e) == ref.queue_len()
+        refs.append(ref)
+    assert bd.merge(bs, [(i, i) for i in range(len(dst_docs))]) == 0
+    saved = bd.save_all(deflate=False)
+    for i, ref in enumerate(refs):
+        ref.merge(o.Doc.load(src_docs[i]))
+        bd.check(i)
+        assert bd.queue_len(i) == ref.queue_len() == 0
+        assert bd.hydrate_json(i) == ref.hydrate_json(), i
+        assert bd.get_heads(i) == ref.get_heads(), i
+        assert [c["hash"] for c in bd.get_changes(i)] == [c["hash"] for c in ref.changes()], i
+        assert saved[i] == ref.save(deflate=False), i

@@ -202,6 +202,13 @@ def test_merge_many_replicas_in_one_pass(emu):
     check_merge_many(emu, [[a for a, _ in halves], [b for _, b in halves], [bytes(blob[offs[i]:offs[i + 1]]) for i in range(3)]])
 
 
+def test_merge_into_documents_with_queued_changes(emu):
+    from merge_cases import check_merge_into_queued
+    blob, offs = emu.gen_text_docs(0xA11CE, 3, 2, 60, 300, 50, 1)
+    docs = [bytes(blob[offs[i]:offs[i + 1]]) for i in range(6)]
+    check_merge_into_queued(emu, [(docs[0], docs[1]), (docs[2], docs[3]), (docs[4], docs[5])])
+
+
 def test_merge_nothing_new_and_failures(emu):
     from merge_cases import split_map_doc
     blob, offs = emu.gen_map_docs(43, 2, 4, 5, 10, 8, 1)
@@ -301,3 +308,12 @@ def test_adversarial_shapes_small(emu, name, args):
     """the shapes of tests/test_gpu_adversarial.py at sizes the thread-by-thread emulation runs quickly"""
     import adversarial_cases as adv
     adv.check_case(emu, adv.CASES[name](*args))
+
+
+def test_hostile_documents_fail_alone(emu):
+    import adversarial_cases as adv
+    blob, offs = emu.gen_map_docs(77, 5, 3, 3, 20, 16, 1)
+    good = [bytes(blob[offs[i]:offs[i + 1]]) for i in range(5)]
+    blob, offs = emu.gen_text_docs(78, 1, 1, 50, 2000, 100, 1)
+    good.append(bytes(blob[offs[0]:offs[1]]))
+    adv.check_hostile_documents(emu, good, 100000, 50000)

@@ -28,3 +28,22 @@ def engine():
 def test_adversarial_shape(engine, name, args):
     chunks = adv.CASES[name](*args)
     adv.check_case(engine, chunks, budget_s=BUDGET_S)
+
+
+def test_hostile_documents_fail_alone(engine):
+    """documents of ~60 bytes that claim 2^28 - 1 op rows (about 60 GB of derived arrays each) inside a good batch:
+    under a per-document limit they fail alone; under the default limit a batch of six of them exceeds the device and
+    the byte budget fails the largest documents instead of the batch"""
+    blob, offs = engine.gen_map_docs(77, 5, 3, 3, 20, 16, 1)
+    good = [bytes(blob[offs[i]:offs[i + 1]]) for i in range(5)]
+    blob, offs = engine.gen_text_docs(78, 1, 1, 50, 2000, 100, 1)
+    good.append(bytes(blob[offs[0]:offs[1]]))
+    adv.check_hostile_documents(engine, good, (1 << 28) - 1, 1 << 22)
+    docs = []
+    for g in good:
+        docs += [adv.hostile_document((1 << 28) - 1), g]
+    b = engine.load_batch(docs)       # default limits: 6 x 60 GB does not fit
+    st = [b.status(i)[0] for i in range(len(docs))]
+    assert all(st[i] == 0 for i in range(1, len(docs), 2)), st
+    assert all(st[i] != 0 for i in range(0, len(docs), 2)), st
+    assert st.count(90) >= 2, st

@@ -251,6 +251,13 @@ def test_merge_many_replicas_in_one_pass(engine):
     check_merge_many(engine, [[a for a, _ in halves], [b for _, b in halves], [bytes(blob[offs[i]:offs[i + 1]]) for i in range(3)]])
 
 
+def test_merge_into_documents_with_queued_changes(engine):
+    from merge_cases import check_merge_into_queued
+    blob, offs = engine.gen_text_docs(0xA11CE, 3, 2, 60, 300, 50, 1)
+    docs = [bytes(blob[offs[i]:offs[i + 1]]) for i in range(6)]
+    check_merge_into_queued(engine, [(docs[0], docs[1]), (docs[2], docs[3]), (docs[4], docs[5])])
+
+
 def test_merge_nothing_new_and_failures(engine):
     from merge_cases import split_map_doc
     blob, offs = engine.gen_map_docs(43, 2, 4, 5, 10, 8, 1)
