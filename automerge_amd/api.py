@@ -6,6 +6,7 @@ There is no CPU fallback: if the HIP library is missing, importing the engine ra
 import ctypes as C
 import os
 import sys
+import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libautomerge_hip.so")
@@ -171,6 +172,7 @@ class Batch:
         self.engine = engine
         self.h = handle
         self.n = n
+        engine._children.add(self)
 
     def close(self):
         if self.h:
@@ -381,6 +383,7 @@ class Arena:
 class Staged:
     def __init__(self, engine, handle, n):
         self.engine, self.h, self.n = engine, handle, n
+        engine._children.add(self)
 
     def close(self):
         if self.h:
@@ -399,6 +402,7 @@ class Engine:
 
     def __init__(self, gpu=0, lib=None):
         self.lib = lib if lib is not None else load_library()
+        self._children = weakref.WeakSet()   # batches and staged inputs: they hold handles into the context
         ids = (C.c_int * 1)(gpu)
         self.ctx = self.lib.amh_ctx_create(ids, 1)
         if not self.ctx:
@@ -406,6 +410,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "ctx", None):
+            for child in list(self._children):   # their memory goes back to the context's pool: free them first
+                child.close()
             self.lib.amh_ctx_destroy(self.ctx)
             self.ctx = None
 

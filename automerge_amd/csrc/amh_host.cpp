@@ -951,76 +951,99 @@ static i64 host_sleb(const uint8_t* p, size_t n, bool is_unsigned) {
   if (!is_unsigned && shift < 64 && (b & 0x40)) res |= ~(u64)0 << shift;
   return (i64)res;
 }
-static void hydrate_obj(const DocRows& R, u64 obj, u8 objtype, std::string& out, int depth);
-static void hydrate_value(const DocRows& R, u32 r, std::string& out, int depth) {
+// one scalar value, or the opening of a nested object (returns true: the caller descends into it)
+static bool hydrate_value_open(const DocRows& R, u32 r, std::string& out) {
   out += "{\"id\":\"" + std::to_string(R.id_ctr[r]) + "@" + R.actor_hex[R.id_actor[r]] + "\",";
   u8 a = R.action[r];
   if (a == 0 || a == 2 || a == 4 || a == 6) {
     const char* names[] = {"map", "", "list", "", "text", "", "table"};
     out += std::string("\"") + names[a] + "\":";
-    hydrate_obj(R, ((u64)R.id_ctr[r] << 32) | R.id_actor[r], a, out, depth + 1);
-  } else {
-    u64 m = R.vmeta[r];
-    u32 t = (u32)(m & 15);
-    size_t l = (size_t)(m >> 4);
-    const uint8_t* raw = R.chunk + R.D->ocol[OC_VAL_RAW].off + R.vraw_off[r];
-    switch (t) {
-      case 0: out += "\"null\":null"; break;
-      case 1: out += "\"bool\":false"; break;
-      case 2: out += "\"bool\":true"; break;
-      case 3: out += "\"uint\":" + std::to_string((u64)host_sleb(raw, l, true)); break;
-      case 4: out += "\"int\":" + std::to_string(host_sleb(raw, l, false)); break;
-      case 5: out += "\"f64\":\"" + hexs(raw, l) + "\""; break;
-      case 6: out += "\"str\":"; json_str(out, raw, l); break;
-      case 7: out += "\"bytes\":\"" + hexs(raw, l) + "\""; break;
-      case 8: out += "\"counter\":" + std::to_string(host_sleb(raw, l, false) + R.inc_sum[r]); break;
-      case 9: out += "\"ts\":" + std::to_string(host_sleb(raw, l, false)); break;
-      default: out += "\"unknown\":[" + std::to_string(t) + ",\"" + hexs(raw, l) + "\"]"; break;
-    }
+    return true;
+  }
+  u64 m = R.vmeta[r];
+  u32 t = (u32)(m & 15);
+  size_t l = (size_t)(m >> 4);
+  const uint8_t* raw = R.chunk + R.D->ocol[OC_VAL_RAW].off + R.vraw_off[r];
+  switch (t) {
+    case 0: out += "\"null\":null"; break;
+    case 1: out += "\"bool\":false"; break;
+    case 2: out += "\"bool\":true"; break;
+    case 3: out += "\"uint\":" + std::to_string((u64)host_sleb(raw, l, true)); break;
+    case 4: out += "\"int\":" + std::to_string(host_sleb(raw, l, false)); break;
+    case 5: out += "\"f64\":\"" + hexs(raw, l) + "\""; break;
+    case 6: out += "\"str\":"; json_str(out, raw, l); break;
+    case 7: out += "\"bytes\":\"" + hexs(raw, l) + "\""; break;
+    case 8: out += "\"counter\":" + std::to_string(host_sleb(raw, l, false) + R.inc_sum[r]); break;
+    case 9: out += "\"ts\":" + std::to_string(host_sleb(raw, l, false)); break;
+    default: out += "\"unknown\":[" + std::to_string(t) + ",\"" + hexs(raw, l) + "\"]"; break;
   }
   out += "}";
+  return false;
 }
-static void hydrate_obj(const DocRows& R, u64 obj, u8 objtype, std::string& out, int depth) {
-  if (depth > 200) { out += "null"; return; }
-  auto it = R.obj_range.find(obj);
-  u32 s = 0, e = 0;
-  if (it != R.obj_range.end()) { s = it->second.first; e = it->second.second; }
-  bool is_map = objtype == 0 || objtype == 6, is_text = objtype == 4;
-  if (is_text) {
-    std::string text;
-    u32 i = s;
-    while (i < e) {
-      u32 j = i;
-      int last = -1;
-      while (j < e && same_key_host(R, j, i)) { if (R.visible[j]) last = (int)j; j++; }
-      if (last >= 0) {
-        if (R.action[last] == 1 && (R.vmeta[last] & 15) == 6)
-          text.append((const char*)R.chunk + R.D->ocol[OC_VAL_RAW].off + R.vraw_off[last], (size_t)(R.vmeta[last] >> 4));
-        else text += "\xef\xbf\xbc";
+// The materialized state of an object and everything below it (hydrate.rs:128-167).  An explicit stack of objects being
+// written instead of recursion: nesting has no depth limit in the reference, and must not have one here.
+static void hydrate_obj(const DocRows& R, u64 root_obj, u8 root_type, std::string& out) {
+  struct Frame { u32 i, e; bool is_map, first, in_group, close_value; std::vector<u32> vis; size_t k; };
+  std::vector<Frame> stack;
+  auto open = [&](u64 obj, u8 objtype, bool close_value) {
+    auto it = R.obj_range.find(obj);
+    u32 s = 0, e = 0;
+    if (it != R.obj_range.end()) { s = it->second.first; e = it->second.second; }
+    if (objtype == 4) {   // text: the visible characters in order, no nesting
+      std::string text;
+      u32 i = s;
+      while (i < e) {
+        u32 j = i;
+        int last = -1;
+        while (j < e && same_key_host(R, j, i)) { if (R.visible[j]) last = (int)j; j++; }
+        if (last >= 0) {
+          if (R.action[last] == 1 && (R.vmeta[last] & 15) == 6)
+            text.append((const char*)R.chunk + R.D->ocol[OC_VAL_RAW].off + R.vraw_off[last], (size_t)(R.vmeta[last] >> 4));
+          else text += "\xef\xbf\xbc";
+        }
+        i = j;
       }
-      i = j;
+      json_str(out, (const uint8_t*)text.data(), text.size());
+      if (close_value) out += "}";
+      return;
     }
-    json_str(out, (const uint8_t*)text.data(), text.size());
-    return;
-  }
-  out += is_map ? "{" : "[";
-  bool first = true;
-  u32 i = s;
-  while (i < e) {
-    u32 j = i;
-    std::vector<u32> vis;
-    while (j < e && same_key_host(R, j, i)) { if (R.visible[j]) vis.push_back(j); j++; }
-    if (!vis.empty()) {
-      if (!first) out += ",";
-      first = false;
-      if (is_map) { json_str(out, R.chunk + R.key_off[i], R.key_len[i]); out += ":"; }
-      out += "[";
-      for (size_t k = 0; k < vis.size(); k++) { if (k) out += ","; hydrate_value(R, vis[k], out, depth); }
-      out += "]";
+    Frame f;
+    f.i = s; f.e = e; f.is_map = objtype == 0 || objtype == 6; f.first = true; f.in_group = false; f.close_value = close_value; f.k = 0;
+    out += f.is_map ? "{" : "[";
+    stack.push_back(std::move(f));
+  };
+  open(root_obj, root_type, false);
+  while (!stack.empty()) {
+    Frame& f = stack.back();
+    if (f.in_group) {
+      if (f.k < f.vis.size()) {
+        u32 r = f.vis[f.k++];
+        if (f.k > 1) out += ",";
+        if (hydrate_value_open(R, r, out)) open(((u64)R.id_ctr[r] << 32) | R.id_actor[r], R.action[r], true);   // may reallocate the stack: f is not used below
+      } else {
+        out += "]";
+        f.in_group = false;
+      }
+      continue;
     }
-    i = j;
+    if (f.i < f.e) {
+      u32 i = f.i, j = i;
+      f.vis.clear();
+      while (j < f.e && same_key_host(R, j, i)) { if (R.visible[j]) f.vis.push_back(j); j++; }
+      f.i = j;
+      if (!f.vis.empty()) {
+        if (!f.first) out += ",";
+        f.first = false;
+        if (f.is_map) { json_str(out, R.chunk + R.key_off[i], R.key_len[i]); out += ":"; }
+        out += "[";
+        f.in_group = true; f.k = 0;
+      }
+      continue;
+    }
+    out += f.is_map ? "}" : "]";
+    if (f.close_value) out += "}";
+    stack.pop_back();
   }
-  out += is_map ? "}" : "]";
 }
 
 extern "C" int amh_hydrate_json(const amh_batch* b, uint32_t doc, amh_bytes_out* out) {
@@ -1054,7 +1077,7 @@ extern "C" int amh_hydrate_json(const amh_batch* b, uint32_t doc, amh_bytes_out*
     i = j;
   }
   std::string s;
-  hydrate_obj(R, 0, 0, s, 0);
+  hydrate_obj(R, 0, 0, s);
   out->data = (uint8_t*)malloc(s.size() + 1);
   if (!out->data) return AMH_ERR_OOM;
   memcpy(out->data, s.data(), s.size());

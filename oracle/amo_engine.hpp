@@ -882,7 +882,7 @@ inline void hydrate_value(const Doc& doc, const Op& op, std::string& out, int de
   out += "}";
 }
 inline void hydrate_obj(const Doc& doc, const OpId& obj, uint64_t objtype, std::string& out, int depth) {
-  if (depth > 200) throw Error(E_INVALID_ARG, "object nesting too deep");
+  if (depth > 10000) throw Error(E_INVALID_ARG, "object nesting too deep");   // this recursive restatement guards its own stack; hydrate.rs:128-167 has no limit
   auto tit = doc.trees.find(obj);
   static const std::vector<Op> none;
   const std::vector<Op>& ops = tit == doc.trees.end() ? none : tit->second.ops;

@@ -41,6 +41,15 @@ def wide_overwrite(n=3000, n_actors=4):
     return out
 
 
+def deep_nesting(depth=600):
+    """maps nested `depth` levels deep, a value at the bottom (the reference's hydrate has no depth limit)"""
+    from change_builder import MAKE_MAP
+    ops = [op(MAKE_MAP, obj=None if i == 0 else (i, 0), key="k") for i in range(depth)]
+    ops.append(op(SET, obj=(depth, 0), key="bottom", value=v_str("here")))
+    c, _ = build_change(actor_id(1), 1, 1, [], ops)
+    return [c]
+
+
 def new_map_keys(n=20000):
     rng = random.Random(11)
     keys = ["%s-%d" % ("".join(rng.choice("abcdefgh") for _ in range(rng.randint(1, 12))), i) for i in range(n)]
@@ -90,7 +99,7 @@ def typed_run(n=5000, base=100):
     return [c0, c1]
 
 
-CASES = {"wide_overwrite": wide_overwrite, "overwritten_key": overwritten_key, "counter_increments": counter_increments, "new_map_keys": new_map_keys,
+CASES = {"deep_nesting": deep_nesting, "wide_overwrite": wide_overwrite, "overwritten_key": overwritten_key, "counter_increments": counter_increments, "new_map_keys": new_map_keys,
          "head_siblings": head_siblings, "siblings_behind_one_element": siblings_behind_one_element, "typed_run": typed_run}
 
 
