@@ -2218,7 +2218,13 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       if (fi + 1 == fresh.size() || chunks[fresh[fi + 1]].buf != chunks[k].buf) drain();
     }
     if (fresh.empty() && !dup) drain();
-    if (dup) { p_status[p] = AMH_E_DUPLICATE_SEQ; results[p] = AMH_E_DUPLICATE_SEQ; o.failed = 1; return; }
+    if (dup) {
+      // apply_changes returns from the middle of its loop (automerge.rs:804-812): the changes in front of the offender
+      // stay applied, those it pushed stay queued, the queue is not drained and nothing behind the offender is looked
+      // at.  A document load whose trailing changes do this fails as a whole (load_with_options returns the error).
+      results[p] = AMH_E_DUPLICATE_SEQ;
+      if (mode == APM_LOAD_ERROR || mode == APM_LOAD_IGNORE) { p_status[p] = AMH_E_DUPLICATE_SEQ; o.failed = 1; return; }
+    }
     if (mode == APM_LOAD_ERROR && !items[p].first_was_doc && !queue.empty()) { p_status[p] = AMH_E_MISSING_DEPS; results[p] = AMH_E_MISSING_DEPS; o.failed = 1; return; }
     new_queue[p] = queue; queue_dirty[p] = 1;
     if (order.empty()) { p_status[p] = -1; return; }
@@ -2362,7 +2368,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   }
   commit_queues();
   for (u32 p = 0; p < P; p++) if (results[p]) rc = AMH_ERR_DOC_FAILED;
-  if (rc == AMH_ERR_DOC_FAILED) set_error(ctx, std::string(who) + ": some documents were left unchanged (see the per-document results)");
+  if (rc == AMH_ERR_DOC_FAILED) set_error(ctx, std::string(who) + ": some documents were left unchanged, or (duplicate seq number) changed only by the changes in front of the offender; see the per-document results");
   return rc;
 }
 

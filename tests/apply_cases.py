@@ -246,3 +246,61 @@ def check_error_precedence(engine, data):
         got = 4 if 20 <= kind < 40 else kind     # the oracle reports every reconstruction error as kind 4
         assert got == want, (i, kind, want)
     assert b.status(0)[0] == 0 and b.status(1)[0] == 2 and b.status(2)[0] == 2 and b.status(4)[0] == 1
+
+
+def check_duplicate_seq_applies_prefix(engine):
+    """apply_changes([A, D, B]) where D repeats an (actor, seq) of the document with other content: the reference
+    returns DuplicateSeqNumber from the middle of its loop (automerge.rs:804-812), so A stays applied, B is never
+    looked at, and a change queued in front of D stays queued."""
+    from change_builder import SET, actor_id, build_change, op, v_uint
+    a0, a1, a2, a3 = (actor_id(i) for i in range(4))
+    c0, h0 = build_change(a0, 1, 1, [], [op(SET, key="a", value=v_uint(1))])
+    A, hA = build_change(a1, 1, 2, [h0], [op(SET, key="b", value=v_uint(2))])
+    Q, _ = build_change(a3, 1, 9, [b"\x11" * 32], [op(SET, key="q", value=v_uint(9))])      # dependency unknown: queued
+    D, _ = build_change(a0, 1, 1, [], [op(SET, key="z", value=v_uint(26))])                  # (a0, seq 1) again
+    B, _ = build_change(a2, 1, 2, [h0], [op(SET, key="c", value=v_uint(3))])
+    base = o.Doc()
+    base.apply_changes([c0])
+    saved = base.save(deflate=False)
+    ref = o.Doc.load(saved)
+    try:
+        ref.apply_changes([A, Q, D, B])
+        raise AssertionError("the oracle accepted a duplicate seq number")
+    except o.OracleError as e:
+        kind = e.kind
+    b = engine.load_batch([saved, saved])
+    res = b.apply_batch([(0, A + Q + D + B), (1, A + B)])
+    assert res == [kind, 0], res
+    check_doc(b, 0, ref)                       # A applied, Q queued, no B
+    assert b.queue_len(0) == 1
+    assert b.save_all(deflate=False)[0] == ref.save(deflate=False)
+    ref1 = o.Doc.load(saved)
+    ref1.apply_changes([A, B])
+    check_doc(b, 1, ref1)
+
+
+def check_pred_naming_no_op(engine):
+    """A change whose op names a pred that does not exist.  The reference applies it (the pred finds no op to succeed,
+    op_set.rs:194-203) but cannot round-trip it: its own save drops the dangling pred, the re-derived change hashes
+    differently, and its own load of that save fails the heads check.  The engine re-verifies every document it
+    changes, so it refuses the change up front (AMH_DOC_UNSUPPORTED, 91) and leaves the document as it was —
+    INTEGRATION.md lists this under "Inputs answered with 91"."""
+    from change_builder import SET, actor_id, build_change, op, v_uint
+    a0, a1 = actor_id(0), actor_id(1)
+    c0, h0 = build_change(a0, 1, 1, [], [op(SET, key="a", value=v_uint(1))])
+    bad, _ = build_change(a1, 1, 2, [h0], [op(SET, key="a", value=v_uint(2), pred=[(77, 1)])], others=[a0])
+    base = o.Doc()
+    base.apply_changes([c0])
+    saved = base.save(deflate=False)
+    ref = o.Doc.load(saved)
+    ref.apply_changes([bad])                       # accepted
+    try:
+        o.Doc.load(ref.save(deflate=False))
+        round_trips = True
+    except o.OracleError:
+        round_trips = False
+    assert not round_trips
+    b = engine.load_batch([saved])
+    res = b.apply_batch([(0, bad)])
+    assert res == [91], res
+    check_doc(b, 0, o.Doc.load(saved))             # unchanged

@@ -238,6 +238,8 @@ def test_apply_changes_text_replicas(emu):
     ac.check_apply_tail(emu, docs[:4], lambda n: 1)
     ac.check_apply_replicas(emu, docs, 4)
     ac.check_queue_across_calls(emu, docs[0], docs[1])
+    ac.check_duplicate_seq_applies_prefix(emu)
+    ac.check_pred_naming_no_op(emu)
     ac.check_incremental_with_documents(emu, docs[4:8])
     ac.check_save_after_roundtrip(emu, docs[8:12])
 

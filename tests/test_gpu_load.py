@@ -289,6 +289,8 @@ def test_apply_changes_text_replicas(engine):
     ac.check_apply_tail(engine, docs[:4], lambda n: 1)
     ac.check_apply_replicas(engine, docs, 4)
     ac.check_queue_across_calls(engine, docs[0], docs[1])
+    ac.check_duplicate_seq_applies_prefix(engine)
+    ac.check_pred_naming_no_op(engine)
     ac.check_incremental_with_documents(engine, docs[4:8])
     ac.check_save_after_roundtrip(engine, docs[8:12])
 
