@@ -1309,6 +1309,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   G.new_idx = balloc<u32>(mb, NRS, &ok); G.gap_base = balloc<u32>(mb, P + 2, &ok);
   G.sub_end = balloc<u32>(mb, NRD, &ok); G.upd_end = balloc<u32>(mb, NRD, &ok); G.stack = balloc<u32>(mb, NRD, &ok);
   G.x_cnt = balloc<u32>(mb, NRD, &ok); G.x_fill = balloc<u32>(mb, NRD, &ok); G.d_to_m = balloc<u32>(mb, NRD, &ok);
+  G.sub_min1 = balloc<u32>(mb, NRD / 64 + 2, &ok); G.sub_min2 = balloc<u32>(mb, NRD / 4096 + 2, &ok);
   MergeDev* Gdev = (MergeDev*)balloc<u8>(mb, sizeof(MergeDev), &ok);
   {   // lists too long for one thread (amh_types.h, big_*): a list has more than AMH_BIG_LIST entries, so there are few
     u64 entries = (u64)DB.tot_rows + DB.tot_succ + 2 * ((u64)SB.tot_rows + SB.tot_succ) + (ap ? 2 * ((u64)ap->U.tot_rows + ap->U.tot_succ) : 0);
@@ -1324,6 +1325,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   }
   rt_memset(M.fail_line, 0, (P + 1) * 4, ctx->stream);
   rt_memset(G.x_cnt, 0, NRD * 4, ctx->stream); rt_memset(G.x_fill, 0, NRD * 4, ctx->stream);
+  if (ok) rt_memset(G.sub_min2, 0xFF, (NRD / 4096 + 2) * 4, ctx->stream);
   auto mg = [&](int k, u32 n) {
     if (n == 0) return true;
     if (!rt_h2d(Gdev, &G, sizeof(MergeDev), ctx->stream)) return false;
@@ -1379,7 +1381,11 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   rt_memset(G.new_src, 0xFF, ((size_t)tot_new + 1) * 4, ctx->stream);   // pairs given up by a kernel leave their slots empty
   rt_memset(G.new_gap, 0xFF, ((size_t)tot_new + 1) * 4, ctx->stream);
   rt_memset(M.r_succ_cnt, 0, NR * 4, ctx->stream);
-  mg(MK_SUBTREE, P);
+#ifdef AMH_EMU
+  mg(MK_SUBTREE, P);            // per-document stack walk
+#else
+  mg(MK_SUBTREE, DB.tot_rows);  // thread per row (g_mg_sub_*)
+#endif
   pt.mark("exec: setup + subtree", &ctx->stream);
   if (ap) {
     u32 nr = G.U.tot_rows;

@@ -1023,76 +1023,91 @@ template <int KIND> __global__ void __launch_bounds__(AMH_BLOCK) g_big_mg(const 
     __syncthreads();
   }
 }
-// wave-per-pair forms of the two merge kernels that are serial per document: the wave streams the
-// rows through LDS with coalesced loads and one lane walks them (no memory round trip per step).
-#define MGS_STACK 2048u
-__global__ void __launch_bounds__(64) g_mg_subtree_wave(const MergeDev* Gp) {
+// Subtree ends of the dst documents' sequence elements, thread per row (the emulation tier keeps the per-document
+// stack walk, k_mg_subtree).  Rows are in preorder, so the subtree of element e ends at the first later row that is the
+// first row of an object, or an element whose parent sits in front of e: with q[j] = parent position + 1 (0 for HEAD and
+// for an object's first row, "none" for rows that are not elements) that is the first j > e with q[j] <= e.  Pass 1
+// looks the parents up (id -> row table) and leaves q and its minimum per 64 and per 4096 rows; pass 2 finds the ends,
+// skipping tiles whose minimum is too large; pass 3 checks that every parent is an ancestor (its subtree is still open).
+__global__ void __launch_bounds__(AMH_BLOCK) g_mg_sub_parent(const MergeDev* Gp, u32 n) {
   const MergeDev& G = *Gp;
-  u32 p = blockIdx.x;
-  if (p >= G.n_pairs || G.p_status[p] != 0) return;
-  __shared__ u32 t_oc[64], t_oa[64], t_kc[64], t_ka[64], t_ic[64], t_ia[64], t_fl[64];
-  __shared__ u32 s_i[MGS_STACK], s_c[MGS_STACK], s_a[MGS_STACK];
   const BatchDev& D = G.D;
-  const u32 lane = threadIdx.x;
-  u32 a = G.p_a[p], rb = D.row_base[a], n = D.cnt[a].n_rows;
-  u32 sp = 0, last_ins = AMH_NULL32, poc = 0, poa = 0;
-  bool bad = false;
-  auto pop_to = [&](u32 i) {   // end the subtree on top of the stack at row i
-    sp--;
-    u32 e = sp < MGS_STACK ? s_i[sp] : G.stack[rb + sp];
-    G.sub_end[rb + e] = i;
-  };
-  for (u32 t0 = 0; t0 < n; t0 += 64) {
-    u32 i = t0 + lane;
-    if (i < n) {
-      u32 r = rb + i;
-      t_oc[lane] = D.r_obj_ctr[r]; t_oa[lane] = D.r_obj_actor[r];
-      t_kc[lane] = D.r_key_ctr[r]; t_ka[lane] = D.r_key_actor[r];
-      t_ic[lane] = D.r_id_ctr[r]; t_ia[lane] = D.r_id_actor[r];
-      t_fl[lane] = (D.r_key_len[r] != AMH_NULL32 ? 1u : 0u) | (D.r_insert[r] ? 2u : 0u);
-      G.sub_end[r] = i + 1;
-      G.upd_end[r] = i + 1;
-    }
-    __syncthreads();
-    if (lane == 0 && !bad) {
-      u32 cnt = n - t0 < 64 ? n - t0 : 64;
-      for (u32 k = 0; k < cnt; k++) {
-        u32 ii = t0 + k;
-        if (ii == 0 || t_oc[k] != poc || t_oa[k] != poa) {   // object boundary
-          while (sp) pop_to(ii);
-          if (last_ins != AMH_NULL32) G.upd_end[rb + last_ins] = ii;
-          last_ins = AMH_NULL32;
-          poc = t_oc[k]; poa = t_oa[k];
-        }
-        u32 fl = t_fl[k];
-        if ((fl & 1) || !(fl & 2)) continue;   // map row, or an update of an element
-        if (last_ins != AMH_NULL32) G.upd_end[rb + last_ins] = ii;
-        last_ins = ii;
-        u32 kc = t_kc[k], ka = t_ka[k];
-        if (kc == 0) { while (sp) pop_to(ii); }
+  u32 r = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  u32 q = AMH_NULL32;
+  if (r < n) {
+    u32 a = D.r_doc[r];
+    u32 p = a < D.n_docs ? G.d_pair[a] : AMH_NULL32;
+    if (p != AMH_NULL32 && G.p_status[p] == 0) {
+      u32 rb = D.row_base[a], i = r - rb;
+      bool first = i == 0 || D.r_obj_ctr[r] != D.r_obj_ctr[r - 1] || D.r_obj_actor[r] != D.r_obj_actor[r - 1];
+      if (first) q = 0;
+      if (D.r_key_len[r] == AMH_NULL32 && D.r_insert[r]) {
+        u32 kc = D.r_key_ctr[r];
+        if (kc == 0) q = 0;
         else {
-          for (;;) {
-            if (!sp) { bad = true; break; }
-            u32 tc, ta;
-            if (sp - 1 < MGS_STACK) { tc = s_c[sp - 1]; ta = s_a[sp - 1]; }
-            else { u32 e = G.stack[rb + sp - 1]; tc = D.r_id_ctr[rb + e]; ta = D.r_id_actor[rb + e]; }
-            if (tc == kc && ta == ka) break;
-            pop_to(ii);
-          }
-          if (bad) break;
+          u32 pr = ht_find(D, a, pack_id(kc, D.r_key_actor[r]));
+          // the parent is an element of the same object in front of this row (anything else is not preorder)
+          bool ok = !first && pr != AMH_EMPTY32 && pr >= rb && pr < r && D.r_key_len[pr] == AMH_NULL32 && D.r_insert[pr] &&
+                    D.r_obj_ctr[pr] == D.r_obj_ctr[r] && D.r_obj_actor[pr] == D.r_obj_actor[r];
+          if (!ok) G.p_status[p] = AMH_E_UNSUPPORTED;
+          else q = pr - rb + 1;
         }
-        if (sp < MGS_STACK) { s_i[sp] = ii; s_c[sp] = t_ic[k]; s_a[sp] = t_ia[k]; }
-        else G.stack[rb + sp] = ii;
-        sp++;
       }
+    } else {
+      q = 0;   // rows of documents that are not merged end every search
     }
-    __syncthreads();
+    G.stack[r] = q;
   }
-  if (lane == 0) {
-    if (bad) { G.p_status[p] = AMH_E_UNSUPPORTED; return; }
-    while (sp) pop_to(n);
-    if (last_ins != AMH_NULL32) G.upd_end[rb + last_ins] = n;
+  u32 m = q;
+  for (int off = 32; off; off >>= 1) { u32 o = __shfl_xor(m, off); m = o < m ? o : m; }
+  if ((threadIdx.x & 63) == 0 && r < n) {
+    G.sub_min1[r >> 6] = m;
+    atomicMin(&G.sub_min2[r >> 12], m);
   }
+}
+__global__ void __launch_bounds__(AMH_BLOCK) g_mg_sub_end(const MergeDev* Gp, u32 n) {
+  const MergeDev& G = *Gp;
+  const BatchDev& D = G.D;
+  u32 r = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  if (r >= n) return;
+  u32 a = D.r_doc[r];
+  u32 p = a < D.n_docs ? G.d_pair[a] : AMH_NULL32;
+  if (p == AMH_NULL32 || G.p_status[p] != 0) return;
+  u32 rb = D.row_base[a], i = r - rb, end = rb + D.cnt[a].n_rows;
+  u32 se = i + 1, ue = i + 1;
+  if (D.r_key_len[r] == AMH_NULL32 && D.r_insert[r]) {
+    // own update rows: up to the next element row or object start
+    u32 j = r + 1;
+    while (j < end && G.stack[j] == AMH_NULL32) j++;
+    ue = j - rb;
+    // subtree: first j > r with q[j] <= i
+    j = r + 1;
+    for (;;) {
+      if (j >= end) { j = end; break; }
+      if ((j & 63) == 0) {   // at a tile start: skip tiles (and groups of 64 tiles) that hold nothing small enough
+        if ((j & 4095) == 0 && G.sub_min2[j >> 12] > i) { j += 4096; continue; }
+        if (G.sub_min1[j >> 6] > i) { j += 64; continue; }
+      }
+      if (G.stack[j] <= i) break;
+      j++;
+    }
+    se = j - rb;
+  }
+  G.sub_end[r] = se;
+  G.upd_end[r] = ue;
+}
+__global__ void __launch_bounds__(AMH_BLOCK) g_mg_sub_check(const MergeDev* Gp, u32 n) {
+  const MergeDev& G = *Gp;
+  const BatchDev& D = G.D;
+  u32 r = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  if (r >= n) return;
+  u32 q = G.stack[r];
+  if (q == AMH_NULL32 || q == 0) return;
+  u32 a = D.r_doc[r];
+  u32 p = a < D.n_docs ? G.d_pair[a] : AMH_NULL32;
+  if (p == AMH_NULL32 || G.p_status[p] != 0) return;
+  u32 rb = D.row_base[a];
+  if (G.sub_end[rb + q - 1] <= r - rb) G.p_status[p] = AMH_E_UNSUPPORTED;   // the parent's subtree ended before this row: not preorder
 }
 // the virtual chunk [dst chunk | src chunk]: one block per pair, 16-byte copies (chunks are 16-byte aligned and padded)
 __global__ void __launch_bounds__(AMH_BLOCK) g_mg_copy_chunks_blk(const MergeDev* Gp) {
@@ -1111,7 +1126,13 @@ __global__ void __launch_bounds__(AMH_BLOCK) g_mg_copy_chunks_blk(const MergeDev
 void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream) {
   if (n == 0) return;
   hipStream_t s = (hipStream_t)stream;
-  if (k == MK_SUBTREE) { hipLaunchKernelGGL(g_mg_subtree_wave, dim3(n), dim3(64), 0, s, G); return; }
+  if (k == MK_SUBTREE) {   // n = rows of the dst batch
+    dim3 g((n + AMH_BLOCK - 1) / AMH_BLOCK), b(AMH_BLOCK);
+    hipLaunchKernelGGL(g_mg_sub_parent, g, b, 0, s, G, n);
+    hipLaunchKernelGGL(g_mg_sub_end, g, b, 0, s, G, n);
+    hipLaunchKernelGGL(g_mg_sub_check, g, b, 0, s, G, n);
+    return;
+  }
   if (k == MK_COPY_CHUNKS) { hipLaunchKernelGGL(g_mg_copy_chunks_blk, dim3(n), dim3(AMH_BLOCK), 0, s, G); return; }
   dim3 grid((n + AMH_BLOCK - 1) / AMH_BLOCK), block(AMH_BLOCK);
 #define M(id, name) case id: hipLaunchKernelGGL(g_##name, grid, block, 0, s, G, n); break;

@@ -254,7 +254,9 @@ struct MergeDev {
   u32* gap_cnt;                    // counters, then exclusive scan
   // dst sequence structure
   u32 *sub_end, *upd_end;          // [D.tot_rows] (document-local indices) end of an element's subtree / of its own update rows
-  u32* stack;                      // [D.tot_rows] scratch of k_mg_subtree
+  u32* stack;                      // [D.tot_rows] scratch of k_mg_subtree; device form: parent position + 1 of an element row (0 = HEAD or
+                                   // the first row of an object, AMH_NULL32 = not an element row)
+  u32 *sub_min1, *sub_min2;        // [D.tot_rows / 64 + 2], [D.tot_rows / 4096 + 2] minimum of `stack` per tile (device form)
   u32* x_cnt;                      // [D.tot_rows] succ entries a dst row gains
   u32* x_fill;                     // [D.tot_rows]
   u32* d_to_m;                     // [D.tot_rows] merged row of a dst row
