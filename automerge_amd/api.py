@@ -43,7 +43,7 @@ EXPORTS = [
     "amh_changes", "amh_hydrate_json", "amh_doc_max_op", "amh_merge_batch", "amh_apply_changes", "amh_save_batch",
     "amh_sync_summaries", "amh_ctx_set_profiling", "amh_ctx_num_kernels", "amh_ctx_kernel_name", "amh_ctx_kernel_time",
     "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free", "amh_apply_batch", "amh_doc_queue_len", "amh_merge_many", "amh_save_after",
-    "amh_sync_summaries_noalloc", "amh_ctx_pool_bytes", "amh_ctx_set_limits",
+    "amh_sync_summaries_noalloc", "amh_ctx_pool_bytes", "amh_ctx_set_limits", "amh_batch_release_ops",
 ]
 
 DOC_ERRORS = {
@@ -86,6 +86,7 @@ def bind(lib):
     lib.amh_ctx_reset_profile.argtypes = [vp]
     lib.amh_ctx_pool_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.amh_ctx_set_limits.argtypes = [vp, C.c_uint64, C.c_uint64]
+    lib.amh_batch_release_ops.argtypes = [vp, vp]
     lib.amh_gen_map_docs.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                      C.POINTER(BytesOut), C.POINTER(C.POINTER(C.c_uint64))]
     lib.amh_gen_text_docs.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
@@ -187,6 +188,12 @@ class Batch:
 
     def __len__(self):
         return self.n
+
+    def release_ops(self):
+        """keep the history (changes, hashes, heads), give the per-op arrays back to the pool: enough for a merge source"""
+        rc = self.engine.lib.amh_batch_release_ops(self.engine.ctx, self.h)
+        if rc != 0:
+            raise EngineError(f"amh_batch_release_ops failed: {rc}")
 
     def status(self, i):
         kind = C.c_int()

@@ -163,6 +163,7 @@ struct amh_batch {
   std::vector<u32> fail_line;
   mutable std::string msg_buf;
   u32 tot_ht = 0, tot_map = 0, tot_out = 0;
+  bool history_only = false;   // amh_batch_release_ops: the per-op arrays are gone, the history (changes, hashes, heads) stays
   mutable HostView hv;
   // changes waiting for their dependencies (Automerge::queue, automerge.rs:168): raw chunks per document
   std::unordered_map<u32, std::vector<std::vector<u8>>> queue;
@@ -336,6 +337,32 @@ extern "C" void amh_batch_free(amh_batch* b) {
   staged_unref(b->staged);
   delete b;
 }
+
+static bool ensure_chg(const amh_batch* b);
+// Keep the history of a loaded batch, give everything per op back to the pool.  What stays serves amh_doc_status,
+// amh_heads, amh_changes, amh_save_after, amh_sync_summaries and the source side of amh_merge_many; everything that needs
+// the op rows (hydrate, save, apply, merge as dst, the pairwise amh_merge_batch) answers AMH_ERR_INVALID_ARG afterwards.
+extern "C" int amh_batch_release_ops(amh_ctx* ctx, amh_batch* b) {
+  if (!ctx || !b) return AMH_ERR_INVALID_ARG;
+  if (b->history_only) return AMH_SUCCESS;
+  if (!ensure_chg(b) || !rt_sync(ctx->stream) || !rt_sync(ctx->side)) return AMH_ERR_DEVICE;   // the host's view of the history, while its sources exist
+  const BatchDev& B = b->B;
+  const void* keep[] = {B.status, B.fail_line, B.desc, B.cnt, B.row_base, B.succ_base, B.chg_base, B.dep_base, B.actor_base, B.doc_hash, B.doc_max_op,
+                        B.heads_ok, B.actor_off, B.actor_len, B.actor_rank, B.actor_by_rank, B.c_actor, B.c_seq, B.c_max_op, B.c_time, B.c_msg_off,
+                        B.c_msg_len, B.c_ndeps, B.c_dep_base, B.c_extra_off, B.c_extra_len, B.c_doc, B.dep_idx, B.c_nops, B.c_start_op, B.c_is_dep,
+                        B.c_hash, B.c_out_off, B.c_out_len, B.out_arena};
+  std::vector<DevAlloc> kept;
+  for (auto& a : b->allocs) {
+    bool k = false;
+    for (const void* q : keep) k = k || (q && q == a.p);
+    if (k) kept.push_back(a); else ctx->pool.release(a.p, a.cap);
+  }
+  b->allocs.swap(kept);
+  b->history_only = true;
+  return AMH_SUCCESS;
+}
+#define AMH_NEEDS_OPS(b, who)                                                                                                        \
+  if ((b)->history_only) { set_error((b)->ctx, std::string(who) + ": the batch's op rows were released (amh_batch_release_ops)"); return AMH_ERR_INVALID_ARG; }
 
 static int load_trailing_chunks(amh_ctx* ctx, amh_batch* b, const amh_load_opts* opts);
 extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts) {
@@ -1049,6 +1076,7 @@ static void hydrate_obj(const DocRows& R, u64 root_obj, u8 root_type, std::strin
 extern "C" int amh_hydrate_json(const amh_batch* b, uint32_t doc, amh_bytes_out* out) {
   if (!b || doc >= b->B.n_docs || !out) return AMH_ERR_INVALID_ARG;
   if (b->status[doc]) return AMH_ERR_DOC_FAILED;
+  AMH_NEEDS_OPS(b, "amh_hydrate_json")
   if (!ensure_chg(b)) return AMH_ERR_DEVICE;
   const HostView& hv = b->hv;
   const BatchDev& B = b->B;
@@ -1100,6 +1128,7 @@ extern "C" void amh_u64_free(uint64_t* p) { free(p); }
 // ---------------------------------------------------------------------------------------------
 extern "C" int amh_debug_array(const amh_batch* b, const char* name, void* out, size_t cap, size_t* len) {
   if (!b || !name || !len) return AMH_ERR_INVALID_ARG;
+  AMH_NEEDS_OPS(b, "amh_debug_array")
   const BatchDev& B = b->B;
   size_t n = B.n_docs, T = (size_t)B.tot_rows + B.tot_dt, NC = B.tot_chg, NR = B.tot_rows, NS = B.tot_succ;
   struct Ent { const char* name; const void* p; size_t bytes; };
@@ -1563,6 +1592,8 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
 extern "C" int amh_merge_batch(amh_ctx* ctx, amh_batch* dst, const amh_batch* src, const uint32_t* dst_idx, const uint32_t* src_idx, size_t n_pairs) {
   if (!ctx || !dst || !src || dst == src || (n_pairs && (!dst_idx || !src_idx)) || n_pairs >= 0x7FFFFFFFull) { set_error(ctx, "amh_merge_batch: invalid argument"); return AMH_ERR_INVALID_ARG; }
   if (n_pairs == 0) return AMH_SUCCESS;
+  AMH_NEEDS_OPS(dst, "amh_merge_batch")
+  AMH_NEEDS_OPS(src, "amh_merge_batch")
   // A document with queued changes (orphans waiting for their dependencies) goes through the apply path, which offers
   // the queue again once the source's changes are in, as the reference's merge does (automerge.rs:821-825, 938).
   if (!dst->queue.empty()) {
@@ -1797,6 +1828,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   u32 P = (u32)items.size();
   results.assign(P, 0);
   if (P == 0) return AMH_SUCCESS;
+  AMH_NEEDS_OPS(dst, who)
   PhaseTimer pt(who);
   // the host view of dst's history (hashes, deps, actors: ~100 bytes per change) comes back on a helper thread while
   // this one splits, stages and decodes the incoming chunks; it is first needed by the decisions further down
@@ -2572,6 +2604,7 @@ extern "C" int amh_doc_queue_len(const amh_batch* b, uint32_t doc, size_t* n) {
 }
 extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch* bc, const amh_save_opts* opts, amh_bytes_out* out) {
   if (!ctx || !bc || !out) { set_error(ctx, "invalid argument"); return AMH_ERR_INVALID_ARG; }
+  AMH_NEEDS_OPS(bc, "amh_save_batch")
   amh_batch* b = const_cast<amh_batch*>(bc);
   BatchDev B = b->B;
   u32 n = B.n_docs;

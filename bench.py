@@ -120,9 +120,14 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
         stats = []
         for k, (lo, hi) in enumerate(bounds):
             ids = list(range(hi - lo))
-            batches = [eng.load_staged(s) for s in staged[k]]
-            if keep_stats:   # per-batch counts of the source loads for the byte model (before the merge replaces batch 0)
-                stats.append([(b.stats(), column_bytes(eng, b, hi - lo)) for b in batches])
+            batches = []
+            for r, s in enumerate(staged[k]):
+                batches.append(eng.load_staged(s))   # every replica is loaded and verified in full
+                if keep_stats:   # per-batch counts of the source loads for the byte model (before the merge replaces batch 0)
+                    stats.append([]) if r == 0 else None
+                    stats[-1].append((batches[-1].stats(), column_bytes(eng, batches[-1], hi - lo)))
+                if r and not args.sequential_merges:
+                    batches[-1].release_ops()       # a merge source is read for its history only: its op rows go back to the pool
             if args.sequential_merges:
                 for r in range(1, R):
                     rc = batches[0].merge(batches[r], [(i, i) for i in ids])
@@ -477,7 +482,7 @@ def main():
     ap.add_argument("--workload", default="merge", choices=["merge", "load", "bigdoc", "sync", "apply"],
                     help="merge = configs[2] (the headline line: BASELINE.json quotes the metric on it): 10k text documents x 8 divergent replicas, "
                          "load 8 + merge 7; load = configs[1]: 100k JSON-map documents; bigdoc = configs[3]: one 10M-op text document")
-    ap.add_argument("--slice", type=int, default=2500, help="merge workload: documents streamed through the pipeline at a time")
+    ap.add_argument("--slice", type=int, default=10000, help="merge workload: documents streamed through the pipeline at a time")
     ap.add_argument("--ops", type=int, default=10000000, help="bigdoc workload: ops of the document")
     ap.add_argument("--replicas", type=int, default=8)
     ap.add_argument("--sequential-merges", action="store_true", help="merge workload: R-1 amh_merge_batch calls instead of one amh_merge_many")

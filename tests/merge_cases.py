@@ -51,6 +51,20 @@ def check_merge_many(engine, reps):
     n_rep, n_docs = len(reps), len(reps[0])
     bd = engine.load_batch(reps[0])
     others = [engine.load_batch(reps[r]) for r in range(1, n_rep)]
+    live0 = engine.pool_bytes()[0]
+    for k, ob in enumerate(others):
+        if k % 2 == 0:     # half of the sources give their op rows back first: the merge only reads their history
+            want = (ob.get_heads(0), [c["hash"] for c in ob.get_changes(0)])
+            ob.release_ops()
+            assert (ob.get_heads(0), [c["hash"] for c in ob.get_changes(0)]) == want
+            try:
+                ob.hydrate_json(0)
+                raise AssertionError("hydrate of a released batch must fail")
+            except AssertionError:
+                raise
+            except Exception:
+                pass
+    assert engine.pool_bytes()[0] < live0
     src_idx = [[i for i in range(n_docs)] for _ in range(n_rep - 1)]
     if n_docs > 1 and n_rep > 2:
         src_idx[1][1] = None
