@@ -43,7 +43,8 @@ EXPORTS = [
     "amh_changes", "amh_hydrate_json", "amh_doc_max_op", "amh_merge_batch", "amh_apply_changes", "amh_save_batch",
     "amh_sync_summaries", "amh_ctx_set_profiling", "amh_ctx_num_kernels", "amh_ctx_kernel_name", "amh_ctx_kernel_time",
     "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free", "amh_apply_batch", "amh_doc_queue_len", "amh_merge_many", "amh_save_after",
-    "amh_sync_summaries_noalloc", "amh_ctx_pool_bytes", "amh_ctx_set_limits", "amh_batch_release_ops",
+    "amh_sync_summaries_noalloc", "amh_ctx_pool_bytes", "amh_ctx_set_limits", "amh_batch_release_ops", "amh_comm_unique_id", "amh_comm_init", "amh_sync_summaries_all",
+    "amh_partition_docs",
 ]
 
 DOC_ERRORS = {
@@ -87,6 +88,10 @@ def bind(lib):
     lib.amh_ctx_pool_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.amh_ctx_set_limits.argtypes = [vp, C.c_uint64, C.c_uint64]
     lib.amh_batch_release_ops.argtypes = [vp, vp]
+    lib.amh_comm_unique_id.argtypes = [C.c_char_p]
+    lib.amh_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    lib.amh_sync_summaries_all.argtypes = [vp, vp, C.POINTER(BytesOut), C.POINTER(C.c_size_t)]
+    lib.amh_partition_docs.argtypes = [C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]
     lib.amh_gen_map_docs.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                      C.POINTER(BytesOut), C.POINTER(C.POINTER(C.c_uint64))]
     lib.amh_gen_text_docs.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
@@ -188,6 +193,19 @@ class Batch:
 
     def __len__(self):
         return self.n
+
+    def sync_summaries_all(self):
+        """every rank's sync summaries on every rank (all-gather on device buffers inside the library, RCCL):
+        the list of per-rank record buffers"""
+        world = getattr(self.engine, "world", 1)
+        o = BytesOut()
+        offs = (C.c_size_t * (world + 1))()
+        rc = self.engine.lib.amh_sync_summaries_all(self.engine.ctx, self.h, C.byref(o), offs)
+        if rc != 0:
+            raise EngineError("amh_sync_summaries_all failed: " + self.engine._err())
+        raw = C.string_at(o.data, o.len)
+        self.engine.lib.amh_bytes_free(C.byref(o))
+        return [raw[offs[r]:offs[r + 1]] for r in range(world)]
 
     def release_ops(self):
         """keep the history (changes, hashes, heads), give the per-op arrays back to the pool: enough for a merge source"""
@@ -485,6 +503,28 @@ class Engine:
     # --- measurement -------------------------------------------------------------------------
     def set_profiling(self, on):
         self.lib.amh_ctx_set_profiling(self.ctx, 1 if on else 0)
+
+    # --- multi-GPU ---------------------------------------------------------------------------
+    def comm_unique_id(self):
+        """rank 0: the 128 bytes every rank passes to comm_init (hand them over with torch.distributed, MPI, a file)"""
+        buf = C.create_string_buffer(128)
+        if self.lib.amh_comm_unique_id(buf) != 0:
+            raise EngineError("amh_comm_unique_id failed: " + (self.lib.amh_last_error(None) or b"").decode())
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        if self.lib.amh_comm_init(self.ctx, unique_id, rank, world) != 0:
+            raise EngineError("amh_comm_init failed: " + self._err())
+        self.world = world
+
+    def partition_docs(self, lens, world):
+        """per-rank document ranges of about equal encoded bytes: first[k] .. first[k + 1]"""
+        n = len(lens)
+        arr = (C.c_size_t * max(1, n))(*lens)
+        first = (C.c_size_t * (world + 1))()
+        if self.lib.amh_partition_docs(arr, n, world, first) != 0:
+            raise ValueError("amh_partition_docs: invalid argument")
+        return list(first)
 
     def set_limits(self, max_doc_rows=0, max_batch_bytes=0):
         """per-document row limit and per-batch byte budget of the derived device arrays (0 = defaults): documents over

@@ -18,6 +18,9 @@
 #include "../../include/automerge_hip.h"
 #include "amh_ingest.h"
 #include "amh_launch.h"
+#ifndef AMH_EMU
+#include "amh_comm.h"
+#endif
 #include "amh_rt.h"
 #include "amh_types.h"
 
@@ -95,6 +98,7 @@ struct amh_ctx {
   bool profiling = false;
   // limits (amh_ctx_set_limits): a document over the per-document limit, or the largest documents of a batch whose
   // derived arrays would not fit the byte budget, fail with AMH_DOC_TOO_LARGE and the rest of the batch goes on
+  struct AmhComm* comm = nullptr;   // RCCL communicator of this process's rank (amh_comm_init); none = single GPU
   u32 max_doc_rows = AMH_MAX_ROWS_PER_DOC;
   u64 max_batch_bytes = 0;   // 0 = what the device has free (plus what the pool holds) when the batch is sized
   double kernel_ms[AK_NUM + MK_NUM] = {0};      // load / save kernels, then the merge / apply kernels
@@ -123,6 +127,7 @@ struct amh_staged {
   size_t arena_bytes = 0;         // bytes of the arena (host and device copies alike)
   bool host_ok = true;            // h_arena is filled (arenas assembled on the device fetch it on first use)
   bool single_chunk = false;      // every input is exactly one document chunk (arenas assembled by merge / apply)
+  bool internal = false;          // the chunks were written by the engine for its own reload: they carry no checksum
   int refs = 1;
 };
 // host copy of an arena that was assembled on the device (merge / apply results): fetched when an accessor needs bytes
@@ -491,6 +496,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   B.n_docs = n;
   B.check_heads = opts ? (opts->verify_heads != 0) : 1;
   B.max_doc_rows = ctx->max_doc_rows;
+  B.skip_doc_sha = st->internal ? 1 : 0;
   B.arena = (const u8*)st->d_arena.p;
   B.doc_off = (const u64*)st->d_doc_off.p;
   bool ok = true;
@@ -747,6 +753,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   }
   if (!big.docs.empty() && !rt_sync(ctx->stream)) return fail("device pipeline failed");
   B.sha_host_min = 0;   // a property of this load, not of the batch (merge / save run the kernels with settings of their own)
+  B.skip_doc_sha = 0;
   collect_profile(ctx);
   // change chunks: a first chunk that is a change, and everything behind the first chunk (automerge.rs:657-695)
   if (trailing && load_trailing_chunks(ctx, b, opts) != AMH_SUCCESS) { amh_batch_free(b); return nullptr; }
@@ -1495,6 +1502,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   M.sv_out = balloc<u8>(mb, (size_t)sv_total + 256, &ok);
   if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
   launch(ctx, AK_SAVE_STORE, M, P * 25);
+  M.skip_doc_sha = 1;   // these chunks only feed the reload below (a later save re-encodes from the rows)
   launch(ctx, AK_SAVE_FINISH, M, P);
   pt.mark("exec: save kernels", &ctx->stream);
   std::vector<u32> sv_off(P + 1), sv_body(P);
@@ -1539,6 +1547,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   {
     auto* st = new amh_staged();
     st->ctx = ctx; st->n_docs = nd; st->host_ok = false; st->single_chunk = true;
+    st->internal = true;
     st->arena_bytes = (size_t)off + 256;
     st->h_doc_off = se;
     st->d_arena.p = ctx->pool.alloc(st->arena_bytes, &st->d_arena.cap);
@@ -2696,6 +2705,109 @@ extern "C" int amh_sync_summaries(amh_ctx* ctx, const amh_batch* bc, amh_bytes_o
 // The same records written into the caller's device buffer, with nothing allocated on the host or the device: no pool,
 // no event, no copy to the host (include/automerge_hip.h).  Returns when the kernels are queued on the context's stream
 // and waits for them (hipStreamSynchronize allocates nothing), so d_out / d_meta are complete on return.
+// == the exchange step of the sync path across GPUs: every rank's summaries, gathered on every rank.
+// The collective runs on device buffers (RCCL over xGMI): sizes by one all-gather of a u64 per rank, the records by an
+// all-gather(v) into one device buffer, which then comes to the host once.  rank_off[world + 1] = where each rank's
+// records start in out.  Without a communicator (single GPU) this is amh_sync_summaries with rank_off = {0, len}.
+extern "C" int amh_sync_summaries_all(amh_ctx* ctx, const amh_batch* bc, amh_bytes_out* out, size_t* rank_off) {
+  if (!ctx || !bc || !out || !rank_off) { set_error(ctx, "invalid argument"); return AMH_ERR_INVALID_ARG; }
+#ifdef AMH_EMU
+  int rc0 = amh_sync_summaries(ctx, bc, out);
+  rank_off[0] = 0; rank_off[1] = out->len;
+  return rc0;
+#else
+  if (!ctx->comm) {
+    int rc0 = amh_sync_summaries(ctx, bc, out);
+    rank_off[0] = 0; rank_off[1] = out->len;
+    return rc0;
+  }
+  amh_batch* b = const_cast<amh_batch*>(bc);
+  BatchDev B = b->B;
+  const u32 n = B.n_docs;
+  const int world = amh_comm_world(ctx->comm), rank = amh_comm_rank(ctx->comm);
+  out->data = nullptr; out->len = 0;
+  bool ok = true;
+  CallScratch scratch(b);
+  u32 total = 0;
+  B.sync_off = balloc<u32>(b, (size_t)n + 2, &ok);
+  if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  if (n) {
+    launch(ctx, AK_SYNC_SIZE, B, n);
+    if (!scan_inplace(b, B.sync_off, n, &total)) { set_error(ctx, "scan failed"); return AMH_ERR_DEVICE; }
+    if (total == 0xFFFFFFFFu) { set_error(ctx, "sync summaries exceed 4 GiB"); return AMH_ERR_BATCH_TOO_LARGE; }
+  }
+  B.sync_out = balloc<u8>(b, (size_t)total + 64, &ok);
+  u64* d_sizes = balloc<u64>(b, (size_t)world + 1, &ok);
+  if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  if (n) launch(ctx, AK_SYNC_FILL, B, n);
+  std::vector<u64> sizes(world, 0), offs(world + 1, 0);
+  u64 mine = total;
+  if (!rt_h2d(d_sizes + world, &mine, sizeof(u64), ctx->stream)) { set_error(ctx, "H2D copy failed"); return AMH_ERR_DEVICE; }
+  const char* e = amh_comm_allgather_u64(ctx->comm, d_sizes + world, d_sizes, (void*)ctx->stream);
+  if (e) { set_error(ctx, std::string("amh_sync_summaries_all: all-gather of the sizes failed: ") + e); return AMH_ERR_DEVICE; }
+  if (!rt_d2h(sizes.data(), d_sizes, (size_t)world * sizeof(u64), ctx->stream) || !rt_sync(ctx->stream)) { set_error(ctx, "D2H copy failed"); return AMH_ERR_DEVICE; }
+  if (sizes[rank] != total) { set_error(ctx, "amh_sync_summaries_all: the communicator's rank does not match this context"); return AMH_ERR_DEVICE; }
+  for (int r = 0; r < world; r++) offs[r + 1] = offs[r] + ((sizes[r] + 15) & ~(u64)15);   // 16-byte aligned slots in the device buffer
+  u8* d_all = balloc<u8>(b, (size_t)offs[world] + 64, &ok);
+  if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  e = amh_comm_allgatherv(ctx->comm, B.sync_out, d_all, sizes.data(), offs.data(), (void*)ctx->stream);
+  if (e) { set_error(ctx, std::string("amh_sync_summaries_all: all-gather failed: ") + e); return AMH_ERR_DEVICE; }
+  u64 len = 0;
+  for (int r = 0; r < world; r++) { rank_off[r] = (size_t)len; len += sizes[r]; }
+  rank_off[world] = (size_t)len;
+  out->data = (uint8_t*)malloc(len ? (size_t)len : 1);
+  if (!out->data) return AMH_ERR_OOM;
+  for (int r = 0; r < world; r++)
+    if (sizes[r] && !rt_d2h(out->data + rank_off[r], d_all + offs[r], (size_t)sizes[r], ctx->stream)) { free(out->data); out->data = nullptr; set_error(ctx, "D2H copy failed"); return AMH_ERR_DEVICE; }
+  if (!rt_sync(ctx->stream)) { free(out->data); out->data = nullptr; set_error(ctx, "device pipeline failed"); return AMH_ERR_DEVICE; }
+  out->len = (size_t)len;
+  collect_profile(ctx);
+  return AMH_SUCCESS;
+#endif
+}
+extern "C" int amh_comm_unique_id(uint8_t* id128) {
+  if (!id128) return AMH_ERR_INVALID_ARG;
+#ifdef AMH_EMU
+  memset(id128, 0, 128);
+  return AMH_SUCCESS;
+#else
+  const char* e = amh_comm_make_id(id128);
+  if (e) { set_error(nullptr, std::string("amh_comm_unique_id: ") + e); return AMH_ERR_DEVICE; }
+  return AMH_SUCCESS;
+#endif
+}
+extern "C" int amh_comm_init(amh_ctx* ctx, const uint8_t* id128, int rank, int world) {
+  if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) { set_error(ctx, "amh_comm_init: invalid argument"); return AMH_ERR_INVALID_ARG; }
+#ifdef AMH_EMU
+  if (world != 1) { set_error(ctx, "amh_comm_init: the emulation build has no collective"); return AMH_ERR_DEVICE; }
+  return AMH_SUCCESS;
+#else
+  if (ctx->comm) { amh_comm_close(ctx->comm); ctx->comm = nullptr; }
+  const char* e = nullptr;
+  ctx->comm = amh_comm_open(id128, rank, world, ctx->device, &e);
+  if (!ctx->comm) { set_error(ctx, std::string("amh_comm_init: ") + (e ? e : "failed")); return AMH_ERR_DEVICE; }
+  return AMH_SUCCESS;
+#endif
+}
+// == the byte-balanced prefix split of SURVEY.md 8e: documents are independent, so a rank takes a contiguous range; the
+// ranges are cut where the running byte count crosses k / world of the total (load time follows the encoded bytes, not
+// the document count).  first[world + 1]: rank k loads documents [first[k], first[k + 1]).
+extern "C" int amh_partition_docs(const size_t* lens, size_t n, int world, size_t* first) {
+  if ((n && !lens) || world < 1 || !first) return AMH_ERR_INVALID_ARG;
+  unsigned __int128 total = 0;
+  for (size_t i = 0; i < n; i++) total += lens[i];
+  size_t i = 0;
+  unsigned __int128 run = 0;
+  first[0] = 0;
+  for (int k = 1; k < world; k++) {
+    unsigned __int128 want = total * (unsigned)k / (unsigned)world;
+    // a document goes to the rank in whose share its middle byte falls
+    while (i < n && run + lens[i] / 2 < want) run += lens[i++];
+    first[k] = i;
+  }
+  first[world] = n;
+  return AMH_SUCCESS;
+}
 extern "C" int amh_sync_summaries_noalloc(amh_ctx* ctx, const amh_batch* b, uint8_t* d_out, size_t cap, uint32_t* d_meta) {
   if (!ctx || !b || !d_meta || (cap && !d_out)) { set_error(ctx, "invalid argument"); return AMH_ERR_INVALID_ARG; }
 #ifdef AMH_EMU
@@ -2743,6 +2855,9 @@ extern "C" void amh_ctx_destroy(amh_ctx* ctx) {
   rt_sync(ctx->side);
   ctx->pool.trim();
   if (ctx->stage) rt_host_free(ctx->stage);
+#ifndef AMH_EMU
+  if (ctx->comm) { amh_comm_close(ctx->comm); ctx->comm = nullptr; }
+#endif
   rt_event_destroy(&ctx->ev_fork);
   rt_event_destroy(&ctx->ev_fork2);
   rt_event_destroy(&ctx->ev_join);

@@ -283,7 +283,7 @@ AMH_DEV void k_parse(const BatchDev& B, u32 d) {
 AMH_DEV void k_sha_doc(const BatchDev& B, u32 d) {
   if (B.sha_gate ? B.sha_gate[d] : B.status[d]) return;
   const DocDesc& D = B.desc[d];
-  if (D.chunk_len == 0) return;
+  if (D.chunk_len == 0 || B.skip_doc_sha) return;
   if (B.sha_host_min && D.chunk_len >= B.sha_host_min) return;   // the host hashes this one (amh_host.cpp, BigSha)
   const u8* p = B.arena + D.chunk_off;
   // type byte + uleb(len) exactly as stored (strict parse => canonical) and the data: one contiguous range
@@ -2100,6 +2100,7 @@ AMH_DEV void k_save_finish(const BatchDev& B, u32 d) {
   out[0] = 0x85; out[1] = 0x6f; out[2] = 0x4a; out[3] = 0x83;
   out[8] = 0;
   wr_uleb(out + 9, body_len);
+  if (B.skip_doc_sha) { out[4] = out[5] = out[6] = out[7] = 0; return; }   // read back by the engine only (merge / apply reload)
   if (B.sha_host_min && hdr + body_len >= B.sha_host_min) return;   // large chunk: the host, which receives the bytes anyway, hashes it (amh_save_batch)
   u8 h[32];
   sha256_contig(out + 8, (u64)(hdr - 8) + body_len, h);

@@ -352,12 +352,16 @@ def bench_sync(args, eng, rank, world, dist, torch, red_dev):
 
     gathered_bytes = 0
 
+    use_comm = dist is not None and dist.get_backend() == "nccl"   # RCCL inside the library; gloo rehearsals gather through torch
+    if use_comm:
+        amd_dist.init_engine_comm(eng)
+
     def step():
         nonlocal gathered_bytes
         b = eng.load_staged(staged)
-        raw = b.sync_summaries_raw()
+        raw = None if use_comm else b.sync_summaries_raw()
         if dist is not None:
-            parts = amd_dist.all_gather_summaries(raw)
+            parts = b.sync_summaries_all() if use_comm else amd_dist.all_gather_summaries(raw)
             gathered_bytes = sum(len(x) for x in parts)
         else:
             gathered_bytes = len(raw)

@@ -121,6 +121,18 @@ const char* amh_last_error(const amh_ctx*);   /* message of the last failed call
  * An input is what the reference's load accepts: a document chunk, optionally followed by change chunks
  * (save_incremental output), or change chunks alone; the change chunks go through the apply path with the
  * reference's policies (MissingDeps when the first chunk is not a document, on_partial_load). */
+/* Multi-GPU: one process and one context per GPU.  Load, merge, apply and save shard by document and
+ * need no collective: amh_partition_docs cuts a batch into per-rank ranges of equal encoded bytes.  The one exchange
+ * step of the path, the all-gather of sync summaries (what the reference's sync server keeps per peer, sync.rs:243-250),
+ * runs inside the library on device buffers through RCCL over xGMI: amh_comm_unique_id on rank 0, the 128 bytes handed
+ * to every rank out of band (torch.distributed, MPI, a file), amh_comm_init on every rank, then
+ * amh_sync_summaries_all.  rank_off[world + 1] receives where each rank's records start in out. */
+#define AMH_COMM_ID_BYTES 128
+int amh_comm_unique_id(uint8_t* id128);
+int amh_comm_init(amh_ctx*, const uint8_t* id128, int rank, int world);
+int amh_sync_summaries_all(amh_ctx*, const amh_batch*, amh_bytes_out* out, size_t* rank_off);
+int amh_partition_docs(const size_t* lens, size_t n, int world, size_t* first);
+
 /* Limits against hostile inputs (no counterpart in the reference, which loads one document at a time and loses only
  * that document): a document whose op rows, succ entries, changes or deps exceed max_doc_rows (0 = the built-in
  * 2^28), and the largest documents of a batch whose derived device arrays would exceed max_batch_bytes (0 = what the

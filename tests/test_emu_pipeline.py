@@ -319,3 +319,17 @@ def test_hostile_documents_fail_alone(emu):
     blob, offs = emu.gen_text_docs(78, 1, 1, 50, 2000, 100, 1)
     good.append(bytes(blob[offs[0]:offs[1]]))
     adv.check_hostile_documents(emu, good, 100000, 50000)
+
+
+def test_partition_docs_balances_bytes(emu):
+    """amh_partition_docs: contiguous ranges, every document in exactly one, byte load within one document of even"""
+    import random
+    rng = random.Random(3)
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 5, 1000):
+            lens = [rng.randint(1, 5000) if rng.random() < 0.9 else rng.randint(50000, 200000) for _ in range(n)]
+            first = emu.partition_docs(lens, world)
+            assert first[0] == 0 and first[-1] == n and all(first[k] <= first[k + 1] for k in range(world))
+            if n:
+                loads = [sum(lens[first[k]:first[k + 1]]) for k in range(world)]
+                assert max(loads) <= sum(lens) / world + max(lens)

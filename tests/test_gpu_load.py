@@ -183,6 +183,23 @@ def test_sync_summaries(engine, golden_dir):
         assert rec["bloom"] == ref.bloom()
 
 
+def test_sync_summaries_through_the_library_collective(golden_dir):
+    """amh_sync_summaries_all over a one-rank RCCL communicator (what a box with one GPU can run): sizes all-gather,
+    all-gather(v) on device buffers, one copy to the host; equals amh_sync_summaries.  More ranks: tests/test_dist_gloo.py
+    rehearses the host-side route on CPU, the driver's multi-GPU run the RCCL one."""
+    from automerge_amd import Engine
+    eng = Engine(gpu=0)
+    docs = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(golden_dir, "docs", "*.automerge")))] + [b"\x85\x6f\x4a\x83junk"]
+    b = eng.load_batch(docs)
+    want = b.sync_summaries_raw()
+    assert b.sync_summaries_all() == [want]          # no communicator yet: the local records
+    eng.comm_init(eng.comm_unique_id(), 0, 1)
+    assert b.sync_summaries_all() == [want]
+    empty = eng.load_batch([])
+    assert empty.sync_summaries_all() == [b""]
+    b.close(); empty.close(); eng.close()
+
+
 @pytest.mark.parametrize("form", ["auto", "seg", "lane"])
 def test_save(engine, golden_dir, monkeypatch, form):
     """(both forms of the save kernels: wave per (document, column group) / lane per document)
