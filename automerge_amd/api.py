@@ -119,7 +119,7 @@ def load_library(path=None):
     return bind(C.CDLL(path))
 
 
-def _share_torch_hip_runtime():
+def _share_torch_hip_runtime(names=("libhsa-runtime64.so", "libamdhip64.so")):
     """One HIP runtime per process.  The PyTorch ROCm wheel carries its own libamdhip64.so.7 / libhsa-runtime64.so.1; if
     this library is loaded first it pulls in /opt/rocm's copies, and a later `import torch` in the same process then
     finds no GPU.  Loading the wheel's copies first (same sonames, so this library's DT_NEEDED entries bind to them) makes
@@ -134,7 +134,7 @@ def _share_torch_hip_runtime():
     if spec is None or not spec.submodule_search_locations:
         return
     libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
-    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+    for name in names:
         cand = os.path.join(libdir, name)
         if os.path.exists(cand):
             try:
@@ -422,12 +422,43 @@ class Staged:
             pass
 
 
+def _torch_first():
+    """The library opens librccl.so.1 by name on first use.  Where a PyTorch ROCm wheel is installed its RCCL (and what
+    that pulls in) must be loaded by `import torch` itself, not piecemeal before it: RCCL loaded on its own and torch
+    imported afterwards ends in a double free at process exit.  Multi-GPU callers hand the communicator id around with
+    torch.distributed anyway, so importing torch here costs them nothing."""
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+
+
+_live_engines = weakref.WeakSet()
+
+
+def _close_engines_at_exit():
+    """Contexts are destroyed while the HIP runtime (and RCCL, if it was opened) are still up: the interpreter runs this
+    before any library's own exit handlers, whereas a context freed by garbage collection during shutdown may come after
+    them."""
+    for e in list(_live_engines):
+        try:
+            e.close()
+        except Exception:
+            pass
+
+
+import atexit  # noqa: E402
+atexit.register(_close_engines_at_exit)
+
+
 class Engine:
     """One context = one GPU (amh_ctx)."""
 
     def __init__(self, gpu=0, lib=None):
         self.lib = lib if lib is not None else load_library()
         self._children = weakref.WeakSet()   # batches and staged inputs: they hold handles into the context
+        _live_engines.add(self)
         ids = (C.c_int * 1)(gpu)
         self.ctx = self.lib.amh_ctx_create(ids, 1)
         if not self.ctx:
@@ -507,12 +538,14 @@ class Engine:
     # --- multi-GPU ---------------------------------------------------------------------------
     def comm_unique_id(self):
         """rank 0: the 128 bytes every rank passes to comm_init (hand them over with torch.distributed, MPI, a file)"""
+        _torch_first()
         buf = C.create_string_buffer(128)
         if self.lib.amh_comm_unique_id(buf) != 0:
             raise EngineError("amh_comm_unique_id failed: " + (self.lib.amh_last_error(None) or b"").decode())
         return buf.raw
 
     def comm_init(self, unique_id, rank, world):
+        _torch_first()
         if self.lib.amh_comm_init(self.ctx, unique_id, rank, world) != 0:
             raise EngineError("amh_comm_init failed: " + self._err())
         self.world = world

@@ -95,6 +95,8 @@ struct amh_ctx {
   // every call, and the H2D copy of the change chunks runs at the pinned rate
   u8* stage = nullptr;
   size_t stage_cap = 0;
+  u8* pin[2] = {nullptr, nullptr};   // pinned staging buffers of amh_stage_batch (double-buffered H2D), kept for the context's life
+  rt_event ev_pin[2]{};
   bool profiling = false;
   // limits (amh_ctx_set_limits): a document over the per-document limit, or the largest documents of a batch whose
   // derived arrays would not fit the byte budget, fail with AMH_DOC_TOO_LARGE and the rest of the batch goes on
@@ -272,6 +274,8 @@ static bool scan_inplace(amh_batch* b, u32* data, u32 n, u32* total) {
 // ---------------------------------------------------------------------------------------------
 // stage: host ingest + one H2D copy
 // ---------------------------------------------------------------------------------------------
+// inputs of this size and more have their SHA-256 taken by host threads (see BigSha below)
+#define AMH_HOST_SHA_MIN (256u << 10)
 extern "C" amh_staged* amh_stage_batch(amh_ctx* ctx, const uint8_t* const* docs, const size_t* lens, size_t n) {
   if (!ctx || (n && (!docs || !lens)) || n >= 0x7FFFFFFFull) { set_error(ctx, "invalid argument"); return nullptr; }
   auto* st = new amh_staged();
@@ -299,32 +303,69 @@ extern "C" amh_staged* amh_stage_batch(amh_ctx* ctx, const uint8_t* const* docs,
     off = (off + 15) & ~(u64)15;  // 16-byte aligned chunk starts: wide loads in the streaming kernels
   }
   st->h_doc_off[n] = off;
-  st->h_arena.assign(off + 256, 0);  // tail padding: the staged decoders read whole windows
-  {
-    std::vector<std::thread> ts;
-    for (unsigned t = 0; t < nthreads; t++)
-      ts.emplace_back([&, t]() {
-        for (size_t i = t; i < n; i += nthreads) {
-          const uint8_t* src = changed[i] ? rewritten[i].data() : docs[i];
-          size_t l = changed[i] ? rewritten[i].size() : lens[i];
-          if (l) memcpy(st->h_arena.data() + st->h_doc_off[i], src, l);
-        }
-      });
-    for (auto& th : ts) th.join();
-  }
   // document i occupies [doc_off[i], doc_off[i] + len_i); the kernels need the exact length, so the
   // offsets table carries 2 entries per document: start and end
   std::vector<u64> se(2 * n + 2);
+  bool any_large = false;
   for (size_t i = 0; i < n; i++) {
+    size_t l = changed[i] ? rewritten[i].size() : lens[i];
     se[2 * i] = st->h_doc_off[i];
-    se[2 * i + 1] = st->h_doc_off[i] + (changed[i] ? rewritten[i].size() : lens[i]);
+    se[2 * i + 1] = st->h_doc_off[i] + l;
+    any_large = any_large || l >= AMH_HOST_SHA_MIN;
   }
-  st->arena_bytes = st->h_arena.size();
-  st->d_arena.p = ctx->pool.alloc(st->h_arena.size(), &st->d_arena.cap);
+  st->arena_bytes = (size_t)off + 256;   // tail padding: the staged decoders read whole windows
+  st->d_arena.p = ctx->pool.alloc(st->arena_bytes, &st->d_arena.cap);
   st->d_doc_off.p = ctx->pool.alloc(se.size() * sizeof(u64), &st->d_doc_off.cap);
   if (!st->d_arena.p || !st->d_doc_off.p) { set_error(ctx, "device out of memory while staging"); staged_unref(st); return nullptr; }
-  bool ok = rt_h2d(st->d_arena.p, st->h_arena.data(), st->h_arena.size(), ctx->stream) &&
-            rt_h2d(st->d_doc_off.p, se.data(), se.size() * sizeof(u64), ctx->stream) && rt_sync(ctx->stream);
+  // The bytes go to the device through two pinned buffers: while one is on its way over PCIe (async copy), the host
+  // threads fill the other.  No pageable copy, and no host-side mirror of the arena: accessors that need bytes on the
+  // host (actor ids, keys of a hydrate) fetch it on first use, except for batches with documents large enough for
+  // host-side SHA-256 (those threads read the mirror while the device pipeline runs).
+  const size_t PIN = (size_t)32 << 20;
+  for (int k = 0; k < 2; k++)
+    if (!ctx->pin[k]) {
+      ctx->pin[k] = (u8*)rt_host_alloc(PIN);
+      rt_event_create(&ctx->ev_pin[k]);
+      if (!ctx->pin[k]) { set_error(ctx, "out of pinned host memory while staging"); staged_unref(st); return nullptr; }
+    }
+  if (any_large) st->h_arena.assign(st->arena_bytes, 0);
+  st->host_ok = any_large;
+  bool ok = rt_h2d(st->d_doc_off.p, se.data(), se.size() * sizeof(u64), ctx->stream);
+  const u64 total = (u64)off + 256;
+  size_t first_doc = 0;   // first document that reaches into the current piece
+  int piece = 0;
+  bool pending[2] = {false, false};
+  for (u64 c0 = 0; c0 < total && ok; c0 += PIN, piece++) {
+    const u64 c1 = std::min<u64>(total, c0 + PIN);
+    const int k = piece & 1;
+    u8* buf = ctx->pin[k];
+    if (pending[k]) rt_event_sync(&ctx->ev_pin[k]);   // the copy that last read this buffer is done
+    while (first_doc < n && (first_doc + 1 < n ? se[2 * (first_doc + 1)] : total) <= c0) first_doc++;   // its bytes and the gap behind them lie in front of the piece
+    size_t last_doc = first_doc;
+    while (last_doc < n && se[2 * last_doc] < c1) last_doc++;
+    auto fill = [&](size_t i) {   // document i's bytes and the zero gap behind them, clipped to [c0, c1)
+      const uint8_t* src = changed[i] ? rewritten[i].data() : docs[i];
+      const u64 s0 = se[2 * i], s1 = se[2 * i + 1], g1 = i + 1 < n ? se[2 * (i + 1)] : total;
+      u64 lo = std::max(s0, c0), hi = std::min(s1, c1);
+      if (lo < hi) memcpy(buf + (lo - c0), src + (lo - s0), (size_t)(hi - lo));
+      lo = std::max(s1, c0); hi = std::min(g1, c1);
+      if (lo < hi) memset(buf + (lo - c0), 0, (size_t)(hi - lo));
+    };
+    const size_t nd = last_doc - first_doc;
+    if (n == 0) memset(buf, 0, (size_t)(c1 - c0));
+    else if (nd < 64 || nthreads == 1) { for (size_t i = first_doc; i < last_doc; i++) fill(i); }
+    else {
+      std::vector<std::thread> ts;
+      for (unsigned t = 0; t < nthreads; t++)
+        ts.emplace_back([&, t]() { for (size_t i = first_doc + t; i < last_doc; i += nthreads) fill(i); });
+      for (auto& th : ts) th.join();
+    }
+    if (any_large) memcpy(st->h_arena.data() + c0, buf, (size_t)(c1 - c0));
+    ok = rt_h2d((u8*)st->d_arena.p + c0, buf, (size_t)(c1 - c0), ctx->stream);
+    rt_event_record(&ctx->ev_pin[k], ctx->stream);
+    pending[k] = true;
+  }
+  ok = ok && rt_sync(ctx->stream);
   if (!ok) { set_error(ctx, std::string("H2D copy failed: ") + rt_last_error()); staged_unref(st); return nullptr; }
   // keep exact ends on the host too
   st->h_doc_off.resize(2 * n + 2);
@@ -377,7 +418,6 @@ extern "C" amh_batch* amh_load_staged(amh_ctx* ctx, const amh_staged* st_c, cons
 // it 10-50x faster.  The first chunk of inputs of AMH_HOST_SHA_MIN bytes and more is therefore hashed by host threads
 // out of the staged host copy WHILE the device pipeline runs (k_sha_doc skips those chunks); the verdict is applied
 // with the statuses.  Batches of small documents never come here: their hashes are data-parallel on the device.
-#define AMH_HOST_SHA_MIN (256u << 10)
 struct BigSha {
   std::vector<u32> docs;
   std::vector<u8> bad, hash;   // per entry of docs
@@ -515,6 +555,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   };
   B.status = balloc<i32>(b, n + 1, &ok);
   B.fail_line = balloc<u32>(b, n + 1, &ok);
+  B.first_len = trailing ? balloc<u32>(b, n + 1, &ok) : nullptr;
   B.desc = balloc<DocDesc>(b, n + 1, &ok);
   B.cnt = balloc<DocCounts>(b, n + 1, &ok);
   u32** bases[8] = {&B.row_base, &B.succ_base, &B.chg_base, &B.dep_base, &B.actor_base, &B.ht_base, &B.dt_base, &B.map_base};
@@ -2422,11 +2463,20 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
 static int load_trailing_chunks(amh_ctx* ctx, amh_batch* b, const amh_load_opts* opts) {
   const amh_staged* st = b->staged;
   std::vector<ApplyItem> items;
+  // where every input's first chunk ends comes from the parse kernel (4 bytes per document): the host only needs the
+  // input bytes of the few documents that have something behind it
+  std::vector<u32> first_len(b->B.n_docs);
+  if (b->B.n_docs && (!b->B.first_len || !rt_d2h(first_len.data(), b->B.first_len, (size_t)b->B.n_docs * sizeof(u32), ctx->stream) || !rt_sync(ctx->stream))) return AMH_ERR_DEVICE;
+  bool any = false;
+  for (u32 d = 0; d < b->B.n_docs && !any; d++)
+    any = !b->status[d] && first_len[d] != (u32)(st->h_doc_off[2 * (size_t)d + 1] - st->h_doc_off[2 * (size_t)d]);
+  if (!any) return AMH_SUCCESS;
+  if (!ensure_host_arena(st)) return AMH_ERR_DEVICE;
   for (u32 d = 0; d < b->B.n_docs; d++) {
     if (b->status[d]) continue;
     const u8* ptr = st->h_arena.data() + st->h_doc_off[2 * (size_t)d];
     size_t avail = (size_t)(st->h_doc_off[2 * (size_t)d + 1] - st->h_doc_off[2 * (size_t)d]);
-    size_t fl = first_doc_chunk_len(ptr, avail);
+    size_t fl = first_len[d];
     if (fl == avail) continue;
     ApplyItem it;
     it.doc = d;
@@ -2858,6 +2908,7 @@ extern "C" void amh_ctx_destroy(amh_ctx* ctx) {
 #ifndef AMH_EMU
   if (ctx->comm) { amh_comm_close(ctx->comm); ctx->comm = nullptr; }
 #endif
+  for (int k = 0; k < 2; k++) if (ctx->pin[k]) { rt_host_free(ctx->pin[k]); rt_event_destroy(&ctx->ev_pin[k]); }
   rt_event_destroy(&ctx->ev_fork);
   rt_event_destroy(&ctx->ev_fork2);
   rt_event_destroy(&ctx->ev_join);

@@ -215,6 +215,19 @@ AMH_DEV void k_parse(const BatchDev& B, u32 d) {
   D.chunk_len = 0;
   D.data_off = D.data_len = 0;
   D.actors_off = D.heads_off = D.suffix_off = D.suffix_len = 0;
+  if (B.first_len) {   // where the first chunk ends, leniently (the host's rule for "is there anything behind it")
+    u64 fl = avail;
+    const u8* q = B.arena + start;
+    if (avail >= 10 && avail < 0xFFFFFFF0ull && q[0] == 0x85 && q[1] == 0x6f && q[2] == 0x4a && q[3] == 0x83) {
+      if (q[8] == 1 || q[8] == 2) fl = 0;
+      else if (q[8] == 0) {
+        u64 l = 0, ps = 9; u32 shift = 0; bool good = false;
+        while (ps < avail && shift <= 63) { u8 bb = q[ps++]; l |= (u64)(bb & 0x7f) << shift; if (!(bb & 0x80)) { good = true; break; } shift += 7; }
+        if (good && l <= avail - ps) fl = ps + l;
+      }
+    }
+    B.first_len[d] = (u32)(fl > 0xFFFFFFFFull ? 0xFFFFFFFFull : fl);
+  }
   if (avail == 0) return;  // empty input = empty document (automerge.rs:605-608)
   if (avail >= 0xFFFFFFF0ull) { amh_fail(B, d, AMH_E_TOO_LARGE); return; }
   const u8* p = B.arena + start;

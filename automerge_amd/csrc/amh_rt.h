@@ -25,6 +25,7 @@ inline bool rt_memset(void* d, int v, size_t n, rt_stream) { if (n) memset(d, v,
 inline bool rt_sync(rt_stream) { return true; }
 inline bool rt_mem_info(size_t* free_b, size_t* total_b) { *free_b = *total_b = (size_t)64 << 30; return true; }
 inline void rt_event_create(rt_event*) {}
+inline void rt_event_sync(rt_event*) {}
 inline void rt_event_destroy(rt_event*) {}
 inline void rt_event_record(rt_event* e, rt_stream) { e->t = std::chrono::steady_clock::now(); }
 inline float rt_event_ms(rt_event* a, rt_event* b) { return std::chrono::duration<float, std::milli>(b->t - a->t).count(); }
@@ -59,6 +60,7 @@ inline bool rt_memset(void* d, int v, size_t n, rt_stream s) { return n == 0 || 
 inline bool rt_sync(rt_stream s) { return hipStreamSynchronize(s) == hipSuccess; }
 inline bool rt_mem_info(size_t* free_b, size_t* total_b) { return hipMemGetInfo(free_b, total_b) == hipSuccess; }
 inline void rt_event_create(rt_event* e) { (void)hipEventCreate(&e->e); }
+inline void rt_event_sync(rt_event* e) { (void)hipEventSynchronize(e->e); }
 inline void rt_event_destroy(rt_event* e) { (void)hipEventDestroy(e->e); }
 inline void rt_event_record(rt_event* e, rt_stream s) { (void)hipEventRecord(e->e, s); }
 inline float rt_event_ms(rt_event* a, rt_event* b) { float ms = 0; (void)hipEventSynchronize(b->e); (void)hipEventElapsedTime(&ms, a->e, b->e); return ms; }

@@ -185,6 +185,8 @@ struct BatchDev {
   u32 sync_cap;                  // 0 = sync_out holds every record; else its capacity: records that end beyond it are not written
   // lists too long for the thread that owns them (more than AMH_BIG_LIST entries): the thread-per-item kernel records
   // them here and a block per list sorts them afterwards (amh_kernels.hip, g_big_*)
+  u32* first_len;                // [n_docs] bytes of the document chunk an input starts with (0: it starts with a change chunk; the input's
+                                 // length: nothing readable behind it) — what the host needs to know to find trailing change chunks
   u32 skip_doc_sha;              // chunks written by merge / apply for the engine's own reload: no checksum is written or checked
   u32 max_doc_rows;              // per-document limit on op rows / succ entries / changes / deps (amh_ctx_set_limits; default AMH_MAX_ROWS_PER_DOC)
   u32* big_n;                    // [1] recorded lists
