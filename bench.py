@@ -104,11 +104,13 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
     n_slices = max(1, (args.docs + args.slice - 1) // args.slice)
     bounds = [(k * args.docs // n_slices, (k + 1) * args.docs // n_slices) for k in range(n_slices)]
     t0 = time.time()
-    staged, enc_bytes, sample = [], 0, None
+    staged, enc_bytes, sample, t_stage = [], 0, None, 0.0
     for k, (lo, hi) in enumerate(bounds):   # generated and staged slice by slice: the host never holds more than one slice of inputs
         blob, offs = eng.gen_text_docs(0xB070 + rank * args.docs + lo, hi - lo, R, 1000, 5000, 500, threads)
         reps = [[blob[offs[i * R + r]:offs[i * R + r + 1]] for i in range(hi - lo)] for r in range(R)]
+        ts = time.perf_counter()
         staged.append([eng.stage(reps[r]) for r in range(R)])
+        t_stage += time.perf_counter() - ts
         enc_bytes += len(blob)
         if k == 0:
             sample = [[reps[r][i] for r in range(R)] for i in range(min(hi - lo, 256))]
@@ -210,6 +212,8 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
                           "docs_per_gpu": args.docs, "replicas": R, "ops_per_merged_doc": ops / args.docs, "encoded_bytes_per_gpu": enc_bytes,
                           "slices_per_step": n_slices, "docs_per_slice": args.slice, "sharding": f"documents x{world} (replicas of a document co-located)",
                           "merge_call": "sequential amh_merge_batch" if args.sequential_merges else "amh_merge_many", "gen_s": round(t_gen, 2),
+                          "stage_s": round(t_stage, 3),   # host bytes -> HBM through the pinned double buffer (amh_stage_batch), outside the timed region
+                          "pcie_inclusive_ops_per_s": ops_all / (elapsed_max / args.steps + t_stage),
                           "note": "ops counted once per merged document; every merged document is re-derived and re-verified (change hashes, heads) before it replaces the old one"},
                "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "traffic": traffic, "algorithmic_bytes_per_launch": model[dom] / dom_calls, "launch_ms": dom_ms / dom_calls,
