@@ -91,6 +91,34 @@ def column_bytes(eng, batch, n_docs):
     }
 
 
+def pmc_traffic(workload, dom):
+    """HBM bytes per launch of kernel `dom` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/traffic_<workload>.json, tools/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE, separate passes); None when
+    the file is missing.  A bench kernel name may cover several device kernels (forms chosen per batch): the launches of
+    all of them are averaged together."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", f"traffic_{workload}.json")))
+        if tj.get("workload") != workload:
+            return None
+        forms = {"decode_ops": ["g_decode_seg(BatchDev)"], "count": ["g_count_seg(BatchDev)"],
+                 "encode_size": ["void g_encode_seg<false>(BatchDev)"] + [f"void g_encode_grp<false, {g}>(BatchDev)" for g in range(1, 7)],
+                 "encode_store": ["void g_encode_seg<true>(BatchDev)"] + [f"void g_encode_grp<true, {g}>(BatchDev)" for g in range(1, 7)],
+                 "save_size": ["void g_save_seg<false>(BatchDev)", "void g_save_lds<false>(BatchDev)"],
+                 "save_store": ["void g_save_seg<true>(BatchDev)", "void g_save_lds<true>(BatchDev)"]}
+        names = forms.get(dom, [f"g_k_{dom}(BatchDev, unsigned int)", f"g_k_{dom}(MergeDev const*, unsigned int)"])
+        hit = [tj["kernels"][nm] for nm in names if nm in tj["kernels"]]
+        if not hit:
+            return None
+        # the forms of one bench kernel run side by side in a launch of the pipeline step (e.g. the six column groups
+        # of the lane-form encoder): bytes per pipeline launch = sum over forms of their per-launch averages
+        if dom in ("encode_size", "encode_store") and any("g_encode_grp" in nm for nm in names if nm in tj["kernels"]) and not any("g_encode_seg" in nm for nm in names if nm in tj["kernels"]):
+            return sum(h["traffic"] for h in hit)
+        tot_l = sum(h["launches"] for h in hit)
+        return sum(h["traffic"] * h["launches"] for h in hit) / tot_l
+    except Exception:
+        return None
+
+
 def bench_merge(args, eng, rank, world, dist, torch, red_dev):
     """configs[2] (the headline line): `--docs` text documents per GPU (default 10,000), each a 1,000-character base +
     `--replicas` divergent replicas of 5,000 edits (70 % inserts in runs, 30 % deletes).  One step = every document's
@@ -195,16 +223,7 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
                        "GBps": round(model[k] / (v[0] * 1e-3) / 1e9, 2) if k in model and v[0] > 0 else None,
                        **({"overlapped": True} if k in OVERLAPPED else {})}
                    for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0]) if v[1] > 0}
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-            if tj.get("workload") == "merge":
-                names = {"decode_ops": ["g_decode_seg(BatchDev)"], "count": ["g_count_seg(BatchDev)"],
-                         "encode_size": ["void g_encode_seg<false>(BatchDev)"], "encode_store": ["void g_encode_seg<true>(BatchDev)"]}.get(dom, [f"g_k_{dom}(BatchDev, unsigned int)"])
-                vals = [tj["kernels"][nm]["traffic"] * tj["kernels"][nm]["launches"] for nm in names if nm in tj["kernels"]]
-                traffic = sum(vals) / dom_calls if vals else None
-        except Exception:
-            traffic = None
+        traffic = pmc_traffic("merge", dom)
         out = {"metric": "ops loaded+merged/sec (node)", "value": ops_all * args.steps / elapsed_max, "unit": "ops/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64", "data": "synthetic",
@@ -593,17 +612,7 @@ def main():
     total_kernel_ms = sum(v[0] for k, v in kt.items() if k not in OVERLAPPED)
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
     # (profiles/traffic_latest.json, tools/pmc_traffic.py); null when the file is missing
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))["kernels"]
-        names = {"encode_store": [f"void g_encode_grp<true, {g}>(BatchDev)" for g in range(1, 7)],
-                 "encode_size": [f"void g_encode_grp<false, {g}>(BatchDev)" for g in range(1, 7)],
-                 "decode_ops": ["g_decode_cols(BatchDev)"],
-                 "count": ["g_count_lds(BatchDev)"]}.get(dom, [f"g_k_{dom}(BatchDev, unsigned int)"])
-        vals = [tj[nm]["traffic"] for nm in names if nm in tj]
-        traffic = sum(vals) if vals else None
-    except Exception:
-        traffic = None
+    traffic = pmc_traffic("load", dom)
     kernels = {k: {"ms": round(v[0] / max(1, v[1]), 4), "launches": v[1],
                    "GBps": round(model.get(k, 0) / v[1] / (v[0] / v[1] * 1e-3) / 1e9, 2) if v[0] > 0 and v[1] > 0 else None,
                    **({"overlapped": True} if k in OVERLAPPED else {})}
