@@ -144,7 +144,7 @@ static bool ensure_host_arena(const amh_staged* sc) {
 static void staged_unref(amh_staged* s) {
   if (!s) return;
   if (--s->refs > 0) return;
-  s->ctx->pool.release(s->d_arena.p, s->d_arena.cap);
+  if (s->d_arena.cap) s->ctx->pool.release(s->d_arena.p, s->d_arena.cap);   // cap 0: borrowed (rows_to_batch, until the merge hands it over)
   s->ctx->pool.release(s->d_doc_off.p, s->d_doc_off.cap);
   delete s;
 }
@@ -513,6 +513,7 @@ static bool big_hash_changes(amh_batch* b, u32 d) {
          rt_sync(ctx->stream);
 }
 
+static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, struct BigSha& big, const amh_load_opts* opts, bool trailing, bool from_rows, const u8* expect_hash);
 // bytes of derived arrays a batch with these totals takes on the device through load (rows: the op columns, the
 // change view, the id tables; succ: entries, preds and the delete table; changes: metadata and column lengths), a
 // little on the high side
@@ -665,6 +666,26 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   launch(ctx, AK_CHG_INIT, B, B.tot_chg);
   launch(ctx, AK_DECODE_CHG, B, n);
   launch(ctx, AK_DECODE_OPS, B, n * OC_COUNT);
+  return load_tail(ctx, b, big, opts, trailing, false, nullptr);
+}
+
+// The load pipeline from the decoded op rows on: id tables, validation, succ / pred linking, op -> change, the change
+// re-encode and hashing, heads, visibility.  Entered after the decode of a document batch (load_staged_impl) or with the
+// rows a merge / apply just put in document order (mg_execute, from_rows: nothing is saved and decoded in between; the
+// re-derived hashes are then checked against the hashes the changes came with, expect_hash).
+static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_load_opts* opts, bool trailing, bool from_rows, const u8* expect_hash) {
+  BatchDev& B = b->B;
+  const u32 n = B.n_docs;
+  const size_t NC = (size_t)B.tot_chg + 2;
+  bool ok = true;
+  auto fail = [&](const std::string& m) -> amh_batch* {
+    big.join();
+    set_error(ctx, m);
+    rt_sync(ctx->side);   // nothing of this batch may still be running when its memory goes back to the pool
+    collect_profile(ctx);
+    amh_batch_free(b);
+    return nullptr;
+  };
   {   // id -> row tables, sized now that the highest counter of every document is known
     launch(ctx, AK_HT_SIZE, B, n);
     u32 tot_ht = 0, tot_dn = 0;
@@ -677,7 +698,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
     rt_memset(B.ht_key, 0, ((size_t)tot_ht + 1) * 8, ctx->stream);
     rt_memset(B.dn_val, 0xFF, ((size_t)tot_dn + 1) * 4, ctx->stream);
   }
-  launch(ctx, AK_ROWS, B, B.tot_rows);
+  launch(ctx, from_rows ? AK_ROWS_M : AK_ROWS, B, B.tot_rows);
   launch(ctx, AK_OBJ_ORDER, B, B.tot_rows);
   launch(ctx, AK_SUCC, B, B.tot_succ);
   // the delete table and the op space [0, tot_rows + tot_dt), sized for the succ entries that point at deletes
@@ -774,6 +795,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
       if (stt == 0 && !big_hash_changes(b, big.docs[k])) return fail(std::string("device pipeline failed: ") + rt_last_error());
     }
   }
+  if (expect_hash) { B.expect_hash = expect_hash; launch(ctx, AK_VERIFY_HASH, B, B.tot_chg); }
   launch(ctx, AK_HEADS, B, n);
   rt_stream_wait(ctx->stream, &ctx->ev_join);   // visibility is in
   b->status.resize(n);
@@ -1299,6 +1321,8 @@ struct ApplyRun {
   u32* d_u_fill = nullptr;
   std::vector<u32> c_pair, c_rel, amap_base, amap, ix_base, ix_actor, ix_start, ix_nops, ix_row;
   std::vector<u8> c_applied;
+  std::vector<u64> h_start_op;       // [n_chunks] first op counter of the chunk's change
+  std::vector<u32> h_nops;           // [n_chunks] its ops (deletes included)
   std::vector<DocDesc> s_desc;       // per pair: region of the arena holding its chunks
   std::vector<DocCounts> s_cnt;      // per pair: rows of U
   std::vector<u32> s_row_base;       // [P + 1]
@@ -1344,6 +1368,116 @@ static size_t first_doc_chunk_len(const u8* p, size_t avail) {
   return pos + (size_t)len;
 }
 static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts, bool trailing);
+// The merged documents of a merge / apply call as a batch of their own, built from the rows the merge kernels put in
+// document order (M) instead of from saved bytes: M's arrays are what the decode would have produced, the rest of the
+// load pipeline (load_tail) derives everything else and re-verifies every change (re-encode, SHA-256, against the hash
+// the change came with).  M's arrays are borrowed from the merge scratch until adopt_merged_arrays hands them over.
+static amh_batch* rows_to_batch(amh_ctx* ctx, amh_batch* mb, const MergeDev& G, const MgPlan& pl, const ApplyRun* ap, u8* m_arena, const char* who) {
+  const BatchDev& M = G.M;
+  const u32 P = pl.P;
+  auto* st = new amh_staged();
+  st->ctx = ctx; st->n_docs = P; st->host_ok = false; st->single_chunk = true; st->internal = true;
+  st->arena_bytes = (size_t)pl.arena_len + 256;
+  st->h_doc_off.assign(2 * (size_t)P + 2, 0);
+  for (u32 p = 0; p < P; p++) { st->h_doc_off[2 * (size_t)p] = pl.m_desc[p].chunk_off; st->h_doc_off[2 * (size_t)p + 1] = pl.m_desc[p].chunk_off + pl.m_desc[p].chunk_len; }
+  st->d_arena.p = m_arena; st->d_arena.cap = 0;   // borrowed
+  st->d_doc_off.p = ctx->pool.alloc(st->h_doc_off.size() * sizeof(u64), &st->d_doc_off.cap);
+  std::unique_ptr<amh_batch, void (*)(amh_batch*)> nbh(new amh_batch(), amh_batch_free);
+  amh_batch* nb = nbh.get();
+  nb->ctx = ctx;
+  nb->staged = st;
+  auto oom = [&]() -> amh_batch* { set_error(ctx, std::string(who) + ": device out of memory"); return nullptr; };
+  if (!st->d_doc_off.p) return oom();
+  BatchDev& B = nb->B;
+  B = M;
+  B.arena = m_arena;
+  B.doc_off = (const u64*)st->d_doc_off.p;
+  B.check_heads = 0;   // there are no stored heads to compare with: every change hash is checked instead (k_verify_hash)
+  B.max_doc_rows = ctx->max_doc_rows;
+  B.skip_doc_sha = 0; B.sha_host_min = 0; B.first_len = nullptr; B.sha_gate = nullptr; B.sha_bad = nullptr;
+  B.sv_status = nullptr; B.sv_col_len = nullptr; B.sv_wide = nullptr; B.sv_body_len = nullptr; B.sv_off = nullptr; B.sv_out = nullptr;
+  // per document: dep / actor-map bases, highest op counter, dep counts (the host made the merged history)
+  std::vector<u32> dep_base(P + 2, 0), map_base(P + 2, 0), max_op(P + 1, 0);
+  std::vector<DocCounts> cnt(pl.m_cnt);
+  {
+    std::vector<u32> dst_max(P);
+    if (!rt_d2h(dst_max.data(), G.D.doc_max_op, (size_t)P * sizeof(u32), ctx->stream) || !rt_sync(ctx->stream)) { set_error(ctx, std::string(who) + ": D2H copy failed"); return nullptr; }
+    u64 deps = 0, maps = 0;
+    for (u32 p = 0; p < P; p++) {
+      dep_base[p] = (u32)deps; map_base[p] = (u32)maps;
+      u32 nd_p = 0;
+      for (u32 c = pl.m_chg_base[p]; c < pl.m_chg_base[p + 1]; c++) nd_p += pl.mc_ndeps[c];
+      cnt[p].n_chg = pl.m_chg_base[p + 1] - pl.m_chg_base[p];
+      cnt[p].n_deps = nd_p;
+      deps += nd_p;
+      maps += (u64)cnt[p].n_chg * pl.m_desc[p].n_actors;
+      max_op[p] = dst_max[p];
+      if (!ap) {   // row merge: the source document's own highest counter
+        u32 sm = 0;
+        if (!rt_d2h(&sm, G.S.doc_max_op + pl.p_b[p], sizeof(u32), ctx->stream) || !rt_sync(ctx->stream)) { set_error(ctx, std::string(who) + ": D2H copy failed"); return nullptr; }
+        if (sm > max_op[p]) max_op[p] = sm;
+      }
+    }
+    if (deps >= 0xFFFFFFFFull || maps >= 0xFFFFFFFFull) { set_error(ctx, std::string(who) + ": batch too large"); return nullptr; }
+    dep_base[P] = (u32)deps; map_base[P] = (u32)maps;
+    nb->tot_map = (u32)maps;
+    if (ap)   // the applied changes: ids start_op .. start_op + ops - 1 (deletes included: they are rows of U)
+      for (u32 u = 0; u < ap->n_chunks; u++)
+        if (ap->c_applied[u]) { u32 p = ap->c_pair[u]; u64 hi = ap->h_start_op[u] + ap->h_nops[u]; if (hi) hi--; if (hi > max_op[p]) max_op[p] = (u32)std::min<u64>(hi, 0xFFFFFFFEull); }
+  }
+  bool ok = true;
+  const size_t NC = (size_t)B.tot_chg + 2, NR = (size_t)B.tot_rows + 2, NS = (size_t)B.tot_succ + 2, NA = (size_t)B.tot_actors + 1;
+  // row n_rows / n_succ of the counts come from the device (k_mg_doc_succ); the change counts from the host
+  std::vector<DocCounts> dev_cnt(P);
+  if (!rt_d2h(dev_cnt.data(), M.cnt, (size_t)P * sizeof(DocCounts), ctx->stream) || !rt_sync(ctx->stream)) { set_error(ctx, std::string(who) + ": D2H copy failed"); return nullptr; }
+  for (u32 p = 0; p < P; p++) { cnt[p].n_rows = dev_cnt[p].n_rows; cnt[p].n_succ = dev_cnt[p].n_succ; }
+  if (!rt_h2d(M.cnt, cnt.data(), (size_t)P * sizeof(DocCounts), ctx->stream)) { set_error(ctx, std::string(who) + ": H2D copy failed"); return nullptr; }
+  B.dep_base = upload(nb, dep_base, &ok); B.map_base = upload(nb, map_base, &ok); B.doc_max_op = upload(nb, max_op, &ok);
+  B.ht_base = balloc<u32>(nb, P + 2, &ok); B.dt_base = balloc<u32>(nb, P + 2, &ok);
+  B.doc_hash = balloc<u8>(nb, (size_t)P * 32 + 32, &ok);
+  B.dn_base = balloc<u32>(nb, P + 2, &ok); B.dn_stride = balloc<u32>(nb, P + 2, &ok);
+  B.heads_ok = balloc<u32>(nb, P + 1, &ok); B.doc_level = balloc<u32>(nb, P + 1, &ok); B.max_level = balloc<u32>(nb, 4, &ok);
+  B.a_first_chg = balloc<u32>(nb, NA, &ok); B.a_last_chg = balloc<u32>(nb, NA, &ok);
+  B.c_nops = balloc<u32>(nb, NC, &ok); B.c_start_op = balloc<u64>(nb, NC, &ok); B.c_op_base = balloc<u32>(nb, NC, &ok);
+  B.c_next_same_actor = balloc<u32>(nb, NC, &ok); B.c_level = balloc<u32>(nb, NC, &ok);
+  B.c_hash = balloc<u8>(nb, NC * 32, &ok);
+  B.c_out_off = balloc<u32>(nb, NC, &ok); B.c_out_len = balloc<u32>(nb, NC, &ok); B.c_body_len = balloc<u32>(nb, NC, &ok);
+  B.c_cols_off = balloc<u32>(nb, NC, &ok); B.c_col_len = balloc<u32>(nb, NC * AMH_NCOLS, &ok); B.c_wide = balloc<u32>(nb, NC, &ok);
+  B.c_map_base = balloc<u32>(nb, NC, &ok); B.c_n_other = balloc<u32>(nb, NC, &ok);
+  B.chg_actor_map = balloc<u32>(nb, (size_t)nb->tot_map + 1, &ok);
+  B.r_inc_cnt = balloc<u32>(nb, NR, &ok); B.r_inc_sum = balloc<i64>(nb, NR, &ok);
+  B.r_visible = balloc<u8>(nb, NR, &ok); B.r_winner = balloc<u8>(nb, NR, &ok);
+  B.s_row = balloc<u32>(nb, NS, &ok); B.s_target = balloc<u32>(nb, NS, &ok); B.pred_ids = balloc<u64>(nb, NS, &ok);
+  if (!ok) return oom();
+  if (!rt_h2d(st->d_doc_off.p, st->h_doc_off.data(), st->h_doc_off.size() * sizeof(u64), ctx->stream)) { set_error(ctx, std::string(who) + ": H2D copy failed"); return nullptr; }
+  rt_memset(B.doc_hash, 0, (size_t)P * 32 + 32, ctx->stream);
+  rt_memset(B.max_level, 0, 16, ctx->stream);
+  rt_memset(B.s_row, 0xFF, NS * 4, ctx->stream);
+  rt_memset(B.chg_actor_map, 0, ((size_t)nb->tot_map + 1) * 4, ctx->stream);
+  rt_memset(B.ht_base, 0, (P + 2) * sizeof(u32), ctx->stream); rt_memset(B.dt_base, 0, (P + 2) * sizeof(u32), ctx->stream);
+  launch(ctx, AK_M_INIT, B, P);
+  BigSha big;   // nothing of a merged document is hashed on the host
+  amh_batch* out = load_tail(ctx, nbh.get(), big, nullptr, false, true, M.c_hash);
+  if (!out) { nbh.release(); return nullptr; }   // load_tail freed it
+  return nbh.release();
+}
+// the merged rows now belong to the new batch: its part of the merge scratch moves over, the rest goes back to the pool
+static void adopt_merged_arrays(amh_batch* mb, amh_batch* nb, u8* m_arena) {
+  const BatchDev& B = nb->B;
+  const void* keep[] = {B.status, B.fail_line, B.desc, B.cnt, B.row_base, B.succ_base, B.chg_base, B.actor_base, B.actor_off, B.actor_len, B.actor_rank,
+                        B.actor_by_rank, B.c_actor, B.c_seq, B.c_max_op, B.c_time, B.c_msg_off, B.c_msg_len, B.c_extra_off, B.c_extra_len, B.c_ndeps,
+                        B.c_dep_base, B.dep_idx, B.c_doc, B.c_is_dep, B.r_id_actor, B.r_id_ctr, B.r_obj_actor, B.r_obj_ctr, B.r_key_actor, B.r_key_ctr,
+                        B.r_key_off, B.r_key_len, B.r_vraw_off, B.r_mark_off, B.r_mark_len, B.r_succ_cnt, B.r_succ_base, B.r_doc, B.r_insert, B.r_action,
+                        B.r_expand, B.r_vmeta, B.s_actor, B.s_ctr};
+  std::vector<DevAlloc> rest;
+  for (auto& a : mb->allocs) {
+    if (a.p == (void*)m_arena) { nb->staged->d_arena.p = a.p; nb->staged->d_arena.cap = a.cap; continue; }
+    bool k = false;
+    for (const void* q : keep) k = k || (q && q == a.p);
+    if (k) nb->allocs.push_back(a); else rest.push_back(a);
+  }
+  mb->allocs.swap(rest);
+}
 static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& pl, ApplyRun* ap, const char* who) {
   MG_REFS(pl)
   const BatchDev& DB = dst->B;
@@ -1530,6 +1664,36 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   if (!rt_d2h(p_status.data(), G.p_status, P * sizeof(i32), ctx->stream)) return failm("D2H copy failed");
   if (!rt_h2d(M.status, p_status.data(), P * sizeof(i32), ctx->stream)) return failm("H2D copy failed");
   pt.mark("exec: rows + succ + chunks", &ctx->stream);
+  u32 nd = DB.n_docs;
+  amh_batch* nb = nullptr;
+  int rc = AMH_SUCCESS;
+  // ---- the merged rows go straight into the rest of the load pipeline (id tables, linking, op -> change, the change
+  //      re-encode and hashing): nothing is saved and decoded in between.  Taken when every document of dst is merged
+  //      by this call; otherwise (documents outside the call, pairs with nothing to do, failed pairs) the merged
+  //      documents go through their saved form below, next to the untouched ones.  AMH_MERGE_RELOAD=1 forces that. ---
+  bool direct = getenv("AMH_MERGE_RELOAD") == nullptr && P == nd;
+  for (u32 p = 0; p < P && direct; p++) direct = p_status[p] == 0 && p_a[p] == p && dst->status[p] == 0;
+  if (direct) {
+    nb = rows_to_batch(ctx, mb, G, pl, ap, m_arena, who);
+    if (!nb) return AMH_ERR_DEVICE;
+    bool all_ok = true;
+    for (u32 p = 0; p < P; p++) all_ok = all_ok && nb->status[p] == 0;
+    if (all_ok) {
+      adopt_merged_arrays(mb, nb, m_arena);
+    } else {
+      // A document merged from loaded documents always verifies: anything else is an engine bug, never a silent
+      // result.  A change handed to apply may not survive the document format (a pred naming no op, a non-canonical
+      // encoding: the reference's own save + load rejects such a document too): those documents are left as they
+      // were, and the rest goes through the saved form.
+      if (!ap) { set_error(ctx, std::string(who) + ": a merged document failed verification"); amh_batch_free(nb); return AMH_ERR_DEVICE; }
+      for (u32 p = 0; p < P; p++) if (nb->status[p] != 0) p_status[p] = AMH_E_UNSUPPORTED;
+      amh_batch_free(nb);
+      nb = nullptr;
+      if (!rt_h2d(M.status, p_status.data(), P * sizeof(i32), ctx->stream)) return failm("H2D copy failed");
+    }
+    pt.mark("exec: rows -> pipeline", &ctx->stream);
+  }
+  if (!nb) {
   // ---- merged rows -> document chunks (the save kernels over M) ---------------------------------
   M.sv_status = balloc<i32>(mb, P + 1, &ok); M.sv_col_len = balloc<u32>(mb, (size_t)P * 25 + 1, &ok); M.sv_wide = balloc<u32>(mb, P + 1, &ok);
   M.sv_body_len = balloc<u32>(mb, P + 1, &ok); M.sv_off = balloc<u32>(mb, P + 2, &ok);
@@ -1556,10 +1720,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   // ---- reload: every document of dst, merged ones from their new bytes.  The arena of the new batch is put
   //      together in device memory (merged chunks from the save buffer, the others from the old arena): the
   //      bytes do not visit the host; its host copy is fetched only when an accessor asks for bytes. ---------
-  u32 nd = DB.n_docs;
   amh_staged* old_st = dst->staged;
-  amh_batch* nb = nullptr;
-  int rc = AMH_SUCCESS;
   for (int attempt = 0; attempt < 2; attempt++) {
   std::vector<u64> seg_src(nd), seg_dst(nd), se(2 * (size_t)nd + 2, 0);
   std::vector<u32> seg_len(nd);
@@ -1625,8 +1786,9 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   amh_batch_free(nb);
   nb = nullptr;
   }
-  for (u32 p = 0; p < P; p++) if (p_status[p] > 0) rc = AMH_ERR_DOC_FAILED;
   pt.mark("exec: reload pipeline", &ctx->stream);
+  }
+  for (u32 p = 0; p < P; p++) if (p_status[p] > 0) rc = AMH_ERR_DOC_FAILED;
   // documents of dst that failed earlier keep their status (a reload of their first chunk alone may succeed)
   bool st_dirty = false;
   for (u32 d = 0; d < nd; d++)
@@ -2158,6 +2320,8 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   mg_plan_init(pl, P, DB.n_docs, P, NCH);
   MG_REFS(pl)
   ap.c_applied.assign((size_t)NCH + 1, 0);
+  ap.h_start_op.resize(NCH); ap.h_nops.resize(NCH);
+  for (u32 u = 0; u < NCH; u++) { ap.h_start_op[u] = hdr[u].start_op; ap.h_nops[u] = u_cnt[u].n_rows; }
   ap.amap_base.assign((size_t)NCH + 1, 0);
   ap.ix_base.assign(P + 1, 0);
   std::vector<std::vector<u32>> new_queue(P);

@@ -508,6 +508,62 @@ AMH_DEV void k_decode_chg(const BatchDev& B, u32 d) {
   }
 }
 
+// K4m  merge / apply hand their merged rows and change metadata straight to the pipeline (no save + decode in between):
+//      what k_extract, k_chg_init and the dependency / chain part of k_decode_chg leave behind, from change metadata
+//      that is already in arrays.  Thread per document.
+AMH_DEV void k_m_init(const BatchDev& B, u32 d) {
+  B.heads_ok[d] = 0;
+  B.doc_level[d] = 0;
+  B.ht_base[d] = 0;
+  B.dt_base[d] = 0;
+  if (B.status[d]) return;
+  u32 cb = B.chg_base[d], nc = B.cnt[d].n_chg, ab = B.actor_base[d], na = B.desc[d].n_actors;
+  for (u32 a = 0; a < na; a++) { B.a_first_chg[ab + a] = AMH_EMPTY32; B.a_last_chg[ab + a] = AMH_EMPTY32; }
+  u32 max_lvl = 0;
+  for (u32 i = 0; i < nc; i++) {
+    u32 c = cb + i;
+    B.c_nops[c] = 0;
+    B.c_next_same_actor[c] = AMH_EMPTY32;
+    B.c_map_base[c] = B.map_base[d] + i * na;
+    if (B.c_actor[c] >= na) { amh_fail(B, d, AMH_E_COLLECT_MISSING_ACTOR); return; }
+    u32 lvl = 0;
+    for (u32 k = 0; k < B.c_ndeps[c]; k++) {
+      u32 di = B.dep_idx[B.c_dep_base[c] + k];
+      if (di >= i) { amh_fail(B, d, AMH_E_MISSING_CHANGE); return; }
+      B.c_is_dep[cb + di] = 1;
+      u32 dl = B.c_level[cb + di] + 1;
+      if (dl > lvl) lvl = dl;
+    }
+    B.c_level[c] = lvl;
+    if (lvl > max_lvl) max_lvl = lvl;
+  }
+  B.doc_level[d] = max_lvl;
+  amh_atomic_max(B.max_level, max_lvl);
+  for (u32 i = 0; i < nc; i++) {   // per-actor chains in history order + ordering checks, as k_decode_chg
+    u32 c = cb + i, a = ab + B.c_actor[c];
+    u32 last = B.a_last_chg[a];
+    if (last == AMH_EMPTY32) {
+      B.a_first_chg[a] = c;
+      if (B.c_seq[c] != 1) { amh_fail(B, d, AMH_E_CHANGES_OUT_OF_ORDER); return; }
+    } else {
+      if (B.c_max_op[last] > B.c_max_op[c]) { amh_fail(B, d, AMH_E_CHANGES_OUT_OF_ORDER); return; }
+      if (B.c_seq[last] != B.c_seq[c] - 1) { amh_fail(B, d, AMH_E_CHANGES_OUT_OF_ORDER); return; }
+      B.c_next_same_actor[last] = c;
+    }
+    B.a_last_chg[a] = c;
+  }
+}
+// the re-derived hash of every change of a merged document against the hash the change came with.  Thread per change.
+AMH_DEV void k_verify_hash(const BatchDev& B, u32 c) {
+  u32 d = B.c_doc[c];
+  if (d >= B.n_docs || B.status[d]) return;
+  const u8* x = B.c_hash + (u64)c * 32;
+  const u8* y = B.expect_hash + (u64)c * 32;
+  bool same = true;
+  for (int i = 0; i < 32; i++) same = same && x[i] == y[i];
+  if (!same) amh_fail(B, d, AMH_E_MISMATCHING_HEADS);
+}
+
 // ------------------------------------------------------------------------------------------
 // K5  op column decode — rle.rs:175-210, delta.rs:79-95, boolean.rs:84-101, value.rs:209-272
 //     (meta only).  Thread per (document, column stream); each stream expands its runs into the
@@ -773,6 +829,34 @@ AMH_DEV void k_rows(const BatchDev& B, u32 r) {
     u64 old = amh_atomic_cas64(&B.ht_key[base + h], 0, key);
     if (old == 0) { B.ht_val[base + h] = r; break; }
     if (old == key) { amh_fail(B, d, AMH_E_UNSUPPORTED); return; }  // duplicate op id in one document
+    h = (h + 1) & mask;
+  }
+}
+
+// K6m  the rows of a merged document come normalised and validated (they were rows of loaded documents and of decoded
+//      changes): what is left of k_rows is the owning row of each succ entry and the id -> row table.  Thread per row.
+AMH_DEV void k_rows_m(const BatchDev& B, u32 r) {
+  u32 d = B.r_doc[r];
+  B.r_inc_cnt[r] = 0;
+  B.r_inc_sum[r] = 0;
+  if (d >= B.n_docs || B.status[d]) return;
+  {
+    u32 sc = B.r_succ_cnt[r], sb = B.r_succ_base[r];
+    for (u32 k = 0; k < sc; k++) B.s_row[sb + k] = r;
+  }
+  u32 ia = B.r_id_actor[r], ic = B.r_id_ctr[r];
+  u32 stride = B.dn_stride[d];
+  if (stride) {
+    if (ic >= stride || ia >= B.desc[d].n_actors) { amh_fail(B, d, AMH_E_UNSUPPORTED); return; }
+    if (amh_atomic_cas(&B.dn_val[B.dn_base[d] + ia * stride + ic], AMH_NULL32, r) != AMH_NULL32) amh_fail(B, d, AMH_E_UNSUPPORTED);
+    return;
+  }
+  u64 base = B.ht_base[d], size = B.ht_base[d + 1] - base, mask = size - 1;
+  u64 key = pack_id(ic, ia) + 1, h = amh_mix64(key) & mask;
+  for (u64 i = 0; i < size; i++) {
+    u64 old = amh_atomic_cas64(&B.ht_key[base + h], 0, key);
+    if (old == 0) { B.ht_val[base + h] = r; break; }
+    if (old == key) { amh_fail(B, d, AMH_E_UNSUPPORTED); return; }
     h = (h + 1) & mask;
   }
 }

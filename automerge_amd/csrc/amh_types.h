@@ -185,6 +185,7 @@ struct BatchDev {
   u32 sync_cap;                  // 0 = sync_out holds every record; else its capacity: records that end beyond it are not written
   // lists too long for the thread that owns them (more than AMH_BIG_LIST entries): the thread-per-item kernel records
   // them here and a block per list sorts them afterwards (amh_kernels.hip, g_big_*)
+  const u8* expect_hash;         // [tot_chg * 32] merge / apply: the hashes the changes of a merged document came with (k_verify_hash)
   u32* first_len;                // [n_docs] bytes of the document chunk an input starts with (0: it starts with a change chunk; the input's
                                  // length: nothing readable behind it) — what the host needs to know to find trailing change chunks
   u32 skip_doc_sha;              // chunks written by merge / apply for the engine's own reload: no checksum is written or checked
