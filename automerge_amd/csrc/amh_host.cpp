@@ -26,6 +26,8 @@
 
 #define AMH_EMPTY32 0xFFFFFFFFu
 #define AMH_NCOLS 14
+#define AMH_BIGCOL_HOST (32u << 10)   // = AMH_BIGCOL / AMH_SEG of amh_segdec.inl
+#define AMH_SEG_HOST 4096u
 #define AMH_LEVEL_CAP_HOST 48u   // = AMH_LEVEL_CAP of amh_kernels.inl
 
 static thread_local std::string g_last_error;
@@ -589,6 +591,30 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
     launch_on(ctx, ctx->side, AK_SHA_DOC, B, n);
     rt_event_record(&ctx->ev_join, ctx->side);
   }
+#ifndef AMH_EMU
+  {   // documents large enough to hold a column of AMH_BIGCOL_HOST bytes: their big columns are cut into ranges, a wave each
+    u64 cand = 0, bytes = 0, segs = 0;
+    for (u32 d = 0; d < n; d++) {
+      u64 l = st->h_doc_off[2 * (size_t)d + 1] - st->h_doc_off[2 * (size_t)d];
+      if (l >= AMH_BIGCOL_HOST) { cand++; bytes += l; segs += l / AMH_SEG_HOST + 13; }
+    }
+    B.bc_n = nullptr;
+    if (cand && !getenv("AMH_NO_BIGCOL") && bytes < 0xF0000000ull && segs < 0x7FFFFFFFull && cand * 13 < 0x7FFFFFFFull) {
+      B.bc_cap_cols = (u32)(cand * 13); B.bc_cap_segs = (u32)segs; B.bc_cap_bytes = (u32)bytes;
+      B.bc_n = balloc<u32>(b, 4, &ok);
+      B.bc_index = balloc<u32>(b, (size_t)n * 13 + 1, &ok);
+      u32** cols[] = {&B.bc_doc, &B.bc_slot, &B.bc_seg0, &B.bc_nseg, &B.bc_ebase, &B.bc_bad};
+      for (auto pc : cols) *pc = balloc<u32>(b, (size_t)B.bc_cap_cols + 1, &ok);
+      B.bc_rows = balloc<u64>(b, (size_t)B.bc_cap_cols + 1, &ok); B.bc_acc = balloc<u64>(b, (size_t)B.bc_cap_cols + 1, &ok);
+      u32** sgs[] = {&B.sg_col, &B.sg_first, &B.sg_second, &B.sg_ntok, &B.sg_entry, &B.sg_pos, &B.sg_end, &B.sg_btok};
+      for (auto pc : sgs) *pc = balloc<u32>(b, (size_t)B.bc_cap_segs + 1, &ok);
+      B.sg_rows = balloc<u64>(b, (size_t)B.bc_cap_segs + 1, &ok); B.sg_acc = balloc<u64>(b, (size_t)B.bc_cap_segs + 1, &ok);
+      B.sg_exit = balloc<u32>(b, (size_t)B.bc_cap_bytes + 1, &ok);
+      if (!ok) return fail("device out of memory");
+      rt_memset(B.bc_n, 0, 4 * sizeof(u32), ctx->stream);
+    }
+  }
+#endif
   launch(ctx, AK_COUNT, B, n);
   rt_stream_wait(ctx->stream, &ctx->ev_join);   // k_extract applies the checksum verdicts
   launch(ctx, AK_EXTRACT, B, n);

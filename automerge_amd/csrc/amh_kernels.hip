@@ -752,9 +752,20 @@ __global__ void __launch_bounds__(AMH_BLOCK) g_big_pred(const BatchDev B) {
 void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
   if (n == 0) return;
   hipStream_t s = (hipStream_t)stream;
-  if (k == AK_COUNT) { hipLaunchKernelGGL(g_count_seg, dim3((B.n_docs + SD_WAVES - 1) / SD_WAVES, 2), dim3(64 * SD_WAVES), 0, s, B); return; }
+  if (k == AK_COUNT) {
+    if (B.bc_n) {   // documents with columns of AMH_BIGCOL bytes and more: cut them into ranges first (amh_segdec.inl)
+      hipLaunchKernelGGL(g_bc_find, dim3((B.n_docs * 13u + AMH_BLOCK - 1) / AMH_BLOCK), dim3(AMH_BLOCK), 0, s, B);
+      hipLaunchKernelGGL(g_bc_chain, dim3((B.bc_cap_segs + BC_WAVES - 1) / BC_WAVES), dim3(64 * BC_WAVES), 0, s, B);
+      hipLaunchKernelGGL(g_bc_resolve, dim3((B.bc_cap_cols + 63) / 64), dim3(64), 0, s, B);
+      hipLaunchKernelGGL(g_bc_measure, dim3((B.bc_cap_segs + SD_WAVES - 1) / SD_WAVES), dim3(64 * SD_WAVES), 0, s, B);
+      hipLaunchKernelGGL(g_bc_prefix, dim3((B.bc_cap_cols + 63) / 64), dim3(64), 0, s, B);
+    }
+    hipLaunchKernelGGL(g_count_seg, dim3((B.n_docs + SD_WAVES - 1) / SD_WAVES, 2), dim3(64 * SD_WAVES), 0, s, B);
+    return;
+  }
   if (k == AK_DECODE_OPS) {
     hipLaunchKernelGGL(g_decode_seg, dim3((B.n_docs + SD_WAVES - 1) / SD_WAVES, SD_NCOLS + 2), dim3(64 * SD_WAVES), 0, s, B);
+    if (B.bc_n) hipLaunchKernelGGL(g_bc_decode, dim3((B.bc_cap_segs + SD_WAVES - 1) / SD_WAVES), dim3(64 * SD_WAVES), 0, s, B);
     return;
   }
   if (k == AK_SAVE_SIZE || k == AK_SAVE_STORE) {

@@ -239,6 +239,11 @@ __device__ __forceinline__ u32 sd_row_item(SdWave& W, u32 cnt, u32 rs, u32 lane,
   return sd_scan_max(f) - 1;
 }
 
+// A column stream of AMH_BIGCOL bytes and more is not walked by one wave: see "a column over many waves" at the end.
+#define AMH_BIGCOL (32u << 10)
+#define AMH_SEG 4096u
+__device__ __forceinline__ bool bc_is_big(const BatchDev& B, u32 len) { return B.bc_n != nullptr && len >= AMH_BIGCOL; }
+
 template <u32 COL> struct SdCol {
   static constexpr bool SUCC_ENTRY = COL == OC_SUCC_ACTOR || COL == OC_SUCC_CTR;
   static constexpr bool IS_DELTA = COL == OC_KEY_CTR || COL == OC_ID_CTR || COL == OC_SUCC_CTR;
@@ -248,6 +253,10 @@ template <u32 COL> struct SdCol {
   static constexpr bool NULLABLE = COL == OC_OBJ_ACTOR || COL == OC_OBJ_CTR || COL == OC_KEY_ACTOR || COL == OC_KEY_CTR ||
                                    COL == OC_ID_ACTOR || COL == OC_ID_CTR || COL == OC_EXPAND;
   static constexpr bool HAS_ACC = IS_DELTA || COL == OC_VAL_META || COL == OC_SUCC_NUM;
+  // slot of the column in the decode launch (blockIdx.y - 2) and in bc_index
+  static constexpr u32 SLOT = COL == OC_OBJ_ACTOR ? 0 : COL == OC_OBJ_CTR ? 1 : COL == OC_KEY_ACTOR ? 2 : COL == OC_KEY_CTR ? 3 : COL == OC_ID_ACTOR ? 4 :
+                              COL == OC_ID_CTR ? 5 : COL == OC_INSERT ? 6 : COL == OC_ACTION ? 7 : COL == OC_VAL_META ? 8 : COL == OC_SUCC_NUM ? 9 :
+                              COL == OC_SUCC_ACTOR ? 10 : COL == OC_SUCC_CTR ? 11 : 12;
 };
 
 template <u32 COL>
@@ -271,7 +280,10 @@ __device__ __forceinline__ void sd_store_row(const BatchDev& B, u32 d, u32 o, u3
 // Returns the tokens consumed (0 = none could be), or SD_REDO when 32-bit arithmetic does not hold the group (the
 // caller runs it again with WIDE); fail receives the error that ends the document.
 #define SD_REDO 0xFFFFFFFFu
-template <u32 COL, bool WIDE>
+// DRY: measure only (big columns, §"a column over many waves" below): the rows and the running sum a range of the column
+// stands for, from a relative state (rows from 0, sum from 0, everything wanted).  Malformed tokens still end the walk;
+// what a value may be (id ranges, raw-column bounds, nulls) is left to the real pass, which sees absolute values.
+template <u32 COL, bool WIDE, bool DRY = false>
 __device__ __forceinline__ u32 sd_do_group(const BatchDev& B, u32 d, SdWave& W, SdStream& S, u32 lane, u32 m, u32 b0, u32 nb,
                                            u32 obase, u32 sbase, u32 raw_len, u32& mx, i32& fail) {
   typedef SdCol<COL> C;
@@ -294,10 +306,10 @@ __device__ __forceinline__ u32 sd_do_group(const BatchDev& B, u32 d, SdWave& W, 
       u64 tot = I.isnull ? 0 : sv * cnt;
       u64 inc = sd_scan_add64(tot);
       u64 first = S.acc + (inc - tot) + sv;           // value of the item's first row
-      if (I.isnull) { e2 = AMH_NULL32; if (C::SUCC_ENTRY && reach && !ecode) ecode = AMH_E_READ_OP; }
+      if (I.isnull) { e2 = AMH_NULL32; if (!DRY && C::SUCC_ENTRY && reach && !ecode) ecode = AMH_E_READ_OP; }
       else {
         e2 = (u32)first; step = (u32)sv;
-        if (reach && !ecode) {
+        if (!DRY && reach && !ecode) {
           i64 lo = (i64)first, hi = (i64)(first + sv * (reach - 1));
           if (lo > hi) { i64 t = lo; lo = hi; hi = t; }
           if (lo < 0 || hi >= 0xFFFFFFFFll) ecode = AMH_E_READ_OP;   // key.rs:172-179, opid.rs:107-113
@@ -314,10 +326,10 @@ __device__ __forceinline__ u32 sd_do_group(const BatchDev& B, u32 d, SdWave& W, 
       i32 tot = I.isnull ? 0 : sv * (i32)cnt;
       i32 inc = (i32)sd_scan_add((u32)tot);
       i32 first = (i32)(u32)S.acc + (inc - tot) + sv;
-      if (I.isnull) { e2 = AMH_NULL32; if (C::SUCC_ENTRY && reach && !ecode) ecode = AMH_E_READ_OP; }
+      if (I.isnull) { e2 = AMH_NULL32; if (!DRY && C::SUCC_ENTRY && reach && !ecode) ecode = AMH_E_READ_OP; }
       else {
         e2 = (u32)first; step = (u32)sv;
-        if (reach && !ecode) {
+        if (!DRY && reach && !ecode) {
           i32 lo = first, hi = first + sv * (i32)(reach - 1);
           if (lo > hi) { i32 t = lo; lo = hi; hi = t; }
           if (lo < 0) ecode = AMH_E_READ_OP;
@@ -337,7 +349,7 @@ __device__ __forceinline__ u32 sd_do_group(const BatchDev& B, u32 d, SdWave& W, 
       u64 inc = sd_scan_add64(tot);
       u64 first = S.acc + (inc - tot);
       e2 = (u32)first; step = (u32)l;
-      if (reach && !ecode) {
+      if (!DRY && reach && !ecode) {
         if (I.isnull) ecode = AMH_E_READ_OP;
         else if ((uv & 15) >= 3) {   // null / bool never touch the raw column (value.rs:221-224)
           u64 last = first + l * (reach - 1);
@@ -353,7 +365,7 @@ __device__ __forceinline__ u32 sd_do_group(const BatchDev& B, u32 d, SdWave& W, 
       u32 inc = sd_scan_add(tot);
       u32 first = (u32)S.acc + (inc - tot);
       e2 = first; step = l32;
-      if (reach && !ecode) {
+      if (!DRY && reach && !ecode) {
         if (I.isnull) ecode = AMH_E_READ_OP;
         else if ((uv & 15) >= 3) {
           u32 last = first + l32 * (reach - 1);
@@ -362,16 +374,23 @@ __device__ __forceinline__ u32 sd_do_group(const BatchDev& B, u32 d, SdWave& W, 
       }
       acc_new = S.acc + sd_bcast(inc, 63);
     }
+  } else if (COL == OC_SUCC_NUM && DRY) {
+    // the measured sum sizes the succ arrays: exact in 64 bits, absurd counts end the measure (the serial count pass,
+    // with the reader's own error rules, then decides)
+    if (__ballot(cnt != 0 && !I.isnull && (u64)I.u > 0x7FFFFFFFull)) { fail = AMH_E_TOO_LARGE; return c; }
+    u64 tot = I.isnull ? 0 : (u64)I.u * cnt;
+    u64 inc = sd_scan_add64(tot);
+    acc_new = S.acc + sd_bcast64(inc, 63);
   } else if (COL == OC_SUCC_NUM) {
     u32 v = (u32)I.u;
     u32 tot = v * cnt;
     u32 inc = sd_scan_add(tot);
     e0 = v; e2 = sbase + (u32)S.acc + (inc - tot); step = v;
-    if (reach && !ecode && I.isnull) ecode = AMH_E_READ_OP;
+    if (!DRY && reach && !ecode && I.isnull) ecode = AMH_E_READ_OP;
     acc_new = S.acc + sd_bcast(inc, 63);
   } else {   // plain RLE of u64: obj actor / ctr, key actor, id actor, action, succ actor
     e0 = I.isnull ? AMH_NULL32 : (u32)I.u;
-    if (reach && !ecode) {
+    if (!DRY && reach && !ecode) {
       const bool over = WIDE ? (u64)I.u >= 0xFFFFFFFFull : false;
       if (COL == OC_ACTION) { if (I.isnull) ecode = AMH_E_READ_OP; else if (I.u > 7) ecode = AMH_E_INVALID_OP; }
       else if (COL == OC_SUCC_ACTOR) { if (I.isnull) ecode = AMH_E_READ_OP; else if (over) ecode = AMH_E_MISSING_ACTOR; }
@@ -383,6 +402,7 @@ __device__ __forceinline__ u32 sd_do_group(const BatchDev& B, u32 d, SdWave& W, 
   if (bad) { fail = (i32)sd_bcast((u32)ecode, (u32)__builtin_ctzll(bad)); return c; }
   // ---- expand ------------------------------------------------------------------------------------------------
   const u32 R = I.total < rem ? I.total : rem;
+  if (DRY) { S.row += R; S.lit = lit_new; S.btok = btok_new; S.acc = acc_new; return c; }
   const u32 orow = obase + S.row;
   if (__ballot(cnt > 1) == 0) {
     // literal values only (and empty runs): every item is one row, R <= 64; compact through LDS
@@ -476,22 +496,29 @@ template <u32 COL> struct SdDecodeF {
 };
 
 // One column stream.  COL selects what an item means and where its rows go.
+// range = a stretch of the column with the reader's state at its start (the whole column: everything zero); `last` =
+// the stretch ends where the column ends (only then does running out of bytes mean the column is exhausted)
 template <u32 COL>
-__device__ __forceinline__ void sd_decode_column(const BatchDev& B, u32 d, SdWave& W) {
+__device__ __forceinline__ void sd_decode_range(const BatchDev& B, u32 d, SdWave& W, u32 pos, u32 end, u32 row0, u64 lit, u32 btok, u64 acc, bool last) {
   typedef SdCol<COL> C;
   const u32 lane = threadIdx.x & 63;
   const DocDesc& D = B.desc[d];
   const u32 want = C::SUCC_ENTRY ? B.cnt[d].n_succ : B.cnt[d].n_rows;
-  if (want == 0) return;
+  if (want == 0 || (row0 >= want && !last)) return;
   const u32 obase = C::SUCC_ENTRY ? B.succ_base[d] : B.row_base[d];
   SdStream S;
   S.src = B.arena + D.chunk_off;
-  S.pos = D.ocol[COL].off;
-  S.end = S.pos + D.ocol[COL].len;
-  S.want = want; S.row = 0; S.lit = 0; S.btok = 0; S.acc = 0;
+  S.pos = pos;
+  S.end = end;
+  S.want = want; S.row = row0 < want ? row0 : want; S.lit = lit; S.btok = btok; S.acc = acc;
   SdDecodeF<COL> f{B, d, obase, COL == OC_SUCC_NUM ? B.succ_base[d] : 0u, D.ocol[OC_VAL_RAW].len, 0u};
   const i32 fail = sd_walk(W, S, lane, f, AMH_E_READ_OP);
   if (fail) { if (lane == 0) amh_fail(B, d, fail); return; }
+  if (COL == OC_ID_CTR || COL == OC_SUCC_CTR) {
+    u32 m = sd_scan_max(f.mx);
+    if (lane == 63 && m) amh_atomic_max(&B.doc_max_op[d], m);
+  }
+  if (!last) return;
   if (S.row < want) {
     // the column is exhausted.  Inside a literal run the reader fails (the announced value is missing); otherwise
     // the iterator yields None from here on
@@ -499,10 +526,12 @@ __device__ __forceinline__ void sd_decode_column(const BatchDev& B, u32 d, SdWav
     if (!ok) { if (lane == 0) amh_fail(B, d, AMH_E_READ_OP); return; }
     for (u32 r = S.row + lane; r < want; r += 64) sd_store_row<COL>(B, d, obase + r, COL == OC_EXPAND ? 0u : AMH_NULL32, 0, AMH_NULL32);
   }
-  if (COL == OC_ID_CTR || COL == OC_SUCC_CTR) {
-    u32 m = sd_scan_max(f.mx);
-    if (lane == 63 && m) amh_atomic_max(&B.doc_max_op[d], m);
-  }
+}
+template <u32 COL>
+__device__ __forceinline__ void sd_decode_column(const BatchDev& B, u32 d, SdWave& W) {
+  const DocDesc& D = B.desc[d];
+  if (bc_is_big(B, D.ocol[COL].len) && B.bc_index[d * 13u + SdCol<COL>::SLOT] != AMH_NULL32) return;   // cut into ranges, a wave each: g_bc_decode
+  sd_decode_range<COL>(B, d, W, D.ocol[COL].off, D.ocol[COL].off + D.ocol[COL].len, 0, 0, 0, 0, true);
 }
 
 // All op columns of a batch in one launch.  blockIdx.y = column (uniform per workgroup).  y = 0, 1: the two string columns,
@@ -530,6 +559,238 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_decode_seg(BatchDev B) {
     DC(0, OC_OBJ_ACTOR) DC(1, OC_OBJ_CTR) DC(2, OC_KEY_ACTOR) DC(3, OC_KEY_CTR) DC(4, OC_ID_ACTOR) DC(5, OC_ID_CTR) DC(6, OC_INSERT)
     DC(7, OC_ACTION) DC(8, OC_VAL_META) DC(9, OC_SUCC_NUM) DC(10, OC_SUCC_ACTOR) DC(11, OC_SUCC_CTR) DC(12, OC_EXPAND)
 #undef DC
+    default: break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// A column of one document over many waves.  One wave per column leaves a 10M-op document (columns of megabytes) to 15
+// waves walking 256 bytes at a time.  A run-length stream cannot be entered anywhere: which tokens are headers is a chain
+// from the start.  But the chain is cheap to resolve for EVERY possible entry of a 4 KiB segment at once:
+//   chain    (wave per segment) token starts by ballots; every token, taken as a header, names the next header
+//            (+2 run / null run, +1+n literal run); pointer doubling over the segment's tokens in LDS (12 rounds) turns
+//            that into the exit of the chain entered at each token: how many tokens of the following segments are
+//            spoken for (a run's value, or the rest of a literal run).  Exits go to sg_exit.
+//   resolve  (thread per column) the true entry of every segment: one dependent lookup per segment from the column start;
+//            then where every range starts (behind a pending run value) and ends.
+//   measure  (wave per range) the decode's own group code in dry mode: rows and running sum of the range.
+//   prefix   (thread per column) exclusive sums: every range's absolute row, running sum, boolean token parity.
+//   decode   (wave per range) sd_decode_range with the full entry state.  The count pass takes the totals.
+// Boolean columns have no chain (every token is a count): they only use measure / prefix / decode.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 bc_slot_col(u32 slot) {
+  const u32 cols[13] = {OC_OBJ_ACTOR, OC_OBJ_CTR, OC_KEY_ACTOR, OC_KEY_CTR, OC_ID_ACTOR, OC_ID_CTR, OC_INSERT, OC_ACTION, OC_VAL_META, OC_SUCC_NUM, OC_SUCC_ACTOR, OC_SUCC_CTR, OC_EXPAND};
+  return cols[slot];
+}
+#define BC_SLOT_ID_CTR 5u
+#define BC_SLOT_SUCC_NUM 9u
+// thread per (document, decode slot)
+__global__ void __launch_bounds__(AMH_BLOCK) g_bc_find(BatchDev B) {
+  u32 i = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  if (i >= B.n_docs * 13u) return;
+  u32 d = i / 13u, slot = i % 13u;
+  B.bc_index[i] = AMH_NULL32;
+  if (B.status[d] != 0 || B.desc[d].chunk_len == 0) return;
+  const ColRef cr = B.desc[d].ocol[bc_slot_col(slot)];
+  if (cr.len < AMH_BIGCOL) return;
+  u32 nseg = (cr.len + AMH_SEG - 1) / AMH_SEG;
+  u32 e = atomicAdd(&B.bc_n[0], 1u);
+  u32 s0 = atomicAdd(&B.bc_n[1], nseg);
+  u32 eb = atomicAdd(&B.bc_n[2], cr.len);
+  if (e >= B.bc_cap_cols || s0 + nseg > B.bc_cap_segs || eb + cr.len > B.bc_cap_bytes) return;   // cannot happen: sized from the input lengths
+  B.bc_doc[e] = d; B.bc_slot[e] = slot; B.bc_seg0[e] = s0; B.bc_nseg[e] = nseg; B.bc_ebase[e] = eb; B.bc_bad[e] = 0;
+  for (u32 k = 0; k < nseg; k++) B.sg_col[s0 + k] = e;
+  B.bc_index[i] = e;
+}
+struct BcWave {
+  u32 tile[SD_TILE / 4 + 4];
+  unsigned short tokpos[AMH_SEG];
+  u32 nxt[AMH_SEG];
+};
+#define BC_WAVES 2u
+__global__ void __launch_bounds__(64 * BC_WAVES) g_bc_chain(BatchDev B) {
+  __shared__ BcWave L[BC_WAVES];
+  const u32 wave = sd_uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const u32 seg = blockIdx.x * BC_WAVES + wave;
+  u32 nsegs = B.bc_n[1];
+  if (nsegs > B.bc_cap_segs) nsegs = B.bc_cap_segs;
+  if (seg >= nsegs) return;
+  BcWave& W = L[wave];
+  const u32 e = B.sg_col[seg], d = B.bc_doc[e], slot = B.bc_slot[e];
+  const ColRef cr = B.desc[d].ocol[bc_slot_col(slot)];
+  const u8* src = B.arena + B.desc[d].chunk_off;
+  const u32 k = seg - B.bc_seg0[e];
+  const u32 cb = cr.off, ce = cr.off + cr.len;
+  const u32 b = cb + k * AMH_SEG, en = b + AMH_SEG < ce ? b + AMH_SEG : ce;
+  // ---- token starts: a byte starts a token if it is the column's first or the byte in front has no continuation bit
+  u32 ntok = 0;
+  u32 prevb = b > cb ? src[b - 1] : 0u;   // byte in front of the current tile
+  const u32 a0 = b & ~3u;
+  for (u32 tb = a0; tb < en; tb += SD_TILE) {
+    sd_lds_sync();
+    W.tile[lane] = *(const u32*)(src + tb + 4 * lane);   // the arena is padded: reading past the column is harmless
+    sd_lds_sync();
+    const u8* t8 = (const u8*)W.tile;
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+      const u32 bi = 64 * j + lane, pos = tb + bi;
+      const u32 pb = bi ? t8[bi - 1] : prevb;
+      const bool st = pos >= b && pos < en && (pos == cb || !(pb & 0x80));
+      const u64 mk = __ballot(st);
+      if (st) W.tokpos[ntok + sd_mbcnt(mk)] = (unsigned short)(pos - b);
+      ntok += (u32)__builtin_popcountll(mk);
+    }
+    prevb = sd_uniform((u32)t8[SD_TILE - 1]);
+  }
+  sd_lds_sync();
+  // ---- every token as a header: where the next header is
+  const bool is_bool = slot == 6 || slot == 12;
+  if (!is_bool) {
+    for (u32 j = lane; j < ntok; j += 64) {
+      const u8* p = src + b + W.tokpos[j];
+      const u8* lim = src + ce;
+      u64 r = 0; u32 shift = 0; u8 by = 0;
+      for (u32 i = 0; i < 10 && p + i < lim; i++) { by = p[i]; if (shift < 64) r |= (u64)(by & 0x7f) << shift; shift += 7; if (!(by & 0x80)) break; }
+      if (shift < 64 && (by & 0x40)) r |= ~(u64)0 << shift;
+      const i64 sv = (i64)r;
+      u64 hop = 2;
+      if (sv < 0) { u64 n = (u64)0 - (u64)sv; hop = 1 + (n < 0x3FFFFFF0ull ? n : 0x3FFFFFF0ull); }
+      const u64 x = (u64)j + hop;
+      u32 v;
+      if (x < ntok) v = (u32)x;
+      else { u64 skip = x - ntok; if (skip > 0x3FFFFFFFull) skip = 0x3FFFFFFFull; v = 0x80000000u | ((u32)skip << 1) | ((sv >= 0 && skip == 1) ? 1u : 0u); }
+      W.nxt[j] = v;
+    }
+    sd_lds_sync();
+    for (u32 round = 0; round < 12; round++) {   // pointer doubling: 2^12 = AMH_SEG tokens at most
+      for (u32 j = lane; j < ntok; j += 64) {
+        u32 v = W.nxt[j];
+        if (!(v & 0x80000000u)) W.nxt[j] = W.nxt[v];   // in place: whatever a racing lane left there is further along the same chain
+      }
+      sd_lds_sync();
+    }
+    u32* ex = B.sg_exit + B.bc_ebase[e] + k * AMH_SEG;
+    for (u32 j = lane; j < ntok; j += 64) ex[j] = W.nxt[j] & 0x7FFFFFFFu;
+  }
+  if (lane == 0) {
+    B.sg_ntok[seg] = ntok;
+    B.sg_first[seg] = ntok ? b + W.tokpos[0] : AMH_NULL32;
+    B.sg_second[seg] = ntok > 1 ? b + W.tokpos[1] : AMH_NULL32;
+  }
+}
+// thread per big column
+__global__ void __launch_bounds__(64) g_bc_resolve(BatchDev B) {
+  u32 e = blockIdx.x * 64 + threadIdx.x;
+  u32 ncols = B.bc_n[0];
+  if (ncols > B.bc_cap_cols) ncols = B.bc_cap_cols;
+  if (e >= ncols) return;
+  const u32 slot = B.bc_slot[e], s0 = B.bc_seg0[e], ns = B.bc_nseg[e];
+  const bool is_bool = slot == 6 || slot == 12;
+  const ColRef cr = B.desc[B.bc_doc[e]].ocol[bc_slot_col(slot)];
+  u32 skip = 0, rv = 0;
+  for (u32 k = 0; k < ns; k++) {
+    const u32 seg = s0 + k;
+    B.sg_entry[seg] = (skip << 1) | rv;
+    if (is_bool) continue;
+    const u32 nt = B.sg_ntok[seg];
+    if (skip < nt) { u32 x = B.sg_exit[B.bc_ebase[e] + k * AMH_SEG + skip]; skip = x >> 1; rv = x & 1; }
+    else { skip -= nt; if (skip == 0) rv = 0; }
+  }
+  // ranges: a segment's range starts at its first token, or behind it when that token is the value of a run whose header
+  // lies in an earlier segment; it ends where the next range starts
+  u32 next = cr.off + cr.len;
+  for (u32 k = ns; k-- > 0;) {
+    const u32 seg = s0 + k;
+    const u32 nt = B.sg_ntok[seg], en = B.sg_entry[seg];
+    u32 start;
+    if (nt == 0) start = next;
+    else if (en & 1) start = nt > 1 ? B.sg_second[seg] : next;
+    else start = B.sg_first[seg];
+    B.sg_pos[seg] = start;
+    B.sg_end[seg] = next;
+    next = start;
+  }
+}
+template <u32 COL> struct SdDryF {
+  const BatchDev& B;
+  u32 d, mx;
+  __device__ __forceinline__ bool wide(const SdStream& S) const { return SdCol<COL>::HAS_ACC && S.acc >= (1u << 30); }
+  template <bool WIDE>
+  __device__ __forceinline__ u32 group(SdWave& W, SdStream& S, u32 lane, u32 m, u32 b0, u32 nb, i32& fail) {
+    return sd_do_group<COL, WIDE, true>(B, d, W, S, lane, m, b0, nb, 0u, 0u, 0u, mx, fail);
+  }
+};
+// the reader's state at the start of a range, from the resolved entry of its segment
+__device__ __forceinline__ u64 bc_entry_lit(u32 entry) { return (entry & 1) ? 0ull : (u64)(entry >> 1); }
+template <u32 COL>
+__device__ __forceinline__ void bc_measure_range(const BatchDev& B, u32 seg, u32 e, u32 d, SdWave& W) {
+  const u32 lane = threadIdx.x & 63;
+  SdStream S;
+  S.src = B.arena + B.desc[d].chunk_off;
+  S.pos = B.sg_pos[seg]; S.end = B.sg_end[seg];
+  S.want = 0xFFFFFFFFu; S.row = 0; S.lit = bc_entry_lit(B.sg_entry[seg]); S.btok = 0; S.acc = 0;
+  SdDryF<COL> f{B, d, 0u};
+  i32 fail = 0;
+  if (S.pos < S.end) fail = sd_walk(W, S, lane, f, AMH_E_READ_OP);
+  const bool last = seg + 1 == B.bc_seg0[e] + B.bc_nseg[e];
+  if (lane == 0) {
+    B.sg_rows[seg] = S.row; B.sg_acc[seg] = S.acc; B.sg_btok[seg] = S.btok;
+    if (fail || S.row == 0xFFFFFFFFu || (last && S.lit != 0)) B.bc_bad[e] = 1;   // malformed, absurdly long, or the column ends inside a literal run
+  }
+}
+#define BC_COLS(X) X(0, OC_OBJ_ACTOR) X(1, OC_OBJ_CTR) X(2, OC_KEY_ACTOR) X(3, OC_KEY_CTR) X(4, OC_ID_ACTOR) X(5, OC_ID_CTR) X(6, OC_INSERT) \
+  X(7, OC_ACTION) X(8, OC_VAL_META) X(9, OC_SUCC_NUM) X(10, OC_SUCC_ACTOR) X(11, OC_SUCC_CTR) X(12, OC_EXPAND)
+__global__ void __launch_bounds__(64 * SD_WAVES) g_bc_measure(BatchDev B) {
+  __shared__ SdWave L[SD_WAVES];
+  const u32 wave = sd_uniform(threadIdx.x >> 6);
+  const u32 seg = blockIdx.x * SD_WAVES + wave;
+  u32 nsegs = B.bc_n[1];
+  if (nsegs > B.bc_cap_segs) nsegs = B.bc_cap_segs;
+  if (seg >= nsegs) return;
+  const u32 e = B.sg_col[seg], d = B.bc_doc[e];
+  switch (B.bc_slot[e]) {
+#define X(i, col) case i: bc_measure_range<col>(B, seg, e, d, L[wave]); break;
+    BC_COLS(X)
+#undef X
+    default: break;
+  }
+}
+// thread per big column: exclusive sums over its ranges, totals
+__global__ void __launch_bounds__(64) g_bc_prefix(BatchDev B) {
+  u32 e = blockIdx.x * 64 + threadIdx.x;
+  u32 ncols = B.bc_n[0];
+  if (ncols > B.bc_cap_cols) ncols = B.bc_cap_cols;
+  if (e >= ncols) return;
+  const u32 s0 = B.bc_seg0[e], ns = B.bc_nseg[e];
+  u64 rows = 0, acc = 0; u32 btok = 0;
+  for (u32 k = 0; k < ns; k++) {
+    const u32 seg = s0 + k;
+    const u64 r = B.sg_rows[seg], a = B.sg_acc[seg]; const u32 t = B.sg_btok[seg];
+    B.sg_rows[seg] = rows; B.sg_acc[seg] = acc; B.sg_btok[seg] = btok;
+    rows += r; acc += a; btok += t;
+  }
+  B.bc_rows[e] = rows; B.bc_acc[e] = acc;
+}
+__global__ void __launch_bounds__(64 * SD_WAVES) g_bc_decode(BatchDev B) {
+  __shared__ SdWave L[SD_WAVES];
+  const u32 wave = sd_uniform(threadIdx.x >> 6);
+  const u32 seg = blockIdx.x * SD_WAVES + wave;
+  u32 nsegs = B.bc_n[1];
+  if (nsegs > B.bc_cap_segs) nsegs = B.bc_cap_segs;
+  if (seg >= nsegs) return;
+  const u32 e = B.sg_col[seg], d = B.bc_doc[e];
+  if (B.status[d] != 0) return;
+  const u32 pos = B.sg_pos[seg], end = B.sg_end[seg];
+  const bool last = seg + 1 == B.bc_seg0[e] + B.bc_nseg[e];
+  if (pos >= end && !last) return;
+  const u64 r64 = B.sg_rows[seg];
+  const u32 row0 = r64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)r64;
+  const u64 lit = bc_entry_lit(B.sg_entry[seg]), acc = B.sg_acc[seg];
+  const u32 btok = B.sg_btok[seg];
+  switch (B.bc_slot[e]) {
+#define X(i, col) case i: sd_decode_range<col>(B, d, L[wave], pos, end, row0, lit, btok, acc, last); break;
+    BC_COLS(X)
+#undef X
     default: break;
   }
 }
@@ -621,8 +882,21 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_count_seg(BatchDev B) {
   u32 a = 0, b = 0;
   i32 fail;
   if (blockIdx.y == 0) {
-    fail = sd_count_column<SD_CNT_ITEMS>(B, d, w, D.ocol[OC_ID_CTR], B.max_doc_rows + 1, AMH_E_READ_OP, a);
-    if (!fail) fail = sd_count_column<SD_CNT_SUM>(B, d, w, D.ocol[OC_SUCC_NUM], a, AMH_E_READ_OP, b);
+    // columns that were cut into ranges: the totals are known (a column with a malformed token in it, or a succ-count
+    // column that does not hold exactly one value per row, is walked as before: the serial reader's error rules)
+    const u32 ei = bc_is_big(B, D.ocol[OC_ID_CTR].len) ? B.bc_index[d * 13u + BC_SLOT_ID_CTR] : AMH_NULL32;
+    const u32 es = bc_is_big(B, D.ocol[OC_SUCC_NUM].len) ? B.bc_index[d * 13u + BC_SLOT_SUCC_NUM] : AMH_NULL32;
+    bool have_rows = false;
+    fail = 0;
+    if (ei != AMH_NULL32 && !B.bc_bad[ei]) {
+      const u64 r = B.bc_rows[ei];
+      if (r > B.max_doc_rows) fail = AMH_E_TOO_LARGE; else { a = (u32)r; have_rows = true; }
+    }
+    if (!fail && !have_rows) fail = sd_count_column<SD_CNT_ITEMS>(B, d, w, D.ocol[OC_ID_CTR], B.max_doc_rows + 1, AMH_E_READ_OP, a);
+    if (!fail) {
+      if (es != AMH_NULL32 && !B.bc_bad[es] && B.bc_rows[es] == (u64)a && B.bc_acc[es] <= (u64)B.max_doc_rows) b = (u32)B.bc_acc[es];
+      else fail = sd_count_column<SD_CNT_SUM>(B, d, w, D.ocol[OC_SUCC_NUM], a, AMH_E_READ_OP, b);
+    }
   } else {
     fail = sd_count_column<SD_CNT_UNTIL_NULL>(B, d, w, D.ccol[CC_ACTOR], B.max_doc_rows + 1, AMH_E_READ_CHANGE, a);
     if (!fail) fail = sd_count_column<SD_CNT_SUM>(B, d, w, D.ccol[CC_DEPS_NUM], a, AMH_E_READ_CHANGE, b);

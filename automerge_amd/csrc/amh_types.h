@@ -188,6 +188,16 @@ struct BatchDev {
   const u8* expect_hash;         // [tot_chg * 32] merge / apply: the hashes the changes of a merged document came with (k_verify_hash)
   u32* first_len;                // [n_docs] bytes of the document chunk an input starts with (0: it starts with a change chunk; the input's
                                  // length: nothing readable behind it) — what the host needs to know to find trailing change chunks
+  // A column of one document over many waves (device form; amh_segdec.inl): column streams of AMH_BIGCOL bytes and more
+  // are cut into segments of AMH_SEG bytes.  bc_* = per big column, sg_* = per segment.  bc_n = nullptr: none in this batch.
+  u32* bc_n;                     // [4] big columns found, segments, exit-table entries
+  u32 bc_cap_cols, bc_cap_segs, bc_cap_bytes;
+  u32* bc_index;                 // [n_docs * 13] entry of (document, decode slot) in bc_*, AMH_NULL32 = a small column
+  u32 *bc_doc, *bc_slot, *bc_seg0, *bc_nseg, *bc_ebase, *bc_bad;
+  u64 *bc_rows, *bc_acc;         // totals over the column: rows, running sum
+  u32 *sg_col, *sg_first, *sg_second, *sg_ntok, *sg_entry, *sg_pos, *sg_end, *sg_btok;
+  u64 *sg_rows, *sg_acc;         // per segment, then the exclusive prefix inside the column
+  u32* sg_exit;                  // [bc_cap_bytes] per token of a segment: (tokens to skip in the following segments << 1) | the first of them is a run's value
   u32 skip_doc_sha;              // chunks written by merge / apply for the engine's own reload: no checksum is written or checked
   u32 max_doc_rows;              // per-document limit on op rows / succ entries / changes / deps (amh_ctx_set_limits; default AMH_MAX_ROWS_PER_DOC)
   u32* big_n;                    // [1] recorded lists
