@@ -691,6 +691,15 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   launch(ctx, AK_ACTORS, B, n);
   launch(ctx, AK_CHG_INIT, B, B.tot_chg);
   launch(ctx, AK_DECODE_CHG, B, n);
+#ifndef AMH_EMU
+  B.fr_n = nullptr;
+  if ((u64)B.tot_rows + B.tot_succ >= 8192 && !getenv("AMH_NO_BIGCOL")) {   // runs of 8192 rows and more are filled by the whole grid
+    B.fr_cap = (u32)(2 * 13 * (((u64)B.tot_rows + B.tot_succ) / 8192 + 1) + 64);   // runs of >= 8192 rows, in pieces of <= 65536
+    B.fr_n = balloc<u32>(b, 4, &ok); B.fr_items = balloc<u32>(b, 8 * (size_t)B.fr_cap, &ok);
+    if (!ok) return fail("device out of memory");
+    rt_memset(B.fr_n, 0, 16, ctx->stream);
+  }
+#endif
   launch(ctx, AK_DECODE_OPS, B, n * OC_COUNT);
   return load_tail(ctx, b, big, opts, trailing, false, nullptr);
 }

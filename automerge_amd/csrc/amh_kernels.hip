@@ -185,6 +185,14 @@ __device__ __forceinline__ void decode_str_body(const BatchDev& B, DsShared& S) 
       if (n == 0) continue;
       const u32 r_begin = S.it_rs[l][0], r_end = S.it_rs[l][n], rb = S.rb[l];
       for (u32 r0 = r_begin; r0 < r_end; r0 += 64) {
+        // whole blocks of 64 rows inside one null item (a text document's key column is one null run of millions of
+        // rows): the arrays already hold the null pattern (the host's fill), nothing to store
+        u32 k0 = 0;
+        for (u32 j = 1; j < n; j++) k0 = S.it_rs[l][j] <= r0 ? j : k0;
+        if (S.it_len[l][k0] == AMH_NULL32 && S.it_rs[l][k0 + 1] >= r0 + 64) {
+          r0 += 64 * ((S.it_rs[l][k0 + 1] - r0) / 64 - 1);
+          continue;
+        }
         const u32 r = r0 + lane;
         u32 k = 0;
         for (u32 j = 1; j < n; j++) k = S.it_rs[l][j] <= r ? j : k;
@@ -766,6 +774,7 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
   if (k == AK_DECODE_OPS) {
     hipLaunchKernelGGL(g_decode_seg, dim3((B.n_docs + SD_WAVES - 1) / SD_WAVES, SD_NCOLS + 2), dim3(64 * SD_WAVES), 0, s, B);
     if (B.bc_n) hipLaunchKernelGGL(g_bc_decode, dim3((B.bc_cap_segs + SD_WAVES - 1) / SD_WAVES), dim3(64 * SD_WAVES), 0, s, B);
+    if (B.fr_n) hipLaunchKernelGGL(g_fill_runs, dim3(2048), dim3(AMH_BLOCK), 0, s, B);
     return;
   }
   if (k == AK_SAVE_SIZE || k == AK_SAVE_STORE) {

@@ -240,6 +240,7 @@ __device__ __forceinline__ u32 sd_row_item(SdWave& W, u32 cnt, u32 rs, u32 lane,
 }
 
 // A column stream of AMH_BIGCOL bytes and more is not walked by one wave: see "a column over many waves" at the end.
+#define AMH_BIGRUN 8192u
 #define AMH_BIGCOL (32u << 10)
 #define AMH_SEG 4096u
 __device__ __forceinline__ bool bc_is_big(const BatchDev& B, u32 len) { return B.bc_n != nullptr && len >= AMH_BIGCOL; }
@@ -420,7 +421,30 @@ __device__ __forceinline__ u32 sd_do_group(const BatchDev& B, u32 d, SdWave& W, 
     }
     if (lane < R) sd_store_row<COL>(B, d, orow + lane, a, b, cc);
   } else {
+    // a run of AMH_BIGRUN rows and more is left to the whole grid (g_fill_runs): one wave storing 64 rows at a time is
+    // the serial part of a 10M-row document whose object / action / value-meta columns are a handful of runs
+    const bool defer = B.fr_n != nullptr && reach >= AMH_BIGRUN;
+    if (defer) {   // in pieces of 64 Ki rows: a block of g_fill_runs each
+      const u32 st = COL == OC_SUCC_NUM ? e0 : step;
+      const u32 c0 = (C::IS_DELTA || COL == OC_VAL_META || COL == OC_SUCC_NUM) ? e2 : 0u;
+      for (u32 q = 0; q < reach; q += 65536u) {
+        u32 i = atomicAdd(B.fr_n, 1u);
+        if (i >= B.fr_cap) break;
+        u32* it = B.fr_items + 8 * (size_t)i;
+        it[0] = COL; it[1] = d; it[2] = orow + I.rs + q; it[3] = reach - q < 65536u ? reach - q : 65536u;
+        it[4] = (C::IS_DELTA) ? 0u : e0; it[5] = e1; it[6] = c0 + st * q; it[7] = st;
+      }
+    }
+    const u64 defer_m = __ballot(defer);
     for (u32 r0 = 0; r0 < R; r0 += 64) {
+      if (defer_m) {   // whole blocks of 64 rows inside a deferred run: skipped (its first and last partial blocks are written here too)
+        const u64 cover = __ballot(cnt != 0 && I.rs <= r0 && r0 - I.rs < cnt) & defer_m;
+        if (cover) {
+          const u32 tl = (u32)__builtin_ctzll(cover);
+          const u32 endr = sd_bcast(I.rs + reach, tl);
+          if (endr >= r0 + 64) { r0 += 64 * ((endr - r0) / 64 - 1); continue; }
+        }
+      }
       const u32 t = sd_row_item(W, cnt, I.rs, lane, r0);
       const u32 my = r0 + lane;
       const u32 k = my - (u32)__shfl((int)I.rs, (int)t, 64);
@@ -560,6 +584,24 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_decode_seg(BatchDev B) {
     DC(7, OC_ACTION) DC(8, OC_VAL_META) DC(9, OC_SUCC_NUM) DC(10, OC_SUCC_ACTOR) DC(11, OC_SUCC_CTR) DC(12, OC_EXPAND)
 #undef DC
     default: break;
+  }
+}
+
+// the deferred runs: a block per piece of at most 64 Ki rows
+__global__ void __launch_bounds__(AMH_BLOCK) g_fill_runs(BatchDev B) {
+  u32 n = *B.fr_n;
+  if (n > B.fr_cap) n = B.fr_cap;
+  const u32 tid = threadIdx.x, nth = AMH_BLOCK;
+  for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+    const u32* it = B.fr_items + 8 * (size_t)i;
+    const u32 col = it[0], d = it[1], o = it[2], cnt = it[3], a = it[4], b = it[5], c0 = it[6], st = it[7];
+    switch (col) {
+#define X(i_, c_) case c_: for (u32 k = tid; k < cnt; k += nth) sd_store_row<c_>(B, d, o + k, a, b, c0 + st * k); break;
+      X(0, OC_OBJ_ACTOR) X(1, OC_OBJ_CTR) X(2, OC_KEY_ACTOR) X(3, OC_KEY_CTR) X(4, OC_ID_ACTOR) X(5, OC_ID_CTR) X(6, OC_INSERT)
+      X(7, OC_ACTION) X(8, OC_VAL_META) X(9, OC_SUCC_NUM) X(10, OC_SUCC_ACTOR) X(11, OC_SUCC_CTR) X(12, OC_EXPAND)
+#undef X
+      default: break;
+    }
   }
 }
 

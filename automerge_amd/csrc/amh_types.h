@@ -198,6 +198,11 @@ struct BatchDev {
   u32 *sg_col, *sg_first, *sg_second, *sg_ntok, *sg_entry, *sg_pos, *sg_end, *sg_btok;
   u64 *sg_rows, *sg_acc;         // per segment, then the exclusive prefix inside the column
   u32* sg_exit;                  // [bc_cap_bytes] per token of a segment: (tokens to skip in the following segments << 1) | the first of them is a run's value
+  // runs of AMH_BIGRUN rows and more met by the column decoders are not expanded by the wave that decodes them: they are
+  // recorded here and filled by the whole grid afterwards (g_fill_runs).  fr_n = nullptr: expand in place.
+  u32* fr_n;                     // [1]
+  u32* fr_items;                 // [fr_cap * 8] column, document, first row (absolute), rows, a, b, c0, step
+  u32 fr_cap;
   u32 skip_doc_sha;              // chunks written by merge / apply for the engine's own reload: no checksum is written or checked
   u32 max_doc_rows;              // per-document limit on op rows / succ entries / changes / deps (amh_ctx_set_limits; default AMH_MAX_ROWS_PER_DOC)
   u32* big_n;                    // [1] recorded lists
