@@ -373,6 +373,43 @@ def test_million_op_documents(engine):
     assert again.hydrate_json(0) == bs[0].hydrate_json(0)
 
 
+def test_damaged_large_columns(engine, monkeypatch):
+    """a 300k-op document (columns of hundreds of KB: cut into ranges, a wave each) with single bytes damaged all over its
+    column data and the checksum made good again: the same accept / reject decision as the oracle, the
+    same content when both accept; and the same again with the range path switched off (one wave per column)"""
+    import hashlib
+    import random
+    import oracle_lib as o
+    blob, offs = engine.gen_text_docs(0xDA3A6E, 1, 1, 500, 300000, 600, 8)
+    doc = bytes(blob[offs[0]:offs[1]])
+    rng = random.Random(17)
+    variants = [doc]
+    for k in range(14):
+        d = bytearray(doc)
+        pos = rng.randrange(len(d) // 3, len(d) - 8)      # behind the header and the change columns
+        d[pos] = rng.choice([0x00, 0x7f, 0x80, 0xff, d[pos] ^ 0x01, d[pos] ^ 0x40])
+        d[4:8] = hashlib.sha256(bytes(d[8:])).digest()[:4]
+        variants.append(bytes(d))
+    want = []
+    for v in variants:
+        try:
+            r = o.Doc.load(v)
+            want.append((0, r.get_heads(), hashlib.sha256(r.hydrate_json().encode()).hexdigest()))
+        except o.OracleError as e:
+            want.append((e.kind, None, None))
+    assert want[0][0] == 0 and any(w[0] != 0 for w in want)
+    for mode in ("ranges", "one wave per column"):
+        if mode != "ranges":
+            monkeypatch.setenv("AMH_NO_BIGCOL", "1")
+        b = engine.load_batch(variants)
+        for i, w in enumerate(want):
+            kind, _ = b.status(i)
+            assert (kind == 0) == (w[0] == 0), (mode, i, kind, w[0])
+            if kind == 0:
+                assert b.get_heads(i) == w[1] and hashlib.sha256(b.hydrate_json(i).encode()).hexdigest() == w[2], (mode, i)
+        b.close()
+
+
 def test_hash_id_tables(engine, golden_dir, monkeypatch):
     """documents whose op ids are sparse use an open-addressing id table instead of the direct one: force that form"""
     monkeypatch.setenv("AMH_HT_HASH", "1")
