@@ -515,7 +515,10 @@ static bool big_hash_changes(amh_batch* b, u32 d) {
          rt_sync(ctx->stream);
 }
 
-static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, struct BigSha& big, const amh_load_opts* opts, bool trailing, bool from_rows, const u8* expect_hash);
+// merge: the change chunks of a merged document are those of its sources (already verified when they were loaded /
+// decoded): where they lie on the device, in history order
+struct AdoptHistory { std::vector<u64> src; std::vector<u32> len; };
+static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, struct BigSha& big, const amh_load_opts* opts, bool trailing, bool from_rows, const u8* expect_hash, const AdoptHistory* adopt = nullptr);
 // bytes of derived arrays a batch with these totals takes on the device through load (rows: the op columns, the
 // change view, the id tables; succ: entries, preds and the delete table; changes: metadata and column lengths), a
 // little on the high side
@@ -708,7 +711,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
 // re-encode and hashing, heads, visibility.  Entered after the decode of a document batch (load_staged_impl) or with the
 // rows a merge / apply just put in document order (mg_execute, from_rows: nothing is saved and decoded in between; the
 // re-derived hashes are then checked against the hashes the changes came with, expect_hash).
-static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_load_opts* opts, bool trailing, bool from_rows, const u8* expect_hash) {
+static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_load_opts* opts, bool trailing, bool from_rows, const u8* expect_hash, const AdoptHistory* adopt) {
   BatchDev& B = b->B;
   const u32 n = B.n_docs;
   const size_t NC = (size_t)B.tot_chg + 2;
@@ -763,6 +766,28 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
   if (!scan_inplace(b, B.c_op_base, B.tot_chg, &tot_ops)) return fail("scan failed");
   if (tot_ops == 0xFFFFFFFFu) return fail("batch too large");
   B.tot_ops = tot_ops;
+  if (adopt) {
+    // The history of a merged document = the verified change chunks of its sources, in the merged order: gathered into
+    // the batch's out_arena (as the reference's merge keeps the stored changes); no op -> change-order view, re-encode or
+    // hashing.  AMH_VERIFY_MERGE=1 takes the other branch (every change re-derived from the merged rows and compared).
+    const u32 nc = B.tot_chg;
+    std::vector<u32> off((size_t)nc + 1, 0);
+    u64 run = 0;
+    for (u32 c = 0; c < nc; c++) { off[c] = (u32)run; run += adopt->len[c]; if (run >= 0xFFFFFFF0ull) return fail("batch too large: change chunks exceed 4 GiB"); }
+    off[nc] = (u32)run;
+    b->tot_out = (u32)run;
+    B.out_arena = balloc<u8>(b, (size_t)run + 256, &ok);
+    u64* d_src = balloc<u64>(b, (size_t)nc + 1, &ok);
+    if (!ok) return fail("device out of memory");
+    if ((nc && (!rt_h2d(d_src, adopt->src.data(), (size_t)nc * sizeof(u64), ctx->stream) || !rt_h2d(B.c_out_len, adopt->len.data(), (size_t)nc * sizeof(u32), ctx->stream))) ||
+        !rt_h2d(B.c_out_off, off.data(), ((size_t)nc + 1) * sizeof(u32), ctx->stream))
+      return fail("H2D copy failed");
+    rt_event_record(&ctx->ev_fork2, ctx->stream);
+    rt_stream_wait(ctx->side, &ctx->ev_fork2);
+    launch_on(ctx, ctx->side, AK_VISIBLE, B, B.tot_rows);
+    rt_event_record(&ctx->ev_join, ctx->side);
+    amh_copy_bytes(d_src, B.c_out_len, B.c_out_off, B.out_arena, nc, (void*)ctx->stream);
+  } else {
   B.ops_sorted = balloc<u32>(b, (size_t)tot_ops + 1, &ok);
   if (!ok) return fail("device out of memory");
   rt_memset(B.ops_sorted, 0xFF, ((size_t)tot_ops + 1) * 4, ctx->stream);
@@ -831,6 +856,7 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
     }
   }
   if (expect_hash) { B.expect_hash = expect_hash; launch(ctx, AK_VERIFY_HASH, B, B.tot_chg); }
+  }
   launch(ctx, AK_HEADS, B, n);
   rt_stream_wait(ctx->stream, &ctx->ev_join);   // visibility is in
   b->status.resize(n);
@@ -1358,6 +1384,9 @@ struct ApplyRun {
   std::vector<u8> c_applied;
   std::vector<u64> h_start_op;       // [n_chunks] first op counter of the chunk's change
   std::vector<u32> h_nops;           // [n_chunks] its ops (deletes included)
+  std::vector<u64> h_chunk_off;      // [n_chunks] where the chunk lies in U's arena
+  std::vector<u32> h_chunk_len;
+  bool all_dev = false;              // every chunk came out of a loaded batch's device memory (merge): verified and canonical by construction
   std::vector<DocDesc> s_desc;       // per pair: region of the arena holding its chunks
   std::vector<DocCounts> s_cnt;      // per pair: rows of U
   std::vector<u32> s_row_base;       // [P + 1]
@@ -1407,7 +1436,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
 // document order (M) instead of from saved bytes: M's arrays are what the decode would have produced, the rest of the
 // load pipeline (load_tail) derives everything else and re-verifies every change (re-encode, SHA-256, against the hash
 // the change came with).  M's arrays are borrowed from the merge scratch until adopt_merged_arrays hands them over.
-static amh_batch* rows_to_batch(amh_ctx* ctx, amh_batch* mb, const MergeDev& G, const MgPlan& pl, const ApplyRun* ap, u8* m_arena, const char* who) {
+static amh_batch* rows_to_batch(amh_ctx* ctx, amh_batch* mb, const amh_batch* dst, const MergeDev& G, const MgPlan& pl, const ApplyRun* ap, u8* m_arena, const char* who) {
   const BatchDev& M = G.M;
   const u32 P = pl.P;
   auto* st = new amh_staged();
@@ -1475,7 +1504,9 @@ static amh_batch* rows_to_batch(amh_ctx* ctx, amh_batch* mb, const MergeDev& G, 
   B.a_first_chg = balloc<u32>(nb, NA, &ok); B.a_last_chg = balloc<u32>(nb, NA, &ok);
   B.c_nops = balloc<u32>(nb, NC, &ok); B.c_start_op = balloc<u64>(nb, NC, &ok); B.c_op_base = balloc<u32>(nb, NC, &ok);
   B.c_next_same_actor = balloc<u32>(nb, NC, &ok); B.c_level = balloc<u32>(nb, NC, &ok);
-  B.c_hash = balloc<u8>(nb, NC * 32, &ok);
+  // merged from loaded batches: the documents adopt their sources' change chunks and hashes
+  const bool adopt = ap && ap->all_dev && getenv("AMH_VERIFY_MERGE") == nullptr && dst->hv.chg_ok;
+  if (!adopt) B.c_hash = balloc<u8>(nb, NC * 32, &ok);   // else: M's (the hashes the changes came with)
   B.c_out_off = balloc<u32>(nb, NC, &ok); B.c_out_len = balloc<u32>(nb, NC, &ok); B.c_body_len = balloc<u32>(nb, NC, &ok);
   B.c_cols_off = balloc<u32>(nb, NC, &ok); B.c_col_len = balloc<u32>(nb, NC * AMH_NCOLS, &ok); B.c_wide = balloc<u32>(nb, NC, &ok);
   B.c_map_base = balloc<u32>(nb, NC, &ok); B.c_n_other = balloc<u32>(nb, NC, &ok);
@@ -1492,7 +1523,18 @@ static amh_batch* rows_to_batch(amh_ctx* ctx, amh_batch* mb, const MergeDev& G, 
   rt_memset(B.ht_base, 0, (P + 2) * sizeof(u32), ctx->stream); rt_memset(B.dt_base, 0, (P + 2) * sizeof(u32), ctx->stream);
   launch(ctx, AK_M_INIT, B, P);
   BigSha big;   // nothing of a merged document is hashed on the host
-  amh_batch* out = load_tail(ctx, nbh.get(), big, nullptr, false, true, M.c_hash);
+  AdoptHistory ah;
+  if (adopt) {
+    const HostView& ha = dst->hv;
+    const u32 nc = B.tot_chg;
+    ah.src.resize(nc); ah.len.resize(nc);
+    for (u32 c = 0; c < nc; c++) {
+      const u32 from = pl.mc_from[c], x = from & 0x7FFFFFFFu;
+      if (from >> 31) { ah.src[c] = (u64)(uintptr_t)(G.U.arena + ap->h_chunk_off[x]); ah.len[c] = ap->h_chunk_len[x]; }
+      else { ah.src[c] = (u64)(uintptr_t)(G.D.out_arena + ha.c_out_off[x]); ah.len[c] = ha.c_out_len[x]; }
+    }
+  }
+  amh_batch* out = load_tail(ctx, nbh.get(), big, nullptr, false, true, adopt ? nullptr : M.c_hash, adopt ? &ah : nullptr);
   if (!out) { nbh.release(); return nullptr; }   // load_tail freed it
   return nbh.release();
 }
@@ -1500,7 +1542,7 @@ static amh_batch* rows_to_batch(amh_ctx* ctx, amh_batch* mb, const MergeDev& G, 
 static void adopt_merged_arrays(amh_batch* mb, amh_batch* nb, u8* m_arena) {
   const BatchDev& B = nb->B;
   const void* keep[] = {B.status, B.fail_line, B.desc, B.cnt, B.row_base, B.succ_base, B.chg_base, B.actor_base, B.actor_off, B.actor_len, B.actor_rank,
-                        B.actor_by_rank, B.c_actor, B.c_seq, B.c_max_op, B.c_time, B.c_msg_off, B.c_msg_len, B.c_extra_off, B.c_extra_len, B.c_ndeps,
+                        B.actor_by_rank, B.c_hash, B.c_actor, B.c_seq, B.c_max_op, B.c_time, B.c_msg_off, B.c_msg_len, B.c_extra_off, B.c_extra_len, B.c_ndeps,
                         B.c_dep_base, B.dep_idx, B.c_doc, B.c_is_dep, B.r_id_actor, B.r_id_ctr, B.r_obj_actor, B.r_obj_ctr, B.r_key_actor, B.r_key_ctr,
                         B.r_key_off, B.r_key_len, B.r_vraw_off, B.r_mark_off, B.r_mark_len, B.r_succ_cnt, B.r_succ_base, B.r_doc, B.r_insert, B.r_action,
                         B.r_expand, B.r_vmeta, B.s_actor, B.s_ctr};
@@ -1709,7 +1751,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   bool direct = getenv("AMH_MERGE_RELOAD") == nullptr && P == nd;
   for (u32 p = 0; p < P && direct; p++) direct = p_status[p] == 0 && p_a[p] == p && dst->status[p] == 0;
   if (direct) {
-    nb = rows_to_batch(ctx, mb, G, pl, ap, m_arena, who);
+    nb = rows_to_batch(ctx, mb, dst, G, pl, ap, m_arena, who);
     if (!nb) return AMH_ERR_DEVICE;
     bool all_ok = true;
     for (u32 p = 0; p < P; p++) all_ok = all_ok && nb->status[p] == 0;
@@ -2356,7 +2398,12 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   MG_REFS(pl)
   ap.c_applied.assign((size_t)NCH + 1, 0);
   ap.h_start_op.resize(NCH); ap.h_nops.resize(NCH);
-  for (u32 u = 0; u < NCH; u++) { ap.h_start_op[u] = hdr[u].start_op; ap.h_nops[u] = u_cnt[u].n_rows; }
+  ap.h_chunk_off.resize(NCH); ap.h_chunk_len.resize(NCH);
+  for (u32 u = 0; u < NCH; u++) {
+    ap.h_start_op[u] = hdr[u].start_op; ap.h_nops[u] = u_cnt[u].n_rows;
+    ap.h_chunk_off[u] = doc_off[2 * (size_t)u]; ap.h_chunk_len[u] = (u32)(doc_off[2 * (size_t)u + 1] - doc_off[2 * (size_t)u]);
+  }
+  ap.all_dev = NCH != 0 && n_host_staged == 0 && seg_src.size() == NCH;
   ap.amap_base.assign((size_t)NCH + 1, 0);
   ap.ix_base.assign(P + 1, 0);
   std::vector<std::vector<u32>> new_queue(P);

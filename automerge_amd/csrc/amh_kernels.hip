@@ -1181,6 +1181,30 @@ __global__ void __launch_bounds__(AMH_BLOCK) g_copy_segments(const u64* src, con
   u32 n = (len[i] + 15) / 16;
   for (u32 k = threadIdx.x; k < n; k += AMH_BLOCK) d[k] = s[k];
 }
+// one block per segment, any alignment: dwords where source and destination share their phase, bytes otherwise
+__global__ void __launch_bounds__(AMH_BLOCK) g_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst) {
+  const u32 i = blockIdx.x;
+  const u8* s = (const u8*)(uintptr_t)src[i];
+  u8* d = dst + dst_off[i];
+  const u32 n = len[i];
+  if ((((uintptr_t)s ^ (uintptr_t)d) & 3) == 0) {
+    u32 head = (4 - ((uintptr_t)d & 3)) & 3;
+    if (head > n) head = n;
+    if (threadIdx.x < head) d[threadIdx.x] = s[threadIdx.x];
+    const u32 words = (n - head) / 4;
+    const u32* sw = (const u32*)(s + head);
+    u32* dw = (u32*)(d + head);
+    for (u32 k = threadIdx.x; k < words; k += AMH_BLOCK) dw[k] = sw[k];
+    const u32 done = head + 4 * words;
+    if (threadIdx.x < n - done) d[done + threadIdx.x] = s[done + threadIdx.x];
+  } else {
+    for (u32 k = threadIdx.x; k < n; k += AMH_BLOCK) d[k] = s[k];
+  }
+}
+void amh_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst, u32 n, void* stream) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(g_copy_bytes, dim3(n), dim3(AMH_BLOCK), 0, (hipStream_t)stream, src, len, dst_off, dst);
+}
 void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void* stream) {
   if (n == 0) return;
   hipLaunchKernelGGL(g_copy_segments, dim3(n), dim3(AMH_BLOCK), 0, (hipStream_t)stream, src, len, dst_off, dst);

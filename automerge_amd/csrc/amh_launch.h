@@ -35,6 +35,8 @@ void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream);
 // copy n byte segments inside device memory: segment i = len[i] bytes from address src[i] to dst + dst_off[i]
 // (16-byte aligned on both sides).  The three tables live in device memory.
 void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void* stream);
+// the same for segments of any alignment and length (change chunks into an out_arena)
+void amh_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst, u32 n, void* stream);
 
 // amh_sync_summaries_noalloc: size / scan / fill with the offsets and scan temporaries in a static device array
 // (amh_kernels.hip).  0 = launched; 1 = device error; 2 = over the static limit.  HIP build only.

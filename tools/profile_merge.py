@@ -10,7 +10,11 @@ staged = [e.stage(reps[r]) for r in range(R)]
 ids = list(range(N))
 def step(verbose=False):
     t0 = time.time()
-    bs = [e.load_staged(s) for s in staged]
+    bs = []
+    for r, s in enumerate(staged):
+        bs.append(e.load_staged(s))
+        if r:
+            bs[-1].release_ops()
     t1 = time.time()
     assert bs[0].merge_many(bs[1:], ids, [ids] * (R - 1)) == 0
     t2 = time.time()
