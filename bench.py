@@ -233,7 +233,7 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
                           "merge_call": "sequential amh_merge_batch" if args.sequential_merges else "amh_merge_many", "gen_s": round(t_gen, 2),
                           "stage_s": round(t_stage, 3),   # host bytes -> HBM through the pinned double buffer (amh_stage_batch), outside the timed region
                           "pcie_inclusive_ops_per_s": ops_all / (elapsed_max / args.steps + t_stage),
-                          "note": "ops counted once per merged document; every merged document is re-derived and re-verified (change hashes, heads) before it replaces the old one"},
+                          "note": "ops counted once per merged document; every replica is loaded in full (every change re-derived from the ops, SHA-256 hashed, heads checked); the merged document keeps those verified change chunks, as the reference's merge keeps stored changes (AMH_VERIFY_MERGE=1 re-derives them from the merged rows as well)"},
                "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "traffic": traffic, "algorithmic_bytes_per_launch": model[dom] / dom_calls, "launch_ms": dom_ms / dom_calls,
                             "launches_per_step": dom_calls, "kernel_ms_total": total_kernel_ms},
