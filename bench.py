@@ -202,16 +202,26 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
     else:
         elapsed_max, ops_all = elapsed, float(ops)
     if rank == 0:
-        # bytes every load-pipeline kernel must move, summed over the document batches of a step: R source loads and
-        # the re-verification load of the merged documents per slice (the kernels of the change chunks handed to the
-        # apply path run under the same names and are in the times but not in the bytes: the fraction is a lower bound)
+        # bytes every load-pipeline kernel must move, summed over the document batches it runs over in a step: the R source
+        # loads and, for the kernels of the tail that still run over them, the merged documents (the kernels of the change
+        # chunks handed to the apply path run under the same names and are in the times but not in the bytes: the
+        # fraction is a lower bound)
         model = {}
+        # kernels that do not run over the merged documents: their rows come from the merge (nothing is parsed or decoded),
+        # and unless AMH_VERIFY_MERGE is set their changes are the sources' chunks (nothing is re-encoded or hashed)
+        not_on_merged = {"parse", "sha_doc", "count", "extract", "actors", "chg_init", "decode_chg", "decode_ops", "rows"}
+        if not os.environ.get("AMH_VERIFY_MERGE") and not args.sequential_merges:
+            not_on_merged |= {"place", "pred_slot_cnt", "pred_slot_base", "pred_fill", "pred_sort", "actor_mark", "actor_rank", "change_view",
+                              "encode_size", "chg_layout", "encode_store", "chg_header", "chg_hash"}
         for sl in stats:
-            for st, cols in sl:
+            for bi, (st, cols) in enumerate(sl):
                 st = dict(st)
                 st["actors"] = 2 * st["n_docs"]
                 st["actor_map"] = 2 * st["changes"]
+                merged = bi == len(sl) - 1
                 for kname, v in algorithmic_bytes(st, cols).items():
+                    if merged and kname in not_on_merged:
+                        continue
                     model[kname] = model.get(kname, 0) + v
         OVERLAPPED = ("sha_doc", "visible")
         ranked = sorted((k for k in kt if kt[k][1] > 0 and k not in OVERLAPPED and k in model), key=lambda k: -kt[k][0])
