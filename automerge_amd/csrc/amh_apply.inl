@@ -22,7 +22,7 @@ AMH_DEV void k_ap_parse(const MergeDev& G, u32 c) {
   for (int i = 0; i < CC_COUNT; i++) { D.ccol[i].off = 0; D.ccol[i].len = 0; }
   for (int i = 0; i < OC_COUNT; i++) { D.ocol[i].off = 0; D.ocol[i].len = 0; }
   H.deps_off = H.n_deps = H.actor_off = H.actor_len = H.msg_off = H.msg_len = H.others_off = H.n_other = H.extra_off = H.extra_len = 0;
-  H.seq = H.start_op = 0; H.time = 0; H.mark_len = 0; H.pad_ = 0;
+  H.seq = H.start_op = 0; H.time = 0; H.mark_len = 0; H.head_len = 0;
   u64 start = U.doc_off[2 * (u64)c], avail = U.doc_off[2 * (u64)c + 1] - start;
   D.chunk_off = start;
   D.chunk_len = 0;
@@ -62,6 +62,7 @@ AMH_DEV void k_ap_parse(const MergeDev& G, u32 c) {
     pos += al;
   }
   u64 meta_pos = pos, otot = 0;
+  H.head_len = (u32)meta_pos;
   int rc = parse_col_meta<2>(p, pos, end, len, otot, (ColMapper*)0);
   if (rc) { amh_fail(U, c, rc == 2 ? AMH_E_UNSUPPORTED : AMH_E_PARSE); return; }
   if (otot > end - pos) { amh_fail(U, c, AMH_E_PARSE); return; }

@@ -97,6 +97,8 @@ struct amh_ctx {
   // every call, and the H2D copy of the change chunks runs at the pinned rate
   u8* stage = nullptr;
   size_t stage_cap = 0;
+  u8* heads = nullptr;            // pinned: the packed heads of device-resident change chunks on their way to the host
+  size_t heads_cap = 0;
   u8* pin[2] = {nullptr, nullptr};   // pinned staging buffers of amh_stage_batch (double-buffered H2D), kept for the context's life
   rt_event ev_pin[2]{};
   bool profiling = false;
@@ -2269,7 +2271,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     });
   }
   std::vector<u64> seg_src, seg_dst;
-  std::vector<u32> seg_len;
+  std::vector<u32> seg_len, h_head_len, h_head_off;
   size_t n_host_staged = 0;
   for (u32 u = 0; u < staged_of.size(); u++) {
     const HostChunk& hc = chunks[staged_of[u]];
@@ -2318,10 +2320,6 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
           !rt_h2d(d_len, seg_len.data(), ns * sizeof(u32), ctx->stream))
         return faild("H2D copy failed");
       amh_copy_segments(d_src, d_len, d_dst, d_arena, ns, (void*)ctx->stream);
-      rt_event_record(&ctx->ev_fork, ctx->stream);
-      rt_stream_wait(ctx->side, &ctx->ev_fork);
-      if (!rt_d2h(h_arena.data(), d_arena, h_arena.size(), ctx->side)) return faild("D2H copy failed");
-      rt_event_record(&ctx->ev_join, ctx->side);
     }
     rt_memset(U.status, 0, (NCH + 1) * sizeof(i32), ctx->stream);
     rt_memset(U.fail_line, 0, (NCH + 1) * sizeof(u32), ctx->stream);
@@ -2339,6 +2337,30 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     };
     mg0(MK_AP_PARSE, NCH);
     launch(ctx, AK_SHA_DOC, U, NCH);
+    u32 *d_hl = nullptr, *d_ho = nullptr;
+    u8* d_heads = nullptr;
+    u32 heads_total = 0;
+    if (!seg_src.empty()) {
+      // Of the device-resident chunks the host reads the heads only (author and other actors, dependency hashes): those
+      // are packed on the device and come back with the other results of this pass; the rest of a chunk is fetched only
+      // if it ends up in the document's queue (commit_queues).
+      d_hl = balloc<u32>(hb, (size_t)NCH + 2, &ok); d_ho = balloc<u32>(hb, (size_t)NCH + 2, &ok);
+      if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+      amh_ap_head_len(ap.d_hdr, U.status, d_hl, NCH, (void*)ctx->stream);
+      if (!rt_d2d(d_ho, d_hl, (size_t)NCH * sizeof(u32), ctx->stream)) return faild("device copy failed");
+      if (!scan_inplace(hb, d_ho, NCH, &heads_total)) return faild("scan failed");
+      if (heads_total == 0xFFFFFFFFu) { set_error(ctx, std::string(who) + ": batch too large"); return AMH_ERR_BATCH_TOO_LARGE; }
+      d_heads = balloc<u8>(hb, (size_t)heads_total + 16, &ok);
+      if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+      if ((size_t)heads_total + 16 > ctx->heads_cap) {
+        if (ctx->heads) rt_host_free(ctx->heads);
+        ctx->heads_cap = ((size_t)heads_total + 16) + ((size_t)heads_total + 16) / 4;
+        ctx->heads = (u8*)rt_host_alloc(ctx->heads_cap);
+        if (!ctx->heads) { ctx->heads_cap = 0; set_error(ctx, std::string(who) + ": out of host memory"); return AMH_ERR_OOM; }
+      }
+      amh_ap_head_copy(d_arena, d_off, d_hl, d_ho, d_heads, NCH, (void*)ctx->stream);
+      h_head_len.resize(NCH); h_head_off.resize(NCH);
+    }
     mg0(MK_AP_COUNT, NCH);
     u32 tot_rows = 0, tot_preds = 0;
     for (int attempt = 0;; attempt++) {
@@ -2380,13 +2402,19 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     rt_memset(U.s_row, 0xFF, NS * 4, ctx->stream);
     launch(ctx, AK_DECODE_OPS, U, NCH * OC_COUNT);
     mg0(MK_AP_VERIFY, tot_rows);
-    if (!seg_src.empty()) rt_stream_wait(ctx->stream, &ctx->ev_join);
+    if (!seg_src.empty() && (!rt_d2h(ctx->heads, d_heads, (size_t)heads_total, ctx->stream) || !rt_d2h(h_head_len.data(), d_hl, (size_t)NCH * sizeof(u32), ctx->stream) ||
+                             !rt_d2h(h_head_off.data(), d_ho, (size_t)NCH * sizeof(u32), ctx->stream)))
+      return faild("D2H copy failed");
     if (!rt_d2h(u_status.data(), U.status, NCH * sizeof(i32), ctx->stream) || !rt_d2h(hdr.data(), ap.d_hdr, NCH * sizeof(ChgHdr), ctx->stream) ||
         !rt_d2h(u_cnt.data(), U.cnt, NCH * sizeof(DocCounts), ctx->stream) ||
         !rt_d2h(u_hash.data(), U.doc_hash, (size_t)NCH * 32, ctx->stream) || !rt_d2h(u_row_base.data(), U.row_base, (NCH + 1) * sizeof(u32), ctx->stream) ||
         !rt_sync(ctx->stream))
       return faild("device pipeline failed");
     collect_profile(ctx);
+    if (!seg_src.empty())   // the heads go to their places in the host's picture of the arena
+      host_parallel_for(NCH, [&](u32 u) {
+        if (chunks[staged_of[u]].dev && h_head_len[u]) memcpy(h_arena.data() + doc_off[2 * (size_t)u], ctx->heads + h_head_off[u], h_head_len[u]);
+      });
   }
   pt.mark("apply: U decode + verify", &ctx->stream);
   view_thread.join();
@@ -2675,11 +2703,16 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   mapa_base[P] = (u32)map_a.size(); mapb_base[P] = (u32)map_b.size();
   m_actor_base[P] = (u32)m_actor_off.size(); m_chg_base[P] = (u32)mc_from.size();
   ap.ix_base[P] = (u32)ap.ix_actor.size();
+  bool queue_fetch_failed = false;
   auto commit_queues = [&]() {
     for (u32 p = 0; p < P; p++) {
       if (!queue_dirty[p] || (p_status[p] > 0)) continue;
       std::vector<std::vector<u8>> nq;
       for (u32 k : new_queue[p]) {
+        if (chunks[k].dev) {   // only its head is on the host
+          nq.emplace_back(chunks[k].len);
+          if (!rt_d2h(nq.back().data(), ap.U.arena + doc_off[2 * (size_t)chunks[k].staged], chunks[k].len, ctx->stream)) queue_fetch_failed = true;
+        } else
         nq.emplace_back(chunks[k].p, chunks[k].p + chunks[k].len);
         memcpy(nq.back().data() + 4, u_hash.data() + (size_t)chunks[k].staged * 32, 4);   // a change accepted with a stale checksum keeps its content hash
       }
@@ -2701,6 +2734,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     for (u32 p = 0; p < P; p++) if (p_status[p] > 0 && results[p] == 0) results[p] = p_status[p];
   }
   commit_queues();
+  if (queue_fetch_failed) { set_error(ctx, std::string(who) + ": D2H copy failed"); return AMH_ERR_DEVICE; }
   for (u32 p = 0; p < P; p++) if (results[p]) rc = AMH_ERR_DOC_FAILED;
   if (rc == AMH_ERR_DOC_FAILED) set_error(ctx, std::string(who) + ": some documents were left unchanged, or (duplicate seq number) changed only by the changes in front of the offender; see the per-document results");
   return rc;
@@ -3151,6 +3185,7 @@ extern "C" void amh_ctx_destroy(amh_ctx* ctx) {
   rt_sync(ctx->side);
   ctx->pool.trim();
   if (ctx->stage) rt_host_free(ctx->stage);
+  if (ctx->heads) rt_host_free(ctx->heads);
 #ifndef AMH_EMU
   if (ctx->comm) { amh_comm_close(ctx->comm); ctx->comm = nullptr; }
 #endif

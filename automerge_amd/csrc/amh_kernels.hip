@@ -1209,6 +1209,30 @@ void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* d
   if (n == 0) return;
   hipLaunchKernelGGL(g_copy_segments, dim3(n), dim3(AMH_BLOCK), 0, (hipStream_t)stream, src, len, dst_off, dst);
 }
+// The heads of the staged change chunks (everything in front of the op column metadata: dependency hashes, author,
+// message, other actors), packed back to back for the copy to the host: the decisions of an apply read nothing else of
+// a chunk, and the heads are a fraction of the bytes.  Lengths and places in units of 16 bytes (chunks start 16-byte
+// aligned and the gap behind each is zero).
+__global__ void __launch_bounds__(AMH_BLOCK) g_ap_head_len(const ChgHdr* hdr, const i32* status, u32* len16, u32 n) {
+  const u32 u = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  if (u < n) len16[u] = status[u] ? 0u : (hdr[u].head_len + 15u) & ~15u;
+}
+__global__ void __launch_bounds__(AMH_BLOCK) g_ap_head_copy(const u8* arena, const u64* doc_off, const u32* len16, const u32* off, u8* dst, u32 n) {
+  const u32 u = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  if (u >= n) return;
+  const uint4* s = (const uint4*)(arena + doc_off[2 * (u64)u]);
+  uint4* d = (uint4*)(dst + off[u]);
+  const u32 k = len16[u] / 16;
+  for (u32 i = 0; i < k; i++) d[i] = s[i];
+}
+void amh_ap_head_len(const ChgHdr* hdr, const i32* status, u32* len16, u32 n, void* stream) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(g_ap_head_len, dim3((n + AMH_BLOCK - 1) / AMH_BLOCK), dim3(AMH_BLOCK), 0, (hipStream_t)stream, hdr, status, len16, n);
+}
+void amh_ap_head_copy(const u8* arena, const u64* doc_off, const u32* len16, const u32* off, u8* dst, u32 n, void* stream) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(g_ap_head_copy, dim3((n + AMH_BLOCK - 1) / AMH_BLOCK), dim3(AMH_BLOCK), 0, (hipStream_t)stream, arena, doc_off, len16, off, dst, n);
+}
 
 
 // ------------------------------------------------------------------------------------------

@@ -37,6 +37,10 @@ void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream);
 void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void* stream);
 // the same for segments of any alignment and length (change chunks into an out_arena)
 void amh_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst, u32 n, void* stream);
+// heads of staged change chunks: len16[u] = bytes in front of chunk u's column metadata rounded up to 16 (0 for failed
+// chunks); the copy packs them at off[u] (exclusive sums of len16) of dst
+void amh_ap_head_len(const ChgHdr* hdr, const i32* status, u32* len16, u32 n, void* stream);
+void amh_ap_head_copy(const u8* arena, const u64* doc_off, const u32* len16, const u32* off, u8* dst, u32 n, void* stream);
 
 // amh_sync_summaries_noalloc: size / scan / fill with the offsets and scan temporaries in a static device array
 // (amh_kernels.hip).  0 = launched; 1 = device error; 2 = over the static limit.  HIP build only.

@@ -227,7 +227,8 @@ struct ChgHdr {
   u32 extra_off, extra_len;
   u64 seq, start_op;
   i64 time;
-  u32 mark_len, pad_;              // length of the chunk's mark-name column (0 = none): all the host needs of its descriptor
+  u32 mark_len;                    // length of the chunk's mark-name column (0 = none): all the host needs of its descriptor
+  u32 head_len;                    // bytes in front of the op column metadata (all the host reads of a device-resident chunk)
 };
 // apply_changes (automerge.rs:785-914): the change chunks of all pairs are staged as one batch U whose
 // "documents" are the chunks (same column decoders as the document path; the pred group sits in the succ

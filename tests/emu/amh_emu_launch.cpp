@@ -58,6 +58,12 @@ void amh_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst,
 void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void*) {
   for (u32 i = 0; i < n; i++) memcpy(dst + dst_off[i], (const u8*)(uintptr_t)src[i], len[i]);
 }
+void amh_ap_head_len(const ChgHdr* hdr, const i32* status, u32* len16, u32 n, void*) {
+  for (u32 u = 0; u < n; u++) len16[u] = status[u] ? 0u : (hdr[u].head_len + 15u) & ~15u;
+}
+void amh_ap_head_copy(const u8* arena, const u64* doc_off, const u32* len16, const u32* off, u8* dst, u32 n, void*) {
+  for (u32 u = 0; u < n; u++) memcpy(dst + off[u], arena + doc_off[2 * (u64)u], len16[u]);
+}
 
 // Test hook: the register writer (FastWriter: 16-byte stores, in-place widening of long literal headers) against the
 // byte-wise writer (ColWriter) over the same value sequence, for the three encoder kinds.  Returns 0 when the bytes
