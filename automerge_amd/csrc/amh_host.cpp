@@ -99,6 +99,8 @@ struct amh_ctx {
   size_t stage_cap = 0;
   u8* heads = nullptr;            // pinned: the packed heads of device-resident change chunks on their way to the host
   size_t heads_cap = 0;
+  u8* res = nullptr;              // pinned: per-chunk results of an apply's decode pass (headers, counts, hashes)
+  size_t res_cap = 0;
   u8* pin[2] = {nullptr, nullptr};   // pinned staging buffers of amh_stage_batch (double-buffered H2D), kept for the context's life
   rt_event ev_pin[2]{};
   bool profiling = false;
@@ -2054,6 +2056,7 @@ struct ApplyItem {
   struct DevChunk { const u8* d; u32 len; u32 buf; };
   std::vector<DevChunk> dev;
 };
+template <class T> struct PinSpan { T* p = nullptr; T& operator[](size_t i) const { return p[i]; } T* data() const { return p; } };
 struct HostChunk {
   u32 pair = 0;
   const u8* p = nullptr;       // whole type-1 chunk (caller memory, the queue, or `owned`)
@@ -2139,6 +2142,8 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     host_parallel_for(P, [&](u32 p) {
       std::vector<HostChunk>& out = per_pair[p];
       u32 bi = 0;
+      auto qit = dst->queue.find(items[p].doc);
+      out.reserve(items[p].bufs.size() + items[p].dev.size() + (qit != dst->queue.end() ? qit->second.size() : 0));
       for (auto& bf : items[p].bufs) {
         size_t before = out.size();
         split_chunks(p, bf.first, bf.second, out);
@@ -2151,7 +2156,6 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
         hc.pair = p; hc.dev = dc.d; hc.len = dc.len; hc.buf = bi + dc.buf;
         out.push_back(std::move(hc));
       }
-      auto qit = dst->queue.find(items[p].doc);
       if (qit != dst->queue.end())
         for (auto& qb : qit->second) {
           HostChunk hc;
@@ -2160,12 +2164,13 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
         }
     });
     size_t total = 0;
-    for (u32 p = 0; p < P; p++) total += per_pair[p].size();
-    chunks.reserve(total);
-    for (u32 p = 0; p < P; p++) {
-      pc_base[p] = (u32)chunks.size();
-      for (auto& hc : per_pair[p]) chunks.push_back(std::move(hc));
-    }
+    for (u32 p = 0; p < P; p++) { pc_base[p] = (u32)total; total += per_pair[p].size(); }
+    chunks.resize(total);
+    host_parallel_for(P, [&](u32 p) {
+      HostChunk* to = chunks.data() + pc_base[p];
+      for (auto& hc : per_pair[p]) *to++ = std::move(hc);
+      std::vector<HostChunk>().swap(per_pair[p]);
+    });
   }
   pt.mark("apply: split");
   // document chunks inside the streams (load_incremental of a whole saved document): loaded as a batch of their own
@@ -2271,8 +2276,9 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     });
   }
   std::vector<u64> seg_src, seg_dst;
-  std::vector<u32> seg_len, h_head_len, h_head_off;
+  std::vector<u32> seg_len;
   size_t n_host_staged = 0;
+  seg_src.reserve(staged_of.size()); seg_len.reserve(staged_of.size()); seg_dst.reserve(staged_of.size());
   for (u32 u = 0; u < staged_of.size(); u++) {
     const HostChunk& hc = chunks[staged_of[u]];
     if (!hc.dev) { n_host_staged++; continue; }
@@ -2281,11 +2287,28 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   u32 NCH = (u32)staged_of.size();
   ap.n_chunks = NCH;
   pt.mark("apply: stage copy");
-  std::vector<i32> u_status(NCH, 0);
-  std::vector<ChgHdr> hdr(NCH);
-  std::vector<DocCounts> u_cnt(NCH);
-  std::vector<u8> u_hash((size_t)NCH * 32 + 32);
-  std::vector<u32> u_row_base(NCH + 1, 0);
+  // what comes back per chunk lands in pinned memory (pageable copies run at a fraction of the link's rate)
+  PinSpan<i32> u_status; PinSpan<ChgHdr> hdr; PinSpan<DocCounts> u_cnt; PinSpan<u8> u_hash; PinSpan<u32> u_row_base, h_head_len, h_head_off;
+  {
+    auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };
+    const size_t need = al((size_t)NCH * sizeof(i32)) + al((size_t)NCH * sizeof(ChgHdr)) + al((size_t)NCH * sizeof(DocCounts)) + al((size_t)NCH * 32 + 32) + 3 * al(((size_t)NCH + 1) * sizeof(u32)) + 64;
+    if (need > ctx->res_cap) {
+      rt_sync(ctx->stream);
+      if (ctx->res) rt_host_free(ctx->res);
+      ctx->res_cap = need + need / 4;
+      ctx->res = (u8*)rt_host_alloc(ctx->res_cap);
+      if (!ctx->res) { ctx->res_cap = 0; set_error(ctx, std::string(who) + ": out of host memory"); return AMH_ERR_OOM; }
+    }
+    u8* q = ctx->res;
+    u_status.p = (i32*)q; q += al((size_t)NCH * sizeof(i32));
+    hdr.p = (ChgHdr*)q; q += al((size_t)NCH * sizeof(ChgHdr));
+    u_cnt.p = (DocCounts*)q; q += al((size_t)NCH * sizeof(DocCounts));
+    u_hash.p = q; q += al((size_t)NCH * 32 + 32);
+    u_row_base.p = (u32*)q; q += al(((size_t)NCH + 1) * sizeof(u32));
+    h_head_len.p = (u32*)q; q += al(((size_t)NCH + 1) * sizeof(u32));
+    h_head_off.p = (u32*)q;
+    u_row_base[0] = 0;
+  }
   BatchDev& U = ap.U;
   bool ok = true;
   auto faild = [&](const char* m) { set_error(ctx, std::string(who) + ": " + m); collect_profile(ctx); return AMH_ERR_DEVICE; };
@@ -2359,7 +2382,6 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
         if (!ctx->heads) { ctx->heads_cap = 0; set_error(ctx, std::string(who) + ": out of host memory"); return AMH_ERR_OOM; }
       }
       amh_ap_head_copy(d_arena, d_off, d_hl, d_ho, d_heads, NCH, (void*)ctx->stream);
-      h_head_len.resize(NCH); h_head_off.resize(NCH);
     }
     mg0(MK_AP_COUNT, NCH);
     u32 tot_rows = 0, tot_preds = 0;
@@ -3186,6 +3208,7 @@ extern "C" void amh_ctx_destroy(amh_ctx* ctx) {
   ctx->pool.trim();
   if (ctx->stage) rt_host_free(ctx->stage);
   if (ctx->heads) rt_host_free(ctx->heads);
+  if (ctx->res) rt_host_free(ctx->res);
 #ifndef AMH_EMU
   if (ctx->comm) { amh_comm_close(ctx->comm); ctx->comm = nullptr; }
 #endif
