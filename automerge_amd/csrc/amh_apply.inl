@@ -363,7 +363,7 @@ AMH_DEV bool ap_top_less(const MergeDev& G, u32 p, u32 x, u32 y) {
 AMH_DEV bool ap_row_new(const MergeDev& G, u32 r) { return G.new_idx[r + 1] != G.new_idx[r]; }
 AMH_DEV void k_ap_children(const MergeDev& G, u32 r) {
   const ApplyDev& A = G.A;
-  A.o_top[r] = AMH_NULL32;   // jump pointer
+  A.o_top[r] = AMH_NULL32;   // top rows of a long same-gap list: rows in front of it within the gap (k_ap_tie_find)
   A.o_tmp[r] = 0;            // weight
   if (!ap_row_new(G, r)) return;
   u32 p = G.S.r_doc[r];
@@ -371,7 +371,6 @@ AMH_DEV void k_ap_children(const MergeDev& G, u32 r) {
   u32 par = A.parent[r];
   if (par == AMH_NULL32) return;
   if (!ap_row_new(G, par)) { G.p_status[p] = AMH_E_UNSUPPORTED; return; }   // hangs off a row that is not applied: cannot happen for causally ready changes
-  A.o_top[r] = par;
   u32* head = G.S.r_insert[r] ? &A.o_head_ins[par] : &A.o_head_upd[par];
   A.o_next[r] = amh_atomic_exch(head, r);
 }
@@ -413,22 +412,72 @@ AMH_DEV void k_ap_sort_children(const MergeDev& G, u32 r) {
   if (hu != AMH_NULL32 && A.o_next[hu] != AMH_NULL32) A.o_head_upd[r] = ap_sort_list(G, p, hu, false);
   if (hi != AMH_NULL32 && A.o_next[hi] != AMH_NULL32) A.o_head_ins[r] = ap_sort_list(G, p, hi, true);
 }
-// A6c  the top row every new row sits under, by pointer jumping (one launch halves the distances; the host
-//      repeats it until no pointer moved).  Thread per row.
-AMH_DEV void k_ap_jump(const MergeDev& G, u32 r) {
+// A6c  The rows of a subtree in preorder form a list (an element, its updates, then its child elements each with its
+//      subtree); every row finds the row behind it locally, except where a subtree ends: there the walk goes on at
+//      the next sibling of the nearest ancestor that has one.  That "row behind the subtree" (o_up, elements only) is
+//      resolved by pointer jumping over the chain of last children (k_ap_up_jump).  Every row then tells the row
+//      behind it who is in front (k_ap_succ_build), and the lists are ranked towards their top rows by pointer jumping
+//      (k_ap_rank_jump over o_rank = {a row in front, distance to it}: the distances double per launch, threads read
+//      and write whole pairs, so any interleaving keeps "distance to the row named" true).  What is left in o_rank is
+//      every row's top row and its place behind it; the last row of a list gives the top row its weight (k_ap_weight).
+//      Thread per row of U; the host repeats the jump launches until no pointer moved.
+#define AP_UP_END 0x7FFFFFFFu          // nothing behind the subtree (the subtree of a top row ends the list)
+#define AP_UP_TAIL 0x7FFFFFFEu         // left by k_ap_succ_build: the row is the last of its list
+#define AP_UP_OPEN 0x80000000u         // | parent: same as behind the parent's subtree, not yet looked up
+#define AP_RANK_TOP 0x80000000u        // | row: the row named is the list's top row
+AMH_DEV bool ap_row_elem(const BatchDev& S, u32 r) { return S.r_insert[r] && !row_is_prop(S, r); }
+AMH_DEV void k_ap_succ_init(const MergeDev& G, u32 r) {
   const ApplyDev& A = G.A;
-  u32 j = A.o_top[r];
-  if (j == AMH_NULL32) return;
-  u32 jj = A.o_top[j];
-  if (jj == AMH_NULL32) return;
-  A.o_top[r] = jj;
+  A.o_up[r] = AP_UP_END;
+  A.o_rank[r] = (u64)(AP_RANK_TOP | r);
+  if (!ap_row_new(G, r)) return;
+  u32 p = G.S.r_doc[r];
+  if (!mg_pair_ok(G, p) || !ap_row_elem(G.S, r)) return;
+  u32 par = A.parent[r];
+  if (par == AMH_NULL32) return;
+  u32 sib = A.o_next[r];
+  A.o_up[r] = sib != AMH_NULL32 ? sib : (AP_UP_OPEN | par);
+}
+AMH_DEV void k_ap_up_jump(const MergeDev& G, u32 r) {
+  const ApplyDev& A = G.A;
+  u32 u = A.o_up[r];
+  if (!(u & AP_UP_OPEN)) return;
+  A.o_up[r] = A.o_up[u & ~AP_UP_OPEN];
   *A.flag = 1;
+}
+AMH_DEV void k_ap_succ_build(const MergeDev& G, u32 r) {
+  const ApplyDev& A = G.A;
+  if (!ap_row_new(G, r)) return;
+  u32 p = G.S.r_doc[r];
+  if (!mg_pair_ok(G, p)) return;
+  u32 s = AMH_NULL32, par = A.parent[r];
+  if (ap_row_elem(G.S, r)) {
+    s = A.o_head_upd[r];
+    if (s == AMH_NULL32) s = A.o_head_ins[r];
+    if (s == AMH_NULL32 && A.o_up[r] != AP_UP_END) s = A.o_up[r];
+  } else if (par != AMH_NULL32) {   // an update of a new element: the next one, then the element's children, then what follows its subtree
+    s = A.o_next[r];
+    if (s == AMH_NULL32) s = A.o_head_ins[par];
+    if (s == AMH_NULL32 && A.o_up[par] != AP_UP_END) s = A.o_up[par];
+  }
+  if (s != AMH_NULL32) A.o_rank[s] = (u64)r | (1ull << 32);
+  else A.o_up[r] = AP_UP_TAIL;   // nobody else reads it: a row that ends a list has no children
+}
+AMH_DEV void k_ap_rank_jump(const MergeDev& G, u32 r) {
+  const ApplyDev& A = G.A;
+  u64 me = amh_load64(&A.o_rank[r]);
+  u32 n = (u32)me;
+  if (n & AP_RANK_TOP) return;
+  u64 nx = amh_load64(&A.o_rank[n]);
+  amh_store64(&A.o_rank[r], (u64)(u32)nx | (((me >> 32) + (nx >> 32)) << 32));
+  if (!((u32)nx & AP_RANK_TOP)) *A.flag = 1;
 }
 // A6d  weight of a top row = rows of its subtree, itself included.  Thread per row.
 AMH_DEV void k_ap_weight(const MergeDev& G, u32 r) {
-  if (!ap_row_new(G, r)) return;
-  u32 j = G.A.o_top[r];
-  amh_atomic_add(&G.A.o_tmp[j == AMH_NULL32 ? r : j], 1);
+  const ApplyDev& A = G.A;
+  if (A.o_up[r] != AP_UP_TAIL) return;
+  u64 me = A.o_rank[r];
+  A.o_tmp[(u32)me & ~AP_RANK_TOP] = (u32)(me >> 32) + 1;
 }
 // A6e  top rows per gap: rows in front of a dst row (gap_cnt, scanned next) and the list of top rows sharing the gap.
 AMH_DEV void k_ap_top_place(const MergeDev& G, u32 r) {
@@ -460,9 +509,9 @@ AMH_DEV void k_ap_tie_find(const MergeDev& G, u32 r) {
   (void)G; (void)r;
 #endif
 }
-// A6f  emit: a top row starts behind the new rows of smaller gaps (scanned gap_cnt) and behind the top rows of its
-//      own gap that sort in front of it (with their subtrees); its subtree follows in preorder.  Thread per top row.
-AMH_DEV void k_ap_emit(const MergeDev& G, u32 r) {
+// A6f  where a top row goes: behind the new rows of smaller gaps (scanned gap_cnt) and behind the top rows of its own
+//      gap that sort in front of it (with their subtrees).  Thread per top row.
+AMH_DEV void k_ap_top_k(const MergeDev& G, u32 r) {
   const BatchDev& S = G.S;
   const ApplyDev& A = G.A;
   if (!ap_row_new(G, r) || A.parent[r] != AMH_NULL32) return;
@@ -475,22 +524,18 @@ AMH_DEV void k_ap_emit(const MergeDev& G, u32 r) {
   else
   for (u32 m = A.g_head[G.gap_base[p] + g]; m != AMH_NULL32; m = A.o_next[m])
     if (m != r && ap_top_less(G, p, m, r)) k += A.o_tmp[m];
-  u32* stack = A.o_stack + k;   // at most weight - 1 entries: the rows this thread emits
-  G.new_src[k] = r; G.new_gap[k] = g; k++;
-  if (row_is_prop(S, r) || !S.r_insert[r]) return;
-  u32 sp = 0, cur = r;
-  bool first = true;
-  for (;;) {
-    if (!first) { G.new_src[k] = cur; G.new_gap[k] = g; k++; }
-    first = false;
-    for (u32 u = A.o_head_upd[cur]; u != AMH_NULL32; u = A.o_next[u]) { G.new_src[k] = u; G.new_gap[k] = g; k++; }
-    u32 child = A.o_head_ins[cur];
-    u32 sib = cur == r ? AMH_NULL32 : A.o_next[cur];
-    if (child != AMH_NULL32) { if (sib != AMH_NULL32) stack[sp++] = sib; cur = child; }
-    else if (sib != AMH_NULL32) cur = sib;
-    else if (sp) cur = stack[--sp];
-    else break;
-  }
+  A.o_stack[r] = k;
+}
+// A6g  emit: every new row goes behind its top row by its place in the subtree's preorder list.  Thread per row of U.
+AMH_DEV void k_ap_emit(const MergeDev& G, u32 r) {
+  const ApplyDev& A = G.A;
+  if (!ap_row_new(G, r)) return;
+  u32 p = G.S.r_doc[r];
+  if (!mg_pair_ok(G, p)) return;
+  u64 me = A.o_rank[r];
+  u32 t = (u32)me & ~AP_RANK_TOP;
+  u32 k = A.o_stack[t] + (u32)(me >> 32);
+  G.new_src[k] = r; G.new_gap[k] = A.gap[t];
 }
 
 // ------------------------------------------------------------------------------------------

@@ -22,6 +22,8 @@ static inline u32 amh_atomic_exch(u32* p, u32 val) { u32 o = *p; *p = val; retur
 static inline void amh_atomic_inc_grouped(u32* base, u32 idx) { base[idx]++; }
 static inline u64 amh_atomic_cas64(u64* p, u64 cmp, u64 val) { u64 o = *p; if (o == cmp) *p = val; return o; }
 static inline i32 amh_atomic_cas_i32(i32* p, i32 cmp, i32 val) { i32 o = *p; if (o == cmp) *p = val; return o; }
+static inline u64 amh_load64(const u64* p) { return *p; }
+static inline void amh_store64(u64* p, u64 v) { *p = v; }
 #else
 #include <hip/hip_runtime.h>
 #define AMH_DEV __device__ __forceinline__
@@ -51,6 +53,9 @@ AMH_DEV u64 amh_atomic_cas64(u64* p, u64 cmp, u64 val) {
   return atomicCAS((unsigned long long*)p, (unsigned long long)cmp, (unsigned long long)val);
 }
 AMH_DEV i32 amh_atomic_cas_i32(i32* p, i32 cmp, i32 val) { return atomicCAS(p, cmp, val); }
+// whole 8-byte words that other threads of the same launch rewrite (pointer jumping over packed pairs): never torn
+AMH_DEV u64 amh_load64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+AMH_DEV void amh_store64(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 // a list too long for its thread: recorded for the block-per-list kernels (device build; the emulation sorts in place)
 AMH_DEV void big_push(u32* n, u32* items, u32 cap, u32 a, u32 b) {

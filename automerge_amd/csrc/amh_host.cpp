@@ -208,7 +208,7 @@ static void launch(amh_ctx* ctx, int k, const BatchDev& B, u32 n) { launch_on(ct
 static const char* const MK_KERNEL_NAMES[MK_NUM] = {
   "mg_new_flag", "mg_pair_counts", "mg_subtree", "mg_gap", "mg_inherit", "mg_extra_cnt", "mg_rows_dst", "mg_rows_new", "mg_succ_dst",
   "mg_succ_new", "mg_succ_extra", "mg_succ_sort", "mg_doc_succ", "mg_changes", "mg_copy_chunks",
-  "ap_parse", "ap_count", "ap_verify", "ap_map", "ap_chg_meta", "ap_new_flag", "ap_link", "ap_children", "ap_sort_children", "ap_jump", "ap_weight",
+  "ap_parse", "ap_count", "ap_verify", "ap_map", "ap_chg_meta", "ap_new_flag", "ap_link", "ap_children", "ap_sort_children", "ap_succ_init", "ap_up_jump", "ap_succ_build", "ap_rank_jump", "ap_weight", "ap_top_k",
   "ap_top_place", "ap_emit", "ap_pred_cnt", "ap_succ_fill_u", "ap_succ_sort_u", "ap_succ_fill_d", "ap_ties"};
 // a merge / apply kernel, timed like the others when the context is profiling
 static void launch_mg_timed(amh_ctx* ctx, int k, const MergeDev* G, u32 n) {
@@ -1644,6 +1644,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
     A.ix_nops = upload(mb, ap->ix_nops, &ok); A.ix_row = upload(mb, ap->ix_row, &ok);
     u32** scr[] = {&A.gap, &A.anchor, &A.parent, &A.o_next, &A.o_head_upd, &A.o_head_ins, &A.o_top, &A.o_tmp, &A.o_stack};
     for (auto ps : scr) *ps = balloc<u32>(mb, NU, &ok);
+    A.o_up = balloc<u32>(mb, NU, &ok); A.o_rank = balloc<u64>(mb, NU, &ok);
     A.p_tgt = balloc<u32>(mb, (size_t)U.tot_succ + 2, &ok);
     if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
     rt_memset(A.p_tgt, 0xFF, ((size_t)U.tot_succ + 2) * 4, ctx->stream);
@@ -1687,13 +1688,20 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
     mg(MK_AP_LINK, nr);
     mg(MK_AP_CHILDREN, nr);
     mg(MK_AP_SORT_CHILDREN, nr);
-    for (int round = 0; round < 40; round++) {   // pointer jumping: distances halve per launch
-      u32 moved = 0;
-      rt_memset(G.A.flag, 0, 4, ctx->stream);
-      mg(MK_AP_JUMP, nr);
-      if (!rt_d2h(&moved, G.A.flag, 4, ctx->stream) || !rt_sync(ctx->stream)) return failm("D2H copy failed");
-      if (!moved) break;
-    }
+    auto jump_until_still = [&](int k) {   // pointer jumping: distances halve per launch
+      for (int round = 0; round < 40; round++) {
+        u32 moved = 0;
+        rt_memset(G.A.flag, 0, 4, ctx->stream);
+        mg(k, nr);
+        if (!rt_d2h(&moved, G.A.flag, 4, ctx->stream) || !rt_sync(ctx->stream)) return false;
+        if (!moved) break;
+      }
+      return true;
+    };
+    mg(MK_AP_SUCC_INIT, nr);
+    if (!jump_until_still(MK_AP_UP_JUMP)) return failm("D2H copy failed");
+    mg(MK_AP_SUCC_BUILD, nr);
+    if (!jump_until_still(MK_AP_RANK_JUMP)) return failm("D2H copy failed");
     mg(MK_AP_WEIGHT, nr);
     mg(MK_AP_TOP_PLACE, nr);
     mg(MK_AP_TIES, nr);
@@ -1703,7 +1711,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
     mg(MK_INHERIT, P);
   }
   if (!scan_inplace(mb, G.gap_cnt, gap_tot, nullptr)) return failm("scan failed");
-  if (ap) { mg(MK_AP_EMIT, G.U.tot_rows); pt.mark("exec: ap_emit", &ctx->stream); }
+  if (ap) { mg(MK_AP_TOP_K, G.U.tot_rows); mg(MK_AP_EMIT, G.U.tot_rows); pt.mark("exec: ap_emit", &ctx->stream); }
   if (ap) {   // succ lists of the new rows themselves (a later op of the same call overwrote / deleted them)
     BatchDev& S = G.S;
     mg(MK_AP_PRED_CNT, G.U.tot_rows);

@@ -28,7 +28,7 @@ u32 amh_level_sort_tmp_words(u32 tot_chg);
 enum MgKernel {
   MK_NEW_FLAG = 0, MK_PAIR_COUNTS, MK_SUBTREE, MK_GAP, MK_INHERIT, MK_EXTRA_CNT, MK_ROWS_DST, MK_ROWS_NEW, MK_SUCC_DST,
   MK_SUCC_NEW, MK_SUCC_EXTRA, MK_SUCC_SORT, MK_DOC_SUCC, MK_CHANGES, MK_COPY_CHUNKS,
-  MK_AP_PARSE, MK_AP_COUNT, MK_AP_VERIFY, MK_AP_MAP, MK_AP_CHG_META, MK_AP_NEW_FLAG, MK_AP_LINK, MK_AP_CHILDREN, MK_AP_SORT_CHILDREN, MK_AP_JUMP, MK_AP_WEIGHT, MK_AP_TOP_PLACE, MK_AP_EMIT, MK_AP_PRED_CNT,
+  MK_AP_PARSE, MK_AP_COUNT, MK_AP_VERIFY, MK_AP_MAP, MK_AP_CHG_META, MK_AP_NEW_FLAG, MK_AP_LINK, MK_AP_CHILDREN, MK_AP_SORT_CHILDREN, MK_AP_SUCC_INIT, MK_AP_UP_JUMP, MK_AP_SUCC_BUILD, MK_AP_RANK_JUMP, MK_AP_WEIGHT, MK_AP_TOP_K, MK_AP_TOP_PLACE, MK_AP_EMIT, MK_AP_PRED_CNT,
   MK_AP_SUCC_FILL_U, MK_AP_SUCC_SORT_U, MK_AP_SUCC_FILL_D, MK_AP_TIES, MK_NUM
 };
 void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream);

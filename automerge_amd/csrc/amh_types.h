@@ -247,9 +247,11 @@ struct ApplyDev {
   u32 *gap, *anchor, *parent;      // [U rows] dst-local gap (AMH_NULL32 = inside a new subtree), dst row it hangs off, parent row in U
   u32* p_tgt;                      // [U preds] bit 31 set: dst row (global), else row of U; AMH_NULL32 = none
   u32 *o_next, *o_head_upd, *o_head_ins;   // [U rows] sibling / same-gap list links, heads of a row's update and child-element lists
-  u32 *o_top, *o_tmp, *o_stack;            // [U rows] jump pointer (-> top row), weight of a top row, DFS stacks of k_ap_emit
+  u32 *o_top, *o_tmp, *o_stack;            // [U rows] rows in front of a top row within a long same-gap list, weight of a top row, scratch of the long-list sorts / place of a top row among the new rows
+  u32* o_up;                       // [U rows] elements: the row behind the element's subtree (AP_UP_*)
+  u64* o_rank;                     // [U rows] {a row in front of this one in its subtree's preorder, distance to it}; ranked: {top row, place behind it}
   u32* g_head;                     // [gap counters] top rows sharing a gap
-  u32* flag;                       // [1] a pointer moved in this k_ap_jump launch
+  u32* flag;                       // [1] a pointer moved in this k_ap_up_jump / k_ap_rank_jump launch
   u32* u_fill;                     // [U rows]
 };
 struct MergeDev {

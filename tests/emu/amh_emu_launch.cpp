@@ -47,7 +47,7 @@ void amh_launch_mg(int k, const MergeDev* G, u32 n, void*) {
     M(MK_INHERIT, k_mg_inherit) M(MK_EXTRA_CNT, k_mg_extra_cnt) M(MK_ROWS_DST, k_mg_rows_dst) M(MK_ROWS_NEW, k_mg_rows_new)
     M(MK_SUCC_DST, k_mg_succ_dst) M(MK_SUCC_NEW, k_mg_succ_new) M(MK_SUCC_EXTRA, k_mg_succ_extra) M(MK_SUCC_SORT, k_mg_succ_sort)
     M(MK_DOC_SUCC, k_mg_doc_succ) M(MK_CHANGES, k_mg_changes) M(MK_COPY_CHUNKS, k_mg_copy_chunks)
-    M(MK_AP_PARSE, k_ap_parse) M(MK_AP_COUNT, k_ap_count) M(MK_AP_VERIFY, k_ap_verify) M(MK_AP_MAP, k_ap_map) M(MK_AP_CHG_META, k_ap_chg_meta) M(MK_AP_NEW_FLAG, k_ap_new_flag) M(MK_AP_LINK, k_ap_link) M(MK_AP_CHILDREN, k_ap_children) M(MK_AP_SORT_CHILDREN, k_ap_sort_children) M(MK_AP_JUMP, k_ap_jump) M(MK_AP_WEIGHT, k_ap_weight) M(MK_AP_TOP_PLACE, k_ap_top_place) M(MK_AP_EMIT, k_ap_emit) M(MK_AP_PRED_CNT, k_ap_pred_cnt) M(MK_AP_SUCC_FILL_U, k_ap_succ_fill_u) M(MK_AP_SUCC_SORT_U, k_ap_succ_sort_u) M(MK_AP_SUCC_FILL_D, k_ap_succ_fill_d) M(MK_AP_TIES, k_ap_tie_find)
+    M(MK_AP_PARSE, k_ap_parse) M(MK_AP_COUNT, k_ap_count) M(MK_AP_VERIFY, k_ap_verify) M(MK_AP_MAP, k_ap_map) M(MK_AP_CHG_META, k_ap_chg_meta) M(MK_AP_NEW_FLAG, k_ap_new_flag) M(MK_AP_LINK, k_ap_link) M(MK_AP_CHILDREN, k_ap_children) M(MK_AP_SORT_CHILDREN, k_ap_sort_children) M(MK_AP_SUCC_INIT, k_ap_succ_init) M(MK_AP_UP_JUMP, k_ap_up_jump) M(MK_AP_SUCC_BUILD, k_ap_succ_build) M(MK_AP_RANK_JUMP, k_ap_rank_jump) M(MK_AP_WEIGHT, k_ap_weight) M(MK_AP_TOP_K, k_ap_top_k) M(MK_AP_TOP_PLACE, k_ap_top_place) M(MK_AP_EMIT, k_ap_emit) M(MK_AP_PRED_CNT, k_ap_pred_cnt) M(MK_AP_SUCC_FILL_U, k_ap_succ_fill_u) M(MK_AP_SUCC_SORT_U, k_ap_succ_sort_u) M(MK_AP_SUCC_FILL_D, k_ap_succ_fill_d) M(MK_AP_TIES, k_ap_tie_find)
     default: break;
   }
 #undef M
