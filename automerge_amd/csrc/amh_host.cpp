@@ -1323,6 +1323,62 @@ static T* upload(amh_batch* b, const std::vector<T>& v, bool* ok) {
   if (p && !v.empty() && !rt_h2d(p, v.data(), v.size() * sizeof(T), b->ctx->stream)) *ok = false;
   return p;
 }
+// Save of documents with hundreds of thousands of rows (g_sv_big, amh_segenc.inl): the job tables.  `B` is the caller's
+// copy of the batch descriptor (the sv_* fields are per call); the vectors stay alive until the caller has synchronised.
+// AMH_BIGSAVE_ROWS / AMH_BIGSAVE_RANGE: rows from which a document is "big" / rows per range (tests push every shape
+// of document through the ranges with 1 / 64).
+struct SaveBigHost {
+  std::vector<u32> j_bc, j_k, b_doc, b_col, b_first, b_nr;
+  std::vector<u8> big;
+  std::vector<DocCounts> cnt;
+};
+static bool save_big_prepare(amh_ctx* ctx, amh_batch* b, BatchDev& B, const std::vector<i32>& status, SaveBigHost& H) {
+  B.sv_nj = 0; B.sv_nbc = 0; B.sv_big = nullptr;
+#ifndef AMH_EMU
+  u64 thr = 262144, range = 16384;
+  if (const char* e = getenv("AMH_BIGSAVE_ROWS")) thr = strtoull(e, nullptr, 10);
+  if (const char* e = getenv("AMH_BIGSAVE_RANGE")) range = strtoull(e, nullptr, 10);
+  range = std::max<u64>(64, range & ~(u64)63);
+  if (thr == 0) thr = 1;
+  const u32 n = B.n_docs;
+  if (n == 0 || ((u64)B.tot_rows < thr && (u64)B.tot_succ < thr)) return true;
+  H.cnt.resize(n);
+  if (!rt_d2h(H.cnt.data(), B.cnt, (size_t)n * sizeof(DocCounts), ctx->stream)) return false;
+  H.big.assign(n, 0);
+  for (u32 d = 0; d < n; d++) {
+    if ((d < status.size() && status[d]) || ((u64)H.cnt[d].n_rows < thr && (u64)H.cnt[d].n_succ < thr)) continue;
+    H.big[d] = 1;
+    for (u32 col = 9; col < 25; col++) {
+      const u64 ncol = (col == 21 || col == 22) ? H.cnt[d].n_succ : H.cnt[d].n_rows;
+      const u64 nr = (ncol + range - 1) / range;
+      if (nr == 0) continue;
+      if (H.j_bc.size() + nr >= 0x7FFFFFFFull) return false;
+      H.b_doc.push_back(d); H.b_col.push_back(col); H.b_first.push_back((u32)H.j_bc.size()); H.b_nr.push_back((u32)nr);
+      for (u64 k = 0; k < nr; k++) { H.j_bc.push_back((u32)H.b_doc.size() - 1); H.j_k.push_back((u32)k); }
+    }
+  }
+  if (H.j_bc.empty()) return true;
+  bool ok = true;
+  const size_t nj = H.j_bc.size();
+  B.svj_bc = upload(b, H.j_bc, &ok); B.svj_k = upload(b, H.j_k, &ok);
+  B.svb_doc = upload(b, H.b_doc, &ok); B.svb_col = upload(b, H.b_col, &ok); B.svb_first = upload(b, H.b_first, &ok); B.svb_nr = upload(b, H.b_nr, &ok);
+  B.sv_big = upload(b, H.big, &ok);
+  B.svj_sum = balloc<u32>(b, 9 * nj + 1, &ok); B.svj_cin = balloc<u32>(b, 3 * nj + 1, &ok);
+  B.svj_total = balloc<u32>(b, nj + 1, &ok); B.svj_any = balloc<u32>(b, nj + 1, &ok); B.svj_tail = balloc<u32>(b, nj + 1, &ok);
+  if (!ok) { B.sv_nj = 0; B.sv_big = nullptr; return false; }
+  B.sv_nj = (u32)nj; B.sv_nbc = (u32)H.b_doc.size(); B.sv_range = (u32)range;
+#else
+  (void)ctx; (void)b; (void)status; (void)H;
+#endif
+  return true;
+}
+static void save_big_launch(amh_ctx* ctx, const BatchDev& B, int phase) {
+#ifndef AMH_EMU
+  amh_launch_save_big(B, phase, (void*)ctx->stream);
+#else
+  (void)ctx; (void)B; (void)phase;
+#endif
+}
 struct Hash32 {
   u8 b[32];
   bool operator==(const Hash32& o) const { return memcmp(b, o.b, 32) == 0; }
@@ -1787,8 +1843,11 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   M.sv_status = balloc<i32>(mb, P + 1, &ok); M.sv_col_len = balloc<u32>(mb, (size_t)P * 25 + 1, &ok); M.sv_wide = balloc<u32>(mb, P + 1, &ok);
   M.sv_body_len = balloc<u32>(mb, P + 1, &ok); M.sv_off = balloc<u32>(mb, P + 2, &ok);
   if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+  SaveBigHost sbh;
+  if (!save_big_prepare(ctx, mb, M, std::vector<i32>(), sbh)) return failm("save: job tables failed");
   launch(ctx, AK_SAVE_CHECK, M, P);
   launch(ctx, AK_SAVE_SIZE, M, P * 25);
+  save_big_launch(ctx, M, 0);
   launch(ctx, AK_SAVE_LAYOUT, M, P);
   u32 sv_total = 0;
   if (!scan_inplace(mb, M.sv_off, P, &sv_total)) return failm("scan failed");
@@ -1796,6 +1855,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   M.sv_out = balloc<u8>(mb, (size_t)sv_total + 256, &ok);
   if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
   launch(ctx, AK_SAVE_STORE, M, P * 25);
+  save_big_launch(ctx, M, 1);
   M.skip_doc_sha = 1;   // these chunks only feed the reload below (a later save re-encodes from the rows)
   launch(ctx, AK_SAVE_FINISH, M, P);
   pt.mark("exec: save kernels", &ctx->stream);
@@ -2990,8 +3050,11 @@ extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch* bc, const amh_save_
 #ifndef AMH_EMU
   B.sha_host_min = AMH_HOST_SHA_MIN;   // chunks of that size and more: checksum by the host below, which receives the bytes anyway
 #endif
+  SaveBigHost sbh;
+  if (!save_big_prepare(ctx, b, B, b->status, sbh)) { set_error(ctx, "save: job tables failed (device out of memory?)"); return AMH_ERR_DEVICE; }
   launch(ctx, AK_SAVE_CHECK, B, n);
   launch(ctx, AK_SAVE_SIZE, B, n * 25);
+  save_big_launch(ctx, B, 0);
   launch(ctx, AK_SAVE_LAYOUT, B, n);
   u32 total = 0;
   if (!scan_inplace(b, B.sv_off, n, &total)) { set_error(ctx, "scan failed"); return AMH_ERR_DEVICE; }
@@ -2999,6 +3062,7 @@ extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch* bc, const amh_save_
   B.sv_out = balloc<u8>(b, (size_t)total + 256, &ok);
   if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
   launch(ctx, AK_SAVE_STORE, B, n * 25);
+  save_big_launch(ctx, B, 1);
   launch(ctx, AK_SAVE_FINISH, B, n);
   std::vector<u8> host((size_t)total);
   std::vector<u32> off(n + 1), body(n);

@@ -64,6 +64,39 @@ __device__ __forceinline__ ScRoles sc_roles(u64 EQP, u64 NUL, u32 cnt, u32 base,
   r.k_p = n.litlen0;
   return r;
 }
+// the carry update of sc_roles alone
+__device__ __forceinline__ void sc_carry_step(u64 EQP, u64 NUL, u32 cnt, ScCarry& c) {
+  const u64 VALID = sd_low_bits(cnt), top = (u64)1 << (cnt - 1);
+  const u64 START = ~EQP & VALID;
+  const u64 END = ((START >> 1) | (c.start0 ? top : 0)) & VALID;
+  const u64 LONE = START & END & ~NUL;
+  ScCarry n;
+  n.start0 = START & 1;
+  n.lone0 = LONE & 1;
+  n.runlen0 = END ? (u32)__builtin_ctzll(END) + 1 : cnt + c.runlen0;
+  { const u32 z = sc_ctz64(~LONE); n.litlen0 = (LONE & 1) ? (z >= cnt ? cnt + (c.lone0 ? c.litlen0 : 0) : z) : 0; }
+  c = n;
+}
+// A column over many waves (documents of hundreds of thousands of rows: g_sv_big).  The column is cut into ranges of
+// rows, a wave each.  All a range needs of the rows behind it is the carry, and what a range does to the carry depends
+// on the carry it receives only in three ways: which of the three possible (start0, lone0) pairs it is, and the two
+// lengths, which are added where a run or a literal stretch reaches the range's end.  So every range first walks its
+// rows once for all three cases with a marker in the lengths (ScSummary), one thread per column then chains the
+// ranges from the last to the first, and the size and store walks run with the true carries.
+#define SC_MARK 0x80000000u   // lengths stay below it (rows and succ entries of a document < 2^31)
+struct ScSummary { ScCarry h[3]; };   // received (start0, lone0) = (1, 1), (1, 0), (0, 0)
+__device__ __forceinline__ void sc_summary_init(ScSummary& s) {
+  s.h[0].start0 = true;  s.h[0].lone0 = true;  s.h[0].runlen0 = 0;       s.h[0].litlen0 = SC_MARK;
+  s.h[1].start0 = true;  s.h[1].lone0 = false; s.h[1].runlen0 = 0;       s.h[1].litlen0 = 0;
+  s.h[2].start0 = false; s.h[2].lone0 = false; s.h[2].runlen0 = SC_MARK; s.h[2].litlen0 = 0;
+}
+__device__ __forceinline__ ScCarry sc_summary_apply(const ScSummary& s, const ScCarry& in) {
+  ScCarry o = s.h[in.start0 ? (in.lone0 ? 0 : 1) : 2];
+  if (o.runlen0 >= SC_MARK) o.runlen0 = o.runlen0 - SC_MARK + in.runlen0;
+  if (o.litlen0 >= SC_MARK) o.litlen0 = o.litlen0 - SC_MARK + in.litlen0;
+  return o;
+}
+struct ScRange { u32 lo, hi; ScCarry carry; u32 total0; };   // rows [lo, hi) (lo a multiple of 64; hi too, or the column's end), the carry from behind, bytes behind the range
 __device__ __forceinline__ ScCarry sc_carry_init() { ScCarry c; c.start0 = true; c.lone0 = false; c.runlen0 = 0; c.litlen0 = 0; return c; }
 
 // lane i receives lane i - 1's 64-bit value
@@ -73,22 +106,36 @@ __device__ __forceinline__ u64 sd_prev64(u64 v) { return (u64)sd_prev((u32)v) | 
 // Src: void load(u32 e, u64& v, bool& isnull) const — value e of the column (any lane may ask for any e < n).
 // SIGNED: values are written as sleb128 (deltas), else uleb128.  STORE: out = first byte of the column, col_len = its
 // length (from the size pass).  Returns the column length.
+template <class Src>
+__device__ __forceinline__ void sc_num_tile(const Src& src, u32 base, u32 cnt, u32 lane, u64& v, bool& nul, u64& EQP, u64& NUL) {
+  const u32 e = base + lane;
+  const bool valid = lane < cnt;
+  v = 0; nul = true;
+  if (valid) src.load(e, v, nul);
+  u64 pv = sd_prev64(v); bool pn = sd_prev((u32)nul) != 0;
+  if (lane == 0 && base > 0) src.load(base - 1, pv, pn);
+  const bool eqp = valid && e > 0 && pn == nul && (nul || pv == v);
+  EQP = __ballot(eqp); NUL = __ballot(nul && valid);
+}
+template <class Src>
+__device__ __forceinline__ void sc_rle_summary(const Src& src, u32 lo, u32 hi, u32 lane, ScSummary& S, bool& any) {
+  for (u32 base = (hi - 1) & ~63u;; base -= 64) {
+    const u32 cnt = hi - base < 64 ? hi - base : 64;
+    u64 v, EQP, NUL; bool nul;
+    sc_num_tile(src, base, cnt, lane, v, nul, EQP, NUL);
+    any = any || (~NUL & sd_low_bits(cnt)) != 0;
+    sc_carry_step(EQP, NUL, cnt, S.h[0]); sc_carry_step(EQP, NUL, cnt, S.h[1]); sc_carry_step(EQP, NUL, cnt, S.h[2]);
+    if (base == lo) break;
+  }
+}
 template <bool SIGNED, bool STORE, class Src>
-__device__ __forceinline__ u32 sc_rle_column(const Src& src, u32 n, u8* out, u32 col_len, u32 lane) {
-  if (n == 0 || (STORE && col_len == 0)) return 0;
-  ScCarry carry = sc_carry_init();
-  u32 total = 0;
-  bool any = false;
-  for (u32 base = (n - 1) & ~63u;; base -= 64) {
-    const u32 cnt = n - base < 64 ? n - base : 64;
-    const u32 e = base + lane;
-    const bool valid = lane < cnt;
-    u64 v = 0; bool nul = true;
-    if (valid) src.load(e, v, nul);
-    u64 pv = sd_prev64(v); bool pn = sd_prev((u32)nul) != 0;
-    if (lane == 0 && base > 0) src.load(base - 1, pv, pn);
-    const bool eqp = valid && e > 0 && pn == nul && (nul || pv == v);
-    const u64 EQP = __ballot(eqp), NUL = __ballot(nul && valid);
+__device__ __forceinline__ u32 sc_rle_range(const Src& src, const ScRange& rg, u8* out, u32 col_len, u32 lane, bool& any) {
+  ScCarry carry = rg.carry;
+  u32 total = rg.total0;
+  for (u32 base = (rg.hi - 1) & ~63u;; base -= 64) {
+    const u32 cnt = rg.hi - base < 64 ? rg.hi - base : 64;
+    u64 v, EQP, NUL; bool nul;
+    sc_num_tile(src, base, cnt, lane, v, nul, EQP, NUL);
     any = any || (~NUL & sd_low_bits(cnt)) != 0;
     const ScRoles r = sc_roles(EQP, NUL, cnt, base, lane, carry);
     // the numbers this lane writes, in order: P (literal header at the start of the column), H (run header), V (value
@@ -108,29 +155,50 @@ __device__ __forceinline__ u32 sc_rle_column(const Src& src, u32 n, u8* out, u32
       if (hasV) o += nul ? wr_uleb(o, r.rl) : (SIGNED ? wr_sleb(o, (i64)v) : wr_uleb(o, v));
       if (hasL) wr_sleb(o, nL);
     }
-    if (base == 0) break;
+    if (base == rg.lo) break;
   }
+  return total;
+}
+template <bool SIGNED, bool STORE, class Src>
+__device__ __forceinline__ u32 sc_rle_column(const Src& src, u32 n, u8* out, u32 col_len, u32 lane) {
+  if (n == 0 || (STORE && col_len == 0)) return 0;
+  ScRange rg; rg.lo = 0; rg.hi = n; rg.carry = sc_carry_init(); rg.total0 = 0;
+  bool any = false;
+  const u32 total = sc_rle_range<SIGNED, STORE>(src, rg, out, col_len, lane, any);
   return any ? total : 0;   // a column of nulls is not written at all (rle.rs:33)
 }
 
 // ---- boolean columns (boolean.rs:35-50): alternating run lengths, the first one counts `false` ----------------------
 // Src: bool load(u32 e) const.  MAYBE: nothing unless some value is true (MaybeBooleanEncoder, boolean.rs:131-137).
-template <bool MAYBE, bool STORE, class Src>
-__device__ __forceinline__ u32 sc_bool_column(const Src& src, u32 n, u8* out, u32 col_len, u32 lane) {
-  if (n == 0 || (STORE && col_len == 0)) return 0;
-  ScCarry carry = sc_carry_init();
-  u32 total = 0;
-  bool any_true = false;
-  for (u32 base = (n - 1) & ~63u;; base -= 64) {
-    const u32 cnt = n - base < 64 ? n - base : 64;
-    const u32 e = base + lane;
-    const bool valid = lane < cnt;
-    bool v = valid ? src.load(e) : false;
-    bool pv = sd_prev((u32)v) != 0;
-    if (lane == 0 && base > 0) pv = src.load(base - 1);
-    const bool eqp = valid && e > 0 && pv == v;
-    const u64 EQP = __ballot(eqp);
-    any_true = any_true || __ballot(v && valid) != 0;
+template <class Src>
+__device__ __forceinline__ void sc_bool_tile(const Src& src, u32 base, u32 cnt, u32 lane, bool& v, u64& EQP, bool& any_true) {
+  const u32 e = base + lane;
+  const bool valid = lane < cnt;
+  v = valid ? src.load(e) : false;
+  bool pv = sd_prev((u32)v) != 0;
+  if (lane == 0 && base > 0) pv = src.load(base - 1);
+  const bool eqp = valid && e > 0 && pv == v;
+  EQP = __ballot(eqp);
+  any_true = any_true || __ballot(v && valid) != 0;
+}
+template <class Src>
+__device__ __forceinline__ void sc_bool_summary(const Src& src, u32 lo, u32 hi, u32 lane, ScSummary& S, bool& any_true) {
+  for (u32 base = (hi - 1) & ~63u;; base -= 64) {
+    const u32 cnt = hi - base < 64 ? hi - base : 64;
+    bool v; u64 EQP;
+    sc_bool_tile(src, base, cnt, lane, v, EQP, any_true);
+    sc_carry_step(EQP, 0, cnt, S.h[0]); sc_carry_step(EQP, 0, cnt, S.h[1]); sc_carry_step(EQP, 0, cnt, S.h[2]);
+    if (base == lo) break;
+  }
+}
+template <bool STORE, class Src>
+__device__ __forceinline__ u32 sc_bool_range(const Src& src, const ScRange& rg, u8* out, u32 col_len, u32 lane, bool& any_true) {
+  ScCarry carry = rg.carry;
+  u32 total = rg.total0;
+  for (u32 base = (rg.hi - 1) & ~63u;; base -= 64) {
+    const u32 cnt = rg.hi - base < 64 ? rg.hi - base : 64;
+    bool v; u64 EQP;
+    sc_bool_tile(src, base, cnt, lane, v, EQP, any_true);
     const ScRoles r = sc_roles(EQP, 0, cnt, base, lane, carry);
     // a column that starts with `true` starts with an empty run of `false`
     const bool hasZ = base == 0 && lane == 0 && v;
@@ -143,8 +211,16 @@ __device__ __forceinline__ u32 sc_bool_column(const Src& src, u32 n, u8* out, u3
       if (hasZ) *o++ = 0;
       if (r.is_start) wr_uleb(o, r.rl);
     }
-    if (base == 0) break;
+    if (base == rg.lo) break;
   }
+  return total;
+}
+template <bool MAYBE, bool STORE, class Src>
+__device__ __forceinline__ u32 sc_bool_column(const Src& src, u32 n, u8* out, u32 col_len, u32 lane) {
+  if (n == 0 || (STORE && col_len == 0)) return 0;
+  ScRange rg; rg.lo = 0; rg.hi = n; rg.carry = sc_carry_init(); rg.total0 = 0;
+  bool any_true = false;
+  const u32 total = sc_bool_range<STORE>(src, rg, out, col_len, lane, any_true);
   return (MAYBE && !any_true) ? 0 : total;
 }
 
@@ -170,22 +246,36 @@ __device__ __forceinline__ bool sc_str_eq(const ScStr& a, const ScStr& b) {
   return true;
 }
 // Src: ScStr load(u32 e) const
+template <class Src>
+__device__ __forceinline__ void sc_str_tile(const Src& src, u32 base, u32 cnt, u32 lane, ScStr& v, u64& EQP, u64& NUL) {
+  const u32 e = base + lane;
+  const bool valid = lane < cnt;
+  v.bytes = 0; v.p = 0; v.len = 0; v.inl = true; v.isnull = true;
+  if (valid) v = src.load(e);
+  ScStr pv; pv.isnull = true; pv.bytes = 0; pv.p = 0; pv.len = 0; pv.inl = true;
+  if (valid && e > 0) pv = src.load(e - 1);   // (a second load of the neighbour: the values are in L1 / L2)
+  const bool eqp = valid && e > 0 && sc_str_eq(v, pv);
+  EQP = __ballot(eqp); NUL = __ballot(v.isnull && valid);
+}
+template <class Src>
+__device__ __forceinline__ void sc_str_summary(const Src& src, u32 lo, u32 hi, u32 lane, ScSummary& S, bool& any) {
+  for (u32 base = (hi - 1) & ~63u;; base -= 64) {
+    const u32 cnt = hi - base < 64 ? hi - base : 64;
+    ScStr v; u64 EQP, NUL;
+    sc_str_tile(src, base, cnt, lane, v, EQP, NUL);
+    any = any || (~NUL & sd_low_bits(cnt)) != 0;
+    sc_carry_step(EQP, NUL, cnt, S.h[0]); sc_carry_step(EQP, NUL, cnt, S.h[1]); sc_carry_step(EQP, NUL, cnt, S.h[2]);
+    if (base == lo) break;
+  }
+}
 template <bool STORE, class Src>
-__device__ __forceinline__ u32 sc_str_column(const Src& src, u32 n, u8* out, u32 col_len, u32 lane) {
-  if (n == 0 || (STORE && col_len == 0)) return 0;
-  ScCarry carry = sc_carry_init();
-  u32 total = 0;
-  bool any = false;
-  for (u32 base = (n - 1) & ~63u;; base -= 64) {
-    const u32 cnt = n - base < 64 ? n - base : 64;
-    const u32 e = base + lane;
-    const bool valid = lane < cnt;
-    ScStr v; v.bytes = 0; v.p = 0; v.len = 0; v.inl = true; v.isnull = true;
-    if (valid) v = src.load(e);
-    ScStr pv; pv.isnull = true; pv.bytes = 0; pv.p = 0; pv.len = 0; pv.inl = true;
-    if (valid && e > 0) pv = src.load(e - 1);   // (a second load of the neighbour: the values are in L1 / L2)
-    const bool eqp = valid && e > 0 && sc_str_eq(v, pv);
-    const u64 EQP = __ballot(eqp), NUL = __ballot(v.isnull && valid);
+__device__ __forceinline__ u32 sc_str_range(const Src& src, const ScRange& rg, u8* out, u32 col_len, u32 lane, bool& any) {
+  ScCarry carry = rg.carry;
+  u32 total = rg.total0;
+  for (u32 base = (rg.hi - 1) & ~63u;; base -= 64) {
+    const u32 cnt = rg.hi - base < 64 ? rg.hi - base : 64;
+    ScStr v; u64 EQP, NUL;
+    sc_str_tile(src, base, cnt, lane, v, EQP, NUL);
     any = any || (~NUL & sd_low_bits(cnt)) != 0;
     const ScRoles r = sc_roles(EQP, NUL, cnt, base, lane, carry);
     const bool nul = v.isnull;
@@ -211,8 +301,16 @@ __device__ __forceinline__ u32 sc_str_column(const Src& src, u32 n, u8* out, u32
       }
       if (hasL) wr_sleb(o, nL);
     }
-    if (base == 0) break;
+    if (base == rg.lo) break;
   }
+  return total;
+}
+template <bool STORE, class Src>
+__device__ __forceinline__ u32 sc_str_column(const Src& src, u32 n, u8* out, u32 col_len, u32 lane) {
+  if (n == 0 || (STORE && col_len == 0)) return 0;
+  ScRange rg; rg.lo = 0; rg.hi = n; rg.carry = sc_carry_init(); rg.total0 = 0;
+  bool any = false;
+  const u32 total = sc_str_range<STORE>(src, rg, out, col_len, lane, any);
   return any ? total : 0;
 }
 
@@ -220,11 +318,10 @@ __device__ __forceinline__ u32 sc_str_column(const Src& src, u32 n, u8* out, u32
 // kind 0 nothing, 1 bytes at p, 2 an integer written as sleb128, 3 up to 8 bytes in a register
 struct ScRaw { u32 kind, len; u64 x; const u8* p; };
 template <bool STORE, class Src>
-__device__ __forceinline__ u32 sc_raw_column(const Src& src, u32 n, u8* out, u32 col_len, u32 lane) {
-  if (n == 0 || (STORE && col_len == 0)) return 0;
-  u32 total = 0;
-  for (u32 base = (n - 1) & ~63u;; base -= 64) {
-    const u32 cnt = n - base < 64 ? n - base : 64;
+__device__ __forceinline__ u32 sc_raw_range(const Src& src, const ScRange& rg, u8* out, u32 col_len, u32 lane) {
+  u32 total = rg.total0;
+  for (u32 base = (rg.hi - 1) & ~63u;; base -= 64) {
+    const u32 cnt = rg.hi - base < 64 ? rg.hi - base : 64;
     ScRaw v; v.kind = 0; v.len = 0; v.x = 0; v.p = 0;
     if (lane < cnt) v = src.load(base + lane);
     const u32 len = v.kind == 0 ? 0 : (v.kind == 2 ? sleb_size_fast((i64)v.x) : v.len);
@@ -236,9 +333,15 @@ __device__ __forceinline__ u32 sc_raw_column(const Src& src, u32 n, u8* out, u32
       else if (v.kind == 3) for (u32 i = 0; i < len; i++) o[i] = (u8)(v.x >> (8 * i));
       else for (u32 i = 0; i < len; i++) o[i] = v.p[i];
     }
-    if (base == 0) break;
+    if (base == rg.lo) break;
   }
   return total;
+}
+template <bool STORE, class Src>
+__device__ __forceinline__ u32 sc_raw_column(const Src& src, u32 n, u8* out, u32 col_len, u32 lane) {
+  if (n == 0 || (STORE && col_len == 0)) return 0;
+  ScRange rg; rg.lo = 0; rg.hi = n; rg.carry = sc_carry_init(); rg.total0 = 0;
+  return sc_raw_range<STORE>(src, rg, out, col_len, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -509,7 +612,8 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_save_seg(BatchDev B) {
   const u32 d = blockIdx.x * SD_WAVES + wave;
   if (d >= B.n_docs) return;
   const u32 lane = threadIdx.x & 63;
-  const bool live = B.status[d] == 0 && B.sv_status[d] == 0;
+  const bool big = B.sv_big && B.sv_big[d];   // its op columns are cut into ranges (g_sv_big); lengths 0 here, set by g_sv_big_total
+  const bool live = B.status[d] == 0 && B.sv_status[d] == 0 && !big;
   u32* cl = B.sv_col_len + (u64)d * AMH_SV_NCOLS;
   if (STORE && !live) return;
   const u32 n = live ? B.cnt[d].n_rows : 0, ns = live ? B.cnt[d].n_succ : 0;
@@ -568,5 +672,130 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_save_seg(BatchDev B) {
       lm = sc_str_column<STORE>(sm, n, out(24), clen[24], lane);
     }
     put(24, lm);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Document save, a column over many waves (see ScSummary): one wave per job = (big column, range of rows).
+// MODE 0: what the range does to the carry -> svj_sum.  g_sv_big_chain: the carry every range receives -> svj_cin.
+// MODE 1: bytes of the range -> svj_total.  g_sv_big_total: column lengths -> sv_col_len, bytes behind every range
+// -> svj_tail.  MODE 2 (after k_save_layout): the bytes.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sv_carry_pack(const ScCarry& c, u32* w) { w[0] = (c.start0 ? 1u : 0u) | (c.lone0 ? 2u : 0u); w[1] = c.runlen0; w[2] = c.litlen0; }
+__device__ __forceinline__ ScCarry sv_carry_unpack(const u32* w) { ScCarry c; c.start0 = (w[0] & 1) != 0; c.lone0 = (w[0] & 2) != 0; c.runlen0 = w[1]; c.litlen0 = w[2]; return c; }
+template <int MODE>
+__global__ void __launch_bounds__(64 * SD_WAVES) g_sv_big(BatchDev B) {
+  const u32 wave = sd_uniform(threadIdx.x >> 6);
+  const u32 j = blockIdx.x * SD_WAVES + wave;
+  if (j >= B.sv_nj) return;
+  const u32 lane = threadIdx.x & 63;
+  const u32 bc = B.svj_bc[j], k = B.svj_k[j];
+  const u32 d = B.svb_doc[bc], col = B.svb_col[bc];
+  const bool live = B.status[d] == 0 && B.sv_status[d] == 0;
+  const u32 n = live ? B.cnt[d].n_rows : 0, ns = live ? B.cnt[d].n_succ : 0;
+  u32 ncol = (col == 21 || col == 22) ? ns : n;
+  if (col == 24 && B.desc[d].ocol[OC_MARK_NAME].len == 0) ncol = 0;   // only documents with a mark column
+  ScSummary S;
+  sc_summary_init(S);
+  bool any = false;
+  u32 total = 0;
+  ScRange rg;
+  rg.lo = k * B.sv_range;
+  rg.hi = ncol - rg.lo < B.sv_range ? ncol : rg.lo + B.sv_range;
+  const bool work = rg.lo < ncol;
+  u8* out = (u8*)0;
+  u32 col_len = 0;
+  if (MODE != 0) { rg.carry = sv_carry_unpack(B.svj_cin + 3 * (u64)j); rg.total0 = 0; }
+  if (MODE == 2) {
+    if (!work) return;
+    const u32* cl = B.sv_col_len + (u64)d * AMH_SV_NCOLS;
+    col_len = cl[col];
+    if (col_len == 0) return;
+    u64 o = (u64)B.sv_off[d] + sv_data_start(B, d);
+    for (u32 q = 0; q < col; q++) o += cl[q];
+    out = B.sv_out + o;
+    rg.total0 = B.svj_tail[j];
+  }
+  if (work) {
+    SvCtx c{B, B.row_base[d], B.actor_base[d], B.arena + B.desc[d].chunk_off};
+#define SV_NUM(SIGNED, src) { if constexpr (MODE == 0) sc_rle_summary(src, rg.lo, rg.hi, lane, S, any); \
+      else if constexpr (MODE == 1) total = sc_rle_range<SIGNED, false>(src, rg, (u8*)0, 0, lane, any); \
+      else sc_rle_range<SIGNED, true>(src, rg, out, col_len, lane, any); }
+#define SV_BOOL(src) { if constexpr (MODE == 0) sc_bool_summary(src, rg.lo, rg.hi, lane, S, any); \
+      else if constexpr (MODE == 1) total = sc_bool_range<false>(src, rg, (u8*)0, 0, lane, any); \
+      else sc_bool_range<true>(src, rg, out, col_len, lane, any); }
+#define SV_STR(src) { if constexpr (MODE == 0) sc_str_summary(src, rg.lo, rg.hi, lane, S, any); \
+      else if constexpr (MODE == 1) total = sc_str_range<false>(src, rg, (u8*)0, 0, lane, any); \
+      else sc_str_range<true>(src, rg, out, col_len, lane, any); }
+    switch (col) {
+      case 9:  { SvObjSrc s{c, false}; SV_NUM(false, s) } break;
+      case 10: { SvObjSrc s{c, true}; SV_NUM(false, s) } break;
+      case 11: { SvKeyActorSrc s{c}; SV_NUM(false, s) } break;
+      case 12: { SvKeyCtrSrc s{c}; SV_NUM(true, s) } break;
+      case 13: { SvKeyStrSrc s{c}; SV_STR(s) } break;
+      case 14: { SvIdActorSrc s{c}; SV_NUM(false, s) } break;
+      case 15: { SvIdCtrSrc s{c}; SV_NUM(true, s) } break;
+      case 16: { SvInsertSrc s{c}; SV_BOOL(s) } break;
+      case 17: { SvActionSrc s{c}; SV_NUM(false, s) } break;
+      case 18: { SvValMetaSrc s{c}; SV_NUM(false, s) } break;
+      case 19: { SvValRawSrc s{c};
+                 if constexpr (MODE == 1) total = sc_raw_range<false>(s, rg, (u8*)0, 0, lane);
+                 else if constexpr (MODE == 2) sc_raw_range<true>(s, rg, out, col_len, lane); } break;
+      case 20: { SvSuccNumSrc s{c}; SV_NUM(false, s) } break;
+      case 21: { SvSuccActorSrc s{c, B.succ_base[d]}; SV_NUM(false, s) } break;
+      case 22: { SvSuccCtrSrc s{c, B.succ_base[d]}; SV_NUM(true, s) } break;
+      case 23: { SvExpandSrc s{c}; SV_BOOL(s) } break;
+      default: { SvMarkSrc s{c}; SV_STR(s) } break;
+    }
+#undef SV_NUM
+#undef SV_BOOL
+#undef SV_STR
+  }
+  if (lane == 0) {
+    if (MODE == 0) { u32* w = B.svj_sum + 9 * (u64)j; sv_carry_pack(S.h[0], w); sv_carry_pack(S.h[1], w + 3); sv_carry_pack(S.h[2], w + 6); }
+    if (MODE == 1) { B.svj_total[j] = total; B.svj_any[j] = any ? 1u : 0u; }
+  }
+}
+// thread per big column: the ranges from the last to the first
+__global__ void __launch_bounds__(AMH_BLOCK) g_sv_big_chain(BatchDev B) {
+  const u32 bc = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  if (bc >= B.sv_nbc) return;
+  const u32 first = B.svb_first[bc], nr = B.svb_nr[bc];
+  ScCarry cur = sc_carry_init();
+  for (u32 k = nr; k-- > 0;) {
+    const u64 j = (u64)first + k;
+    sv_carry_pack(cur, B.svj_cin + 3 * j);
+    ScSummary S;
+    const u32* w = B.svj_sum + 9 * j;
+    S.h[0] = sv_carry_unpack(w); S.h[1] = sv_carry_unpack(w + 3); S.h[2] = sv_carry_unpack(w + 6);
+    cur = sc_summary_apply(S, cur);
+  }
+}
+__global__ void __launch_bounds__(AMH_BLOCK) g_sv_big_total(BatchDev B) {
+  const u32 bc = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  if (bc >= B.sv_nbc) return;
+  const u32 first = B.svb_first[bc], nr = B.svb_nr[bc], d = B.svb_doc[bc], col = B.svb_col[bc];
+  u32 run = 0, any = 0;
+  for (u32 k = nr; k-- > 0;) {
+    const u64 j = (u64)first + k;
+    B.svj_tail[j] = run;
+    run += B.svj_total[j];
+    any |= B.svj_any[j];
+  }
+  // a column of nothing but nulls (rle.rs:33) / a MaybeBoolean column without a true (boolean.rs:131-137) is not written
+  const bool always = col == 16 || col == 19;
+  B.sv_col_len[(u64)d * AMH_SV_NCOLS + col] = (always || any) ? run : 0;
+}
+void amh_launch_save_big(const BatchDev& B, int phase, void* stream) {
+  if (B.sv_nj == 0) return;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 gj((B.sv_nj + SD_WAVES - 1) / SD_WAVES), bj(64 * SD_WAVES), gc((B.sv_nbc + AMH_BLOCK - 1) / AMH_BLOCK), bcb(AMH_BLOCK);
+  if (phase == 0) {
+    hipLaunchKernelGGL((g_sv_big<0>), gj, bj, 0, s, B);
+    hipLaunchKernelGGL(g_sv_big_chain, gc, bcb, 0, s, B);
+    hipLaunchKernelGGL((g_sv_big<1>), gj, bj, 0, s, B);
+    hipLaunchKernelGGL(g_sv_big_total, gc, bcb, 0, s, B);
+  } else {
+    hipLaunchKernelGGL((g_sv_big<2>), gj, bj, 0, s, B);
   }
 }

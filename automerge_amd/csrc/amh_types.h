@@ -180,6 +180,14 @@ struct BatchDev {
   u32* sv_body_len;              // [n_docs]
   u32* sv_off;                   // [n_docs + 1] chunk offsets in sv_out
   u8* sv_out;
+  // save of documents with hundreds of thousands of rows: their op columns are cut into ranges of sv_range rows, a wave
+  // each (g_sv_big).  A "big column" is one op column (9..24) of one such document; a job is one range of it.
+  u32 sv_nj, sv_nbc, sv_range;
+  const u32 *svj_bc, *svj_k;                            // [sv_nj] big column of the job, its range index
+  const u32 *svb_doc, *svb_col, *svb_first, *svb_nr;    // [sv_nbc] document, column, first job, ranges
+  u32 *svj_sum, *svj_cin;                               // [9 * sv_nj] what the range does to the carry (ScSummary); [3 * sv_nj] the carry it receives
+  u32 *svj_total, *svj_any, *svj_tail;                  // [sv_nj] bytes of the range, a non-null (true) value seen, bytes of the ranges behind it
+  const u8* sv_big;                                     // [n_docs] 1 = the op columns are encoded by g_sv_big
   u32* sync_off;                 // [n_docs + 1] record offsets of the sync summaries
   u8* sync_out;
   u32 sync_cap;                  // 0 = sync_out holds every record; else its capacity: records that end beyond it are not written

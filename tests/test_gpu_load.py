@@ -200,13 +200,19 @@ def test_sync_summaries_through_the_library_collective(golden_dir):
     b.close(); empty.close(); eng.close()
 
 
-@pytest.mark.parametrize("form", ["auto", "seg", "lane"])
+@pytest.mark.parametrize("form", ["auto", "seg", "lane", "ranges", "ranges-lane"])
 def test_save(engine, golden_dir, monkeypatch, form):
-    """(both forms of the save kernels: wave per (document, column group) / lane per document)
+    """(the forms of the save kernels: wave per (document, column group) / lane per document / every op column cut
+    into ranges of 64 rows, a wave each, as documents of hundreds of thousands of rows are saved)
     save_nocompress(load(x)) is byte-identical to the oracle's; save() = same chunk with columns >= 256 bytes
     DEFLATEd (compressed bytes are zlib's: parity unpinned, so compare after loading them back)"""
     import oracle_lib as o
-    if form != "auto":
+    if form.startswith("ranges"):
+        monkeypatch.setenv("AMH_BIGSAVE_ROWS", "1")
+        monkeypatch.setenv("AMH_BIGSAVE_RANGE", "64")
+        if form == "ranges-lane":
+            monkeypatch.setenv("AMH_SAVE_FORM", "lane")
+    elif form != "auto":
         monkeypatch.setenv("AMH_SAVE_FORM", form)
     docs = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(golden_dir, "docs", "*.automerge")))]
     blob, offs = engine.gen_map_docs(31, 5, 4, 5, 50, 64, 2)
