@@ -320,6 +320,30 @@ class Batch:
             raise EngineError(f"amh_apply_batch failed: {rc} {self.engine._err()}")
         return list(res)
 
+    def apply_arena(self, doc_idx, blob, offsets, incremental=False):
+        """apply_batch with the buffers lying back to back in `blob` (bytes): buffer i = blob[offsets[i]:offsets[i + 1]]
+        goes to document doc_idx[i].  The pointer table is built with numpy instead of one Python object per buffer
+        (a receive arena, as a sync server holds the messages of a round)."""
+        import numpy as np
+        idx = np.ascontiguousarray(doc_idx, dtype=np.uint32)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = int(idx.shape[0])
+        if n == 0:
+            return []
+        if offs.shape[0] != n + 1 or int(offs[-1]) > len(blob):
+            raise ValueError("offsets must have len(doc_idx) + 1 entries inside blob")
+        keep = C.c_char_p(blob)
+        base = C.cast(keep, C.c_void_p).value or 0
+        ptrs = (offs[:n] + np.uint64(base)).astype(np.uint64)
+        lens = (offs[1:] - offs[:n]).astype(np.uint64)
+        res = np.zeros(n, dtype=np.int32)
+        rc = self.engine.lib.amh_apply_batch(self.engine.ctx, self.h, C.cast(idx.ctypes.data, C.POINTER(C.c_uint32)),
+                                             C.cast(ptrs.ctypes.data, C.POINTER(C.c_char_p)), C.cast(lens.ctypes.data, C.POINTER(C.c_size_t)),
+                                             n, 1 if incremental else 0, C.cast(res.ctypes.data, C.POINTER(C.c_int)))
+        if rc not in (0, -7):
+            raise EngineError(f"amh_apply_batch failed: {rc} {self.engine._err()}")
+        return res.tolist()
+
     def save_after(self, i, heads):
         """== self[i].save_after(heads) (automerge.rs:993): the changes `heads` has not seen, as change chunks."""
         self.check(i)

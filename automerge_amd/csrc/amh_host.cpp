@@ -2305,26 +2305,39 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   struct StageView { u8* p = nullptr; size_t n = 0; u8* data() const { return p; } size_t size() const { return n; } } h_arena;
   ap.s_desc.resize(P); ap.s_cnt.resize(P); ap.s_row_base.assign(P + 1, 0);
   std::vector<u32> staged_of;   // U index -> chunks index
+  std::vector<u64> seg_src, seg_dst;
+  std::vector<u32> seg_len;
+  size_t n_host_staged = 0;
+  std::vector<u32> p_n(P + 1, 0);   // per pair: its staged chunks, then (prefix sums) the U index of its first one
   {
-    u64 off = 0;
-    staged_of.reserve(chunks.size()); ap.c_pair.reserve(chunks.size()); ap.c_rel.reserve(chunks.size()); doc_off.reserve(2 * chunks.size());
-    for (u32 p = 0; p < P; p++) {
-      u64 region = off;
-      ap.s_desc[p].chunk_off = region;
+    // per pair: staged chunks, device-resident ones among them, bytes of its region (parallel); places by prefix sums;
+    // then every pair fills its own stretch of the tables (parallel)
+    std::vector<u32> p_dev(P + 1, 0);
+    std::vector<u64> p_bytes(P + 1, 0);
+    host_parallel_for(P, [&](u32 p) {
+      u32 n = 0, nd = 0; u64 by = 0;
       for (u32 k = pc_base[p]; k < pc_base[p + 1]; k++) {
-        HostChunk& hc = chunks[k];
+        const HostChunk& hc = chunks[k];
         if (hc.bad) continue;
-        hc.staged = (u32)staged_of.size();
-        staged_of.push_back(k);
-        ap.c_pair.push_back(p);
-        ap.c_rel.push_back((u32)(off - region));
-        doc_off.push_back(off); doc_off.push_back(off + hc.len);
-        off += hc.len;
-        off = (off + 15) & ~(u64)15;
+        n++; nd += hc.dev != nullptr; by += ((u64)hc.len + 15) & ~(u64)15;
       }
-      if (off - region >= 0xFFFFFFF0ull) { set_error(ctx, std::string(who) + ": changes of one document exceed 4 GiB"); return AMH_ERR_BATCH_TOO_LARGE; }
-      ap.s_desc[p].chunk_len = (u32)(off - region);
+      p_n[p] = n; p_dev[p] = nd; p_bytes[p] = by;
+    });
+    u64 off = 0;
+    u32 nu = 0, ndev = 0;
+    for (u32 p = 0; p < P; p++) {
+      if (p_bytes[p] >= 0xFFFFFFF0ull) { set_error(ctx, std::string(who) + ": changes of one document exceed 4 GiB"); return AMH_ERR_BATCH_TOO_LARGE; }
+      if ((u64)nu + p_n[p] >= 0x7FFFFFF0ull) { set_error(ctx, std::string(who) + ": batch too large"); return AMH_ERR_BATCH_TOO_LARGE; }
+      const u64 by = p_bytes[p];
+      const u32 n = p_n[p], nd = p_dev[p];
+      ap.s_desc[p].chunk_off = off; ap.s_desc[p].chunk_len = (u32)by;
+      p_n[p] = nu; p_dev[p] = ndev; p_bytes[p] = off;
+      nu += n; ndev += nd; off += by;
     }
+    p_n[P] = nu; p_dev[P] = ndev;
+    n_host_staged = nu - ndev;
+    staged_of.resize(nu); ap.c_pair.resize(nu); ap.c_rel.resize(nu); doc_off.resize(2 * (size_t)nu);
+    seg_src.resize(ndev); seg_len.resize(ndev); seg_dst.resize(ndev);
     pt.mark("apply: stage layout");
     if ((size_t)off + 256 > ctx->stage_cap) {
       rt_sync(ctx->stream);   // nothing may still be copying out of the old area
@@ -2333,24 +2346,29 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       ctx->stage = (u8*)rt_host_alloc(ctx->stage_cap);
       if (!ctx->stage) { ctx->stage_cap = 0; set_error(ctx, std::string(who) + ": out of host memory"); return AMH_ERR_OOM; }
     }
-    h_arena.p = ctx->stage; h_arena.n = (size_t)off + 256;   // read until the decisions below are made; the reload inside mg_execute may stage again
+    h_arena.p = ctx->stage; h_arena.n = (size_t)off + 256;   // read until the decisions below are made
     memset(h_arena.data() + off, 0, 256);
-    host_parallel_for((u32)staged_of.size(), [&](u32 u) {   // chunk bytes + the alignment gap behind them
-      u64 o0 = doc_off[2 * (size_t)u], o1 = doc_off[2 * (size_t)u + 1], next = (o1 + 15) & ~(u64)15;
-      HostChunk& hc = chunks[staged_of[u]];
-      if (hc.dev) { hc.p = h_arena.data() + o0; return; }   // filled by the copy back from the device arena below
-      memcpy(h_arena.data() + o0, hc.p, hc.len);
-      memset(h_arena.data() + o1, 0, (size_t)(next - o1));
+    host_parallel_for(P, [&](u32 p) {
+      u32 u = p_n[p], sd = p_dev[p];
+      const u64 region = p_bytes[p];
+      u64 o = region;
+      for (u32 k = pc_base[p]; k < pc_base[p + 1]; k++) {
+        HostChunk& hc = chunks[k];
+        if (hc.bad) continue;
+        hc.staged = u;
+        staged_of[u] = k; ap.c_pair[u] = p; ap.c_rel[u] = (u32)(o - region);
+        doc_off[2 * (size_t)u] = o; doc_off[2 * (size_t)u + 1] = o + hc.len;
+        const u64 next = (o + hc.len + 15) & ~(u64)15;
+        if (hc.dev) {   // gathered on the device; the host's picture of the arena receives its head only
+          hc.p = h_arena.data() + o;
+          seg_src[sd] = (u64)(uintptr_t)hc.dev; seg_len[sd] = (u32)hc.len; seg_dst[sd] = o; sd++;
+        } else {        // chunk bytes + the alignment gap behind them
+          memcpy(h_arena.data() + o, hc.p, hc.len);
+          memset(h_arena.data() + o + hc.len, 0, (size_t)(next - (o + hc.len)));
+        }
+        o = next; u++;
+      }
     });
-  }
-  std::vector<u64> seg_src, seg_dst;
-  std::vector<u32> seg_len;
-  size_t n_host_staged = 0;
-  seg_src.reserve(staged_of.size()); seg_len.reserve(staged_of.size()); seg_dst.reserve(staged_of.size());
-  for (u32 u = 0; u < staged_of.size(); u++) {
-    const HostChunk& hc = chunks[staged_of[u]];
-    if (!hc.dev) { n_host_staged++; continue; }
-    seg_src.push_back((u64)(uintptr_t)hc.dev); seg_len.push_back((u32)hc.len); seg_dst.push_back(doc_off[2 * (size_t)u]);
   }
   u32 NCH = (u32)staged_of.size();
   ap.n_chunks = NCH;
@@ -2517,10 +2535,10 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   ap.c_applied.assign((size_t)NCH + 1, 0);
   ap.h_start_op.resize(NCH); ap.h_nops.resize(NCH);
   ap.h_chunk_off.resize(NCH); ap.h_chunk_len.resize(NCH);
-  for (u32 u = 0; u < NCH; u++) {
+  host_parallel_for(NCH, [&](u32 u) {
     ap.h_start_op[u] = hdr[u].start_op; ap.h_nops[u] = u_cnt[u].n_rows;
     ap.h_chunk_off[u] = doc_off[2 * (size_t)u]; ap.h_chunk_len[u] = (u32)(doc_off[2 * (size_t)u + 1] - doc_off[2 * (size_t)u]);
-  }
+  }, 4096, 1024);
   ap.all_dev = NCH != 0 && n_host_staged == 0 && seg_src.size() == NCH;
   ap.amap_base.assign((size_t)NCH + 1, 0);
   ap.ix_base.assign(P + 1, 0);
@@ -2541,20 +2559,16 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       pos += (size_t)l;
     }
   };
-  for (u32 p = 0; p < P; p++) {
+  host_parallel_for(P, [&](u32 p) {
     u32 a = items[p].doc;
     d_pair[a] = p; s_pair[p] = p; p_a[p] = a; p_b[p] = p;
     memset(&m_desc[p], 0, sizeof(DocDesc)); memset(&m_cnt[p], 0, sizeof(DocCounts));
-    // rows of U per pair
-    {
-      u32 first_u = AMH_NULL32, last_u = AMH_NULL32;
-      for (u32 k = pc_base[p]; k < pc_base[p + 1]; k++) if (chunks[k].staged != AMH_NULL32) { if (first_u == AMH_NULL32) first_u = chunks[k].staged; last_u = chunks[k].staged; }
-      u32 rb0 = first_u == AMH_NULL32 ? (p ? ap.s_row_base[p] : 0) : u_row_base[first_u];
-      u32 rb1 = first_u == AMH_NULL32 ? rb0 : u_row_base[last_u + 1];
-      ap.s_row_base[p] = rb0; ap.s_row_base[p + 1] = rb1;
-      ap.s_cnt[p].n_rows = rb1 - rb0;
-    }
-  }
+    // rows of U per pair (the chunks of a pair are staged next to each other, pair after pair)
+    const u32 rb0 = u_row_base[p_n[p]], rb1 = u_row_base[p_n[p + 1]];
+    ap.s_row_base[p] = rb0;
+    if (p + 1 == P) ap.s_row_base[P] = rb1;
+    ap.s_cnt[p].n_rows = rb1 - rb0;
+  }, 1024, 256);
   // Pairs are decided in blocks of DEC_BLK by a few host threads; a block appends into one set of vectors (with the
   // offsets at which each of its pairs starts) and reuses one set of scratch containers, so the join below is a few
   // bulk appends per block and a pair costs no allocations of its own.
@@ -2747,47 +2761,45 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     for (u32 p = blk * DEC_BLK, e = std::min(P, p + DEC_BLK); p < e; p++) decide(p, outs[blk]);
   }, 4, 1);
   pt.mark("apply: decisions: per pair (threads)");
-  {   // one reservation per joined vector
-    size_t n_map_a = 0, n_map_b = 0, n_act = 0, n_chg = 0, n_dep = 0, n_ix = 0, n_amap = 0;
-    for (auto& o : outs) { n_map_a += o.map_a.size(); n_map_b += o.map_b.size(); n_act += o.m_actor_off.size(); n_chg += o.mc_from.size(); n_dep += o.m_dep_idx.size(); n_ix += o.ix_actor.size(); n_amap += o.amap.size(); }
-    map_a.reserve(map_a.size() + n_map_a); map_b.reserve(map_b.size() + n_map_b); map_b2a.reserve(map_b2a.size() + n_map_b);
-    m_actor_off.reserve(m_actor_off.size() + n_act); m_actor_len.reserve(m_actor_len.size() + n_act); m_actor_rank.reserve(m_actor_rank.size() + n_act);
-    mc_from.reserve(mc_from.size() + n_chg); mc_ndeps.reserve(mc_ndeps.size() + n_chg); mc_dep_base.reserve(mc_dep_base.size() + n_chg);
-    mc_doc.reserve(mc_doc.size() + n_chg); mc_is_dep.reserve(mc_is_dep.size() + n_chg); m_dep_idx.reserve(m_dep_idx.size() + n_dep);
-    ap.ix_actor.reserve(n_ix); ap.ix_start.reserve(n_ix); ap.ix_nops.reserve(n_ix); ap.ix_row.reserve(n_ix); ap.amap.reserve(n_amap);
-  }
-  for (u32 blk = 0; blk < n_blk; blk++) {
-    PairOut& o = outs[blk];
-    const u32 b_mapa = (u32)map_a.size(), b_mapb = (u32)map_b.size(), b_actor = (u32)m_actor_off.size(), b_chg = (u32)mc_from.size(), b_ix = (u32)ap.ix_actor.size();
-    for (u32 p = blk * DEC_BLK, e = std::min(P, p + DEC_BLK), i = 0; p < e; p++, i++) {
-      mapa_base[p] = b_mapa + o.p_mapa[i]; mapb_base[p] = b_mapb + o.p_mapb[i];
-      m_actor_base[p] = b_actor + o.p_actor[i]; m_chg_base[p] = b_chg + o.p_chg[i];
-      ap.ix_base[p] = b_ix + o.p_ix[i];
-      if (o.p_arena[i]) { m_desc[p].chunk_off = arena_len; arena_len += o.p_arena[i]; }
+  {   // join: every block's vectors go to their places in the plan (places by prefix sums, copies in parallel)
+    struct Base { size_t mapa, mapb, actor, chg, dep, ix, amap; };
+    std::vector<Base> base(n_blk + 1);
+    Base run{map_a.size(), map_b.size(), m_actor_off.size(), mc_from.size(), m_dep_idx.size(), ap.ix_actor.size(), ap.amap.size()};
+    for (u32 blk = 0; blk < n_blk; blk++) {
+      PairOut& o = outs[blk];
+      base[blk] = run;
+      for (u32 p = blk * DEC_BLK, e = std::min(P, p + DEC_BLK), i = 0; p < e; p++, i++)
+        if (o.p_arena[i]) { m_desc[p].chunk_off = arena_len; arena_len += o.p_arena[i]; }
+      n_failed += o.failed;
+      run.mapa += o.map_a.size(); run.mapb += o.map_b.size(); run.actor += o.m_actor_off.size(); run.chg += o.mc_from.size();
+      run.dep += o.m_dep_idx.size(); run.ix += o.ix_actor.size(); run.amap += o.amap.size();
     }
-    n_failed += o.failed;
-    u32 dep0 = (u32)m_dep_idx.size();
-    for (auto& v : o.mc_dep_base) v += dep0;
-    map_a.insert(map_a.end(), o.map_a.begin(), o.map_a.end());
-    map_b.insert(map_b.end(), o.map_b.begin(), o.map_b.end());
-    map_b2a.insert(map_b2a.end(), o.map_b2a.begin(), o.map_b2a.end());
-    m_actor_off.insert(m_actor_off.end(), o.m_actor_off.begin(), o.m_actor_off.end());
-    m_actor_len.insert(m_actor_len.end(), o.m_actor_len.begin(), o.m_actor_len.end());
-    m_actor_rank.insert(m_actor_rank.end(), o.m_actor_rank.begin(), o.m_actor_rank.end());
-    mc_from.insert(mc_from.end(), o.mc_from.begin(), o.mc_from.end());
-    mc_ndeps.insert(mc_ndeps.end(), o.mc_ndeps.begin(), o.mc_ndeps.end());
-    mc_dep_base.insert(mc_dep_base.end(), o.mc_dep_base.begin(), o.mc_dep_base.end());
-    m_dep_idx.insert(m_dep_idx.end(), o.m_dep_idx.begin(), o.m_dep_idx.end());
-    mc_doc.insert(mc_doc.end(), o.mc_doc.begin(), o.mc_doc.end());
-    mc_is_dep.insert(mc_is_dep.end(), o.mc_is_dep.begin(), o.mc_is_dep.end());
-    ap.ix_actor.insert(ap.ix_actor.end(), o.ix_actor.begin(), o.ix_actor.end());
-    ap.ix_start.insert(ap.ix_start.end(), o.ix_start.begin(), o.ix_start.end());
-    ap.ix_nops.insert(ap.ix_nops.end(), o.ix_nops.begin(), o.ix_nops.end());
-    ap.ix_row.insert(ap.ix_row.end(), o.ix_row.begin(), o.ix_row.end());
-    const u32 b_amap = (u32)ap.amap.size();
-    for (size_t i = 0; i < o.amap_u.size(); i++) ap.amap_base[o.amap_u[i]] = b_amap + o.amap_at[i];
-    ap.amap.insert(ap.amap.end(), o.amap.begin(), o.amap.end());
-    o = PairOut();
+    base[n_blk] = run;
+    map_a.resize(run.mapa); map_b.resize(run.mapb); map_b2a.resize(run.mapb);
+    m_actor_off.resize(run.actor); m_actor_len.resize(run.actor); m_actor_rank.resize(run.actor);
+    mc_from.resize(run.chg); mc_ndeps.resize(run.chg); mc_dep_base.resize(run.chg); mc_doc.resize(run.chg); mc_is_dep.resize(run.chg);
+    m_dep_idx.resize(run.dep);
+    ap.ix_actor.resize(run.ix); ap.ix_start.resize(run.ix); ap.ix_nops.resize(run.ix); ap.ix_row.resize(run.ix);
+    ap.amap.resize(run.amap);
+    host_parallel_for(n_blk, [&](u32 blk) {
+      PairOut& o = outs[blk];
+      const Base& bs = base[blk];
+      for (u32 p = blk * DEC_BLK, e = std::min(P, p + DEC_BLK), i = 0; p < e; p++, i++) {
+        mapa_base[p] = (u32)bs.mapa + o.p_mapa[i]; mapb_base[p] = (u32)bs.mapb + o.p_mapb[i];
+        m_actor_base[p] = (u32)bs.actor + o.p_actor[i]; m_chg_base[p] = (u32)bs.chg + o.p_chg[i];
+        ap.ix_base[p] = (u32)bs.ix + o.p_ix[i];
+      }
+      for (auto& v : o.mc_dep_base) v += (u32)bs.dep;
+      auto put = [](auto& dst, size_t at, const auto& src) { std::copy(src.begin(), src.end(), dst.begin() + at); };
+      put(map_a, bs.mapa, o.map_a); put(map_b, bs.mapb, o.map_b); put(map_b2a, bs.mapb, o.map_b2a);
+      put(m_actor_off, bs.actor, o.m_actor_off); put(m_actor_len, bs.actor, o.m_actor_len); put(m_actor_rank, bs.actor, o.m_actor_rank);
+      put(mc_from, bs.chg, o.mc_from); put(mc_ndeps, bs.chg, o.mc_ndeps); put(mc_dep_base, bs.chg, o.mc_dep_base);
+      put(mc_doc, bs.chg, o.mc_doc); put(mc_is_dep, bs.chg, o.mc_is_dep); put(m_dep_idx, bs.dep, o.m_dep_idx);
+      put(ap.ix_actor, bs.ix, o.ix_actor); put(ap.ix_start, bs.ix, o.ix_start); put(ap.ix_nops, bs.ix, o.ix_nops); put(ap.ix_row, bs.ix, o.ix_row);
+      for (size_t i = 0; i < o.amap_u.size(); i++) ap.amap_base[o.amap_u[i]] = (u32)bs.amap + o.amap_at[i];
+      put(ap.amap, bs.amap, o.amap);
+      o = PairOut();
+    }, 2, 1);
   }
   ap.amap_base[NCH] = (u32)ap.amap.size();
   mapa_base[P] = (u32)map_a.size(); mapb_base[P] = (u32)map_b.size();

@@ -29,7 +29,12 @@ def check_apply_tail(engine, docs, cut):
         bases.append(base.save(deflate=False))
         tails.append(chunks[k:])
     b = engine.load_batch(bases)
-    res = b.apply_batch([(i, b"".join(t)) for i, t in enumerate(tails) if t])
+    # the buffers of the call back to back in one arena (Batch.apply_arena: same call, pointer table built with numpy)
+    items = [(i, b"".join(t)) for i, t in enumerate(tails) if t]
+    offs = [0]
+    for _, buf in items:
+        offs.append(offs[-1] + len(buf))
+    res = b.apply_arena([i for i, _ in items], b"".join(buf for _, buf in items), offs)
     assert not any(res), res
     saved = b.save_all(deflate=False)
     for i in range(len(docs)):
