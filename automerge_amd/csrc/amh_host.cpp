@@ -165,6 +165,11 @@ struct HostView {  // lazily fetched mirrors for the accessors
   std::vector<i64> c_time;
   std::vector<u8> c_hash, out_arena;
   std::map<u32, std::vector<u8>> heads_cache;
+  // the actor tables of the documents, packed (ensure_actor_pack): what an apply reads of the documents it changes when
+  // their bytes are not on the host
+  bool pack_ok = false;
+  std::vector<u8> actor_pack;
+  std::vector<u32> actor_pack_off;   // [n_docs + 1]
 };
 
 struct amh_batch {
@@ -930,6 +935,31 @@ static bool ensure_chg(const amh_batch* b) {
             fetch(b, hv.actor_len, B.actor_len, (size_t)B.tot_actors) && fetch(b, hv.c_doc, B.c_doc, nc);
   hv.chg_ok = ok;
   return ok;
+}
+
+// main thread only (allocates from the pool)
+static bool ensure_actor_pack(amh_batch* b) {
+  HostView& hv = b->hv;
+  if (hv.pack_ok) return true;
+  amh_ctx* ctx = b->ctx;
+  const BatchDev& B = b->B;
+  const u32 n = B.n_docs;
+  bool ok = true;
+  CallScratch scratch(b);
+  u32* d_len = balloc<u32>(b, (size_t)n + 2, &ok); u32* d_off = balloc<u32>(b, (size_t)n + 2, &ok);
+  if (!ok) return false;
+  amh_actor_pack_len(B, d_len, (void*)ctx->stream);
+  if (!rt_d2d(d_off, d_len, (size_t)n * sizeof(u32), ctx->stream)) return false;
+  u32 total = 0;
+  if (!scan_inplace(b, d_off, n, &total) || total == 0xFFFFFFFFu) return false;
+  u8* d_pack = balloc<u8>(b, (size_t)total + 16, &ok);
+  if (!ok) return false;
+  amh_actor_pack_copy(B, d_len, d_off, d_pack, (void*)ctx->stream);
+  hv.actor_pack.resize((size_t)total + 16);
+  hv.actor_pack_off.resize((size_t)n + 1);
+  if (!rt_d2h(hv.actor_pack.data(), d_pack, total, ctx->stream) || !rt_d2h(hv.actor_pack_off.data(), d_off, ((size_t)n + 1) * sizeof(u32), ctx->stream)) return false;
+  hv.pack_ok = true;
+  return true;
 }
 
 static const char* status_msg(int s) {
@@ -1870,6 +1900,7 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   //      together in device memory (merged chunks from the save buffer, the others from the old arena): the
   //      bytes do not visit the host; its host copy is fetched only when an accessor asks for bytes. ---------
   amh_staged* old_st = dst->staged;
+  if (!old_st->single_chunk && !ensure_host_arena(old_st)) return failm("D2H copy failed");   // where the first chunk of an input ends is read from its bytes
   for (int attempt = 0; attempt < 2; attempt++) {
   std::vector<u64> seg_src(nd), seg_dst(nd), se(2 * (size_t)nd + 2, 0);
   std::vector<u32> seg_len(nd);
@@ -2194,10 +2225,14 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   PhaseTimer pt(who);
   // the host view of dst's history (hashes, deps, actors: ~100 bytes per change) comes back on a helper thread while
   // this one splits, stages and decodes the incoming chunks; it is first needed by the decisions further down
+  // (of the documents' own bytes the decisions read the actor tables: packed on the device when the bytes are not on
+  // the host already)
+  const bool use_pack = !dst->staged->host_ok;
+  if (use_pack && !ensure_actor_pack(dst)) { set_error(ctx, std::string(who) + ": D2H copy failed"); return AMH_ERR_DEVICE; }
   bool view_ok = true;
   std::thread view_thread([&]() {
     rt_set_device(ctx->device);
-    view_ok = ensure_chg(dst) && ensure_host_arena(dst->staged);
+    view_ok = ensure_chg(dst);
   });
   struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } view_joiner{view_thread};
   const HostView& ha = dst->hv;
@@ -2635,8 +2670,9 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       if (mode == APM_STRICT || mode == APM_LOAD_ERROR) { p_status[p] = first_err; results[p] = first_err; o.failed = 1; return; }
       if (mode == APM_LOAD_IGNORE) { p_status[p] = -1; return; }   // nothing behind the first chunk is applied (automerge.rs:690-694)
     }
-    const u8* ca = dst->staged->h_arena.data() + dst->staged->h_doc_off[2 * (size_t)a];
     u32 na = ha.desc[a].n_actors, aba = ha.actor_base[a];
+    // actor i of the document: in the packed tables (which start at the document's first actor id) or in the host's copy of its bytes
+    const u8* ca = use_pack ? ha.actor_pack.data() + ha.actor_pack_off[a] - (na ? ha.actor_off[aba] : 0) : dst->staged->h_arena.data() + dst->staged->h_doc_off[2 * (size_t)a];
     auto abytes = [&](u32 i) { return Bytes(ca + ha.actor_off[aba + i], ha.actor_len[aba + i]); };
     bool sorted = true;
     for (u32 i = 1; i < na && sorted; i++) sorted = bcmp(abytes(i - 1), abytes(i)) < 0;

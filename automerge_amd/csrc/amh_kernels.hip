@@ -1230,6 +1230,29 @@ __global__ void __launch_bounds__(AMH_BLOCK) g_ap_head_copy(const u8* arena, con
   const u32 k = len16[u] / 16;
   for (u32 i = 0; i < k; i++) d[i] = s[i];
 }
+// The actor tables of the documents of a batch (the bytes from the first actor id to the end of the last one, length
+// prefixes included), packed back to back for the host: all an apply reads of the documents it changes.
+__global__ void __launch_bounds__(AMH_BLOCK) g_actor_pack_len(BatchDev B, u32* len) {
+  const u32 d = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  if (d >= B.n_docs) return;
+  const u32 na = B.status[d] ? 0 : B.desc[d].n_actors, ab = B.actor_base[d];
+  len[d] = na ? B.actor_off[ab + na - 1] + B.actor_len[ab + na - 1] - B.actor_off[ab] : 0;
+}
+__global__ void __launch_bounds__(AMH_BLOCK) g_actor_pack_copy(BatchDev B, const u32* len, const u32* off, u8* dst) {
+  const u32 d = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  if (d >= B.n_docs || len[d] == 0) return;
+  const u8* s = B.arena + B.desc[d].chunk_off + B.actor_off[B.actor_base[d]];
+  u8* o = dst + off[d];
+  for (u32 i = 0; i < len[d]; i++) o[i] = s[i];
+}
+void amh_actor_pack_len(const BatchDev& B, u32* len, void* stream) {
+  if (B.n_docs == 0) return;
+  hipLaunchKernelGGL(g_actor_pack_len, dim3((B.n_docs + AMH_BLOCK - 1) / AMH_BLOCK), dim3(AMH_BLOCK), 0, (hipStream_t)stream, B, len);
+}
+void amh_actor_pack_copy(const BatchDev& B, const u32* len, const u32* off, u8* dst, void* stream) {
+  if (B.n_docs == 0) return;
+  hipLaunchKernelGGL(g_actor_pack_copy, dim3((B.n_docs + AMH_BLOCK - 1) / AMH_BLOCK), dim3(AMH_BLOCK), 0, (hipStream_t)stream, B, len, off, dst);
+}
 void amh_ap_head_len(const ChgHdr* hdr, const i32* status, u32* len16, u32 n, void* stream) {
   if (n == 0) return;
   hipLaunchKernelGGL(g_ap_head_len, dim3((n + AMH_BLOCK - 1) / AMH_BLOCK), dim3(AMH_BLOCK), 0, (hipStream_t)stream, hdr, status, len16, n);

@@ -42,6 +42,10 @@ void amh_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst,
 void amh_launch_save_big(const BatchDev& B, int phase, void* stream);
 // heads of staged change chunks: len16[u] = bytes in front of chunk u's column metadata rounded up to 16 (0 for failed
 // chunks); the copy packs them at off[u] (exclusive sums of len16) of dst
+// actor tables of a batch's documents packed for the host: len[d] = bytes from the first actor id of document d to the
+// end of its last one; the copy puts them at off[d] (exclusive sums of len) of dst
+void amh_actor_pack_len(const BatchDev& B, u32* len, void* stream);
+void amh_actor_pack_copy(const BatchDev& B, const u32* len, const u32* off, u8* dst, void* stream);
 void amh_ap_head_len(const ChgHdr* hdr, const i32* status, u32* len16, u32 n, void* stream);
 void amh_ap_head_copy(const u8* arena, const u64* doc_off, const u32* len16, const u32* off, u8* dst, u32 n, void* stream);
 

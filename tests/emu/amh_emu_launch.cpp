@@ -58,6 +58,16 @@ void amh_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst,
 void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void*) {
   for (u32 i = 0; i < n; i++) memcpy(dst + dst_off[i], (const u8*)(uintptr_t)src[i], len[i]);
 }
+void amh_actor_pack_len(const BatchDev& B, u32* len, void*) {
+  for (u32 d = 0; d < B.n_docs; d++) {
+    const u32 na = B.status[d] ? 0 : B.desc[d].n_actors, ab = B.actor_base[d];
+    len[d] = na ? B.actor_off[ab + na - 1] + B.actor_len[ab + na - 1] - B.actor_off[ab] : 0;
+  }
+}
+void amh_actor_pack_copy(const BatchDev& B, const u32* len, const u32* off, u8* dst, void*) {
+  for (u32 d = 0; d < B.n_docs; d++)
+    if (len[d]) memcpy(dst + off[d], B.arena + B.desc[d].chunk_off + B.actor_off[B.actor_base[d]], len[d]);
+}
 void amh_ap_head_len(const ChgHdr* hdr, const i32* status, u32* len16, u32 n, void*) {
   for (u32 u = 0; u < n; u++) len16[u] = status[u] ? 0u : (hdr[u].head_len + 15u) & ~15u;
 }
