@@ -442,7 +442,8 @@ AMH_DEV void k_ap_up_jump(const MergeDev& G, u32 r) {
   const ApplyDev& A = G.A;
   u32 u = A.o_up[r];
   if (!(u & AP_UP_OPEN)) return;
-  A.o_up[r] = A.o_up[u & ~AP_UP_OPEN];
+  for (int step = 0; step < 3 && (u & AP_UP_OPEN); step++) u = A.o_up[u & ~AP_UP_OPEN];   // a few jumps per launch: fewer passes over the rows
+  A.o_up[r] = u;
   *A.flag = 1;
 }
 AMH_DEV void k_ap_succ_build(const MergeDev& G, u32 r) {
@@ -466,11 +467,13 @@ AMH_DEV void k_ap_succ_build(const MergeDev& G, u32 r) {
 AMH_DEV void k_ap_rank_jump(const MergeDev& G, u32 r) {
   const ApplyDev& A = G.A;
   u64 me = amh_load64(&A.o_rank[r]);
-  u32 n = (u32)me;
-  if (n & AP_RANK_TOP) return;
-  u64 nx = amh_load64(&A.o_rank[n]);
-  amh_store64(&A.o_rank[r], (u64)(u32)nx | (((me >> 32) + (nx >> 32)) << 32));
-  if (!((u32)nx & AP_RANK_TOP)) *A.flag = 1;
+  if ((u32)me & AP_RANK_TOP) return;
+  for (int step = 0; step < 3 && !((u32)me & AP_RANK_TOP); step++) {   // a few jumps per launch: fewer passes over the rows
+    const u64 nx = amh_load64(&A.o_rank[(u32)me]);
+    me = (u64)(u32)nx | (((me >> 32) + (nx >> 32)) << 32);
+  }
+  amh_store64(&A.o_rank[r], me);
+  if (!((u32)me & AP_RANK_TOP)) *A.flag = 1;
 }
 // A6d  weight of a top row = rows of its subtree, itself included.  Thread per row.
 AMH_DEV void k_ap_weight(const MergeDev& G, u32 r) {
