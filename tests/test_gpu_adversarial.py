@@ -21,6 +21,7 @@ def engine():
     ("new_map_keys", (20000,)),                 # a change-only load of 20k new map keys (one gap)
     ("head_siblings", (8, 1250)),               # 10k siblings inserted at HEAD by different actors
     ("typed_run", (5000, 100)),                 # a 5k-character typed run applied as one change
+    ("typed_run", (50000, 100)),                # ... 50k characters: one subtree 50k deep, placed by list ranking (k_ap_rank_jump)
     ("siblings_behind_one_element", (8, 1250)), # 10k children of one element that arrives in the same call
     ("counter_increments", (20000,)),           # one op gaining 20k successors
     ("wide_overwrite", (3000, 4)),              # one op with 3k preds

@@ -11,11 +11,16 @@ ids = list(range(N))
 def step(verbose=False):
     t0 = time.time()
     bs = []
+    t_rel = 0.0
     for r, s in enumerate(staged):
         bs.append(e.load_staged(s))
         if r:
+            tr = time.time()
             bs[-1].release_ops()
+            t_rel += time.time() - tr
     t1 = time.time()
+    if verbose:
+        print("of the loads: release_ops x%d %.1f ms" % (R - 1, t_rel * 1e3))
     assert bs[0].merge_many(bs[1:], ids, [ids] * (R - 1)) == 0
     t2 = time.time()
     if verbose:
