@@ -188,6 +188,14 @@ struct amh_batch {
 };
 
 static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts, bool trailing);
+// job tables of the columns that are encoded over many waves (save_big_prepare / enc_big_prepare)
+struct SaveBigHost {
+  std::vector<u32> j_bc, j_k, b_doc, b_col, b_first, b_nr, nops, opbase;
+  std::vector<u8> big;
+  std::vector<DocCounts> cnt;
+};
+static bool enc_big_prepare(amh_ctx* ctx, amh_batch* b, BatchDev& B, SaveBigHost& H);
+static void save_big_launch(amh_ctx* ctx, const BatchDev& B, int phase);
 
 // ---------------------------------------------------------------------------------------------
 // launch helpers
@@ -826,7 +834,10 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
   rt_stream_wait(ctx->side, &ctx->ev_fork2);
   launch_on(ctx, ctx->side, AK_VISIBLE, B, B.tot_rows);
   rt_event_record(&ctx->ev_join, ctx->side);
+  SaveBigHost ebh;   // changes of tens of thousands of ops: their columns are cut into ranges, a wave each (g_en_big)
+  if (!enc_big_prepare(ctx, b, B, ebh)) return fail("device pipeline failed: job tables of the change re-encode");
   launch(ctx, AK_ENCODE_SIZE, B, B.tot_chg * AMH_NCOLS);
+  save_big_launch(ctx, B, 2);
   launch(ctx, AK_CHG_LAYOUT, B, B.tot_chg);
 #ifdef AMH_EMU
   memcpy(B.c_out_off, B.c_out_len, (size_t)B.tot_chg * 4);
@@ -840,6 +851,8 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
   B.out_arena = balloc<u8>(b, (size_t)tot_out + 256, &ok);
   if (!ok) return fail("device out of memory");
   launch(ctx, AK_ENCODE_STORE, B, B.tot_chg * AMH_NCOLS);
+  save_big_launch(ctx, B, 3);
+  B.sv_nj = 0; B.sv_nbc = 0; B.sv_big = nullptr;   // (the tables were this pass's)
   launch(ctx, AK_CHG_HEADER, B, B.tot_chg);
   // hash the changes level by level: every change of a level only needs hashes of earlier levels
   B.lvl_order = balloc<u32>(b, (size_t)B.tot_chg + 1, &ok);
@@ -1353,19 +1366,14 @@ static T* upload(amh_batch* b, const std::vector<T>& v, bool* ok) {
   if (p && !v.empty() && !rt_h2d(p, v.data(), v.size() * sizeof(T), b->ctx->stream)) *ok = false;
   return p;
 }
-// Save of documents with hundreds of thousands of rows (g_sv_big, amh_segenc.inl): the job tables.  `B` is the caller's
+// Save of documents with 64k rows and more (g_sv_big, amh_segenc.inl): the job tables.  `B` is the caller's
 // copy of the batch descriptor (the sv_* fields are per call); the vectors stay alive until the caller has synchronised.
 // AMH_BIGSAVE_ROWS / AMH_BIGSAVE_RANGE: rows from which a document is "big" / rows per range (tests push every shape
 // of document through the ranges with 1 / 64).
-struct SaveBigHost {
-  std::vector<u32> j_bc, j_k, b_doc, b_col, b_first, b_nr;
-  std::vector<u8> big;
-  std::vector<DocCounts> cnt;
-};
 static bool save_big_prepare(amh_ctx* ctx, amh_batch* b, BatchDev& B, const std::vector<i32>& status, SaveBigHost& H) {
   B.sv_nj = 0; B.sv_nbc = 0; B.sv_big = nullptr;
 #ifndef AMH_EMU
-  u64 thr = 262144, range = 16384;
+  u64 thr = 65536, range = 16384;
   if (const char* e = getenv("AMH_BIGSAVE_ROWS")) thr = strtoull(e, nullptr, 10);
   if (const char* e = getenv("AMH_BIGSAVE_RANGE")) range = strtoull(e, nullptr, 10);
   range = std::max<u64>(64, range & ~(u64)63);
@@ -1399,6 +1407,52 @@ static bool save_big_prepare(amh_ctx* ctx, amh_batch* b, BatchDev& B, const std:
   B.sv_nj = (u32)nj; B.sv_nbc = (u32)H.b_doc.size(); B.sv_range = (u32)range;
 #else
   (void)ctx; (void)b; (void)status; (void)H;
+#endif
+  return true;
+}
+// The same for the change re-encode of a load: a "big column" is one of the 14 op columns of a change with
+// AMH_BIGENC_ROWS ops (default 65536) and more; ranges of AMH_BIGENC_RANGE values (default 16384).
+static bool enc_big_prepare(amh_ctx* ctx, amh_batch* b, BatchDev& B, SaveBigHost& H) {
+  B.sv_nj = 0; B.sv_nbc = 0; B.sv_big = nullptr;
+#ifndef AMH_EMU
+  u64 thr = 65536, range = 16384;
+  if (const char* e = getenv("AMH_BIGENC_ROWS")) thr = strtoull(e, nullptr, 10);
+  if (const char* e = getenv("AMH_BIGENC_RANGE")) range = strtoull(e, nullptr, 10);
+  range = std::max<u64>(64, range & ~(u64)63);
+  if (thr == 0) thr = 1;
+  const u32 nc = B.tot_chg;
+  if (nc == 0 || (u64)B.tot_ops < thr) return true;
+  H.nops.resize(nc); H.opbase.resize(nc);
+  if (!rt_d2h(H.nops.data(), B.c_nops, (size_t)nc * sizeof(u32), ctx->stream) || !rt_d2h(H.opbase.data(), B.c_op_base, (size_t)nc * sizeof(u32), ctx->stream)) return false;
+  H.big.assign(nc, 0);
+  for (u32 c = 0; c < nc; c++) {
+    const u64 n = H.nops[c];
+    if (n < thr) continue;
+    u32 pb[2] = {0, 0};   // the change's pred entries: j_pred_base[first op], j_pred_base[behind its last op]
+    if (!rt_d2h(&pb[0], B.j_pred_base + H.opbase[c], sizeof(u32), ctx->stream) || !rt_d2h(&pb[1], B.j_pred_base + H.opbase[c] + n, sizeof(u32), ctx->stream)) return false;
+    const u64 pn = pb[1] - pb[0];
+    H.big[c] = 1;
+    for (u32 col = 0; col < AMH_NCOLS; col++) {
+      const u64 ncol = (col == 10 || col == 11) ? pn : n;
+      const u64 nr = (ncol + range - 1) / range;
+      if (nr == 0) continue;
+      if (H.j_bc.size() + nr >= 0x7FFFFFFFull) return false;
+      H.b_doc.push_back(c); H.b_col.push_back(col); H.b_first.push_back((u32)H.j_bc.size()); H.b_nr.push_back((u32)nr);
+      for (u64 k = 0; k < nr; k++) { H.j_bc.push_back((u32)H.b_doc.size() - 1); H.j_k.push_back((u32)k); }
+    }
+  }
+  if (H.j_bc.empty()) return true;
+  bool ok = true;
+  const size_t nj = H.j_bc.size();
+  B.svj_bc = upload(b, H.j_bc, &ok); B.svj_k = upload(b, H.j_k, &ok);
+  B.svb_doc = upload(b, H.b_doc, &ok); B.svb_col = upload(b, H.b_col, &ok); B.svb_first = upload(b, H.b_first, &ok); B.svb_nr = upload(b, H.b_nr, &ok);
+  B.sv_big = upload(b, H.big, &ok);
+  B.svj_sum = balloc<u32>(b, 9 * nj + 1, &ok); B.svj_cin = balloc<u32>(b, 3 * nj + 1, &ok);
+  B.svj_total = balloc<u32>(b, nj + 1, &ok); B.svj_any = balloc<u32>(b, nj + 1, &ok); B.svj_tail = balloc<u32>(b, nj + 1, &ok);
+  if (!ok) { B.sv_nj = 0; B.sv_big = nullptr; return false; }
+  B.sv_nj = (u32)nj; B.sv_nbc = (u32)H.b_doc.size(); B.sv_range = (u32)range;
+#else
+  (void)ctx; (void)b; (void)H;
 #endif
   return true;
 }

@@ -257,7 +257,8 @@ __global__ void __launch_bounds__(64) g_encode_grp(BatchDev B) {
   __shared__ EncShared<EncTiles<G>::N> S;
   const u32 lane = threadIdx.x;
   const u32 c = blockIdx.x * 64 + lane;
-  const bool live = c < B.tot_chg && B.status[B.c_doc[c]] == 0;
+  // (a change whose columns are cut into ranges, g_en_big, counts as not live here: lengths 0, set by g_sv_big_total)
+  const bool live = c < B.tot_chg && B.status[B.c_doc[c]] == 0 && !(B.sv_big && B.sv_big[c]);
   const u32 d = live ? B.c_doc[c] : 0;
   if (G == 6) {   // only when a document of this wave has a mark column
     bool has_marks = live && B.desc[d].ocol[OC_MARK_NAME].len != 0;

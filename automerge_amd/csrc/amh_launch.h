@@ -37,8 +37,9 @@ void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream);
 void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void* stream);
 // the same for segments of any alignment and length (change chunks into an out_arena)
 void amh_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst, u32 n, void* stream);
-// save of very large documents (device build only): phase 0 after AK_SAVE_SIZE (column lengths of the big columns),
-// phase 1 after AK_SAVE_STORE (their bytes); nothing when B.sv_nj == 0
+// columns encoded over many waves (device build only; nothing when B.sv_nj == 0).  Save of very large documents:
+// phase 0 after AK_SAVE_SIZE (column lengths of the big columns), phase 1 after AK_SAVE_STORE (their bytes).  The
+// change re-encode of very large changes: phase 2 after AK_ENCODE_SIZE, phase 3 after AK_ENCODE_STORE.
 void amh_launch_save_big(const BatchDev& B, int phase, void* stream);
 // heads of staged change chunks: len16[u] = bytes in front of chunk u's column metadata rounded up to 16 (0 for failed
 // chunks); the copy packs them at off[u] (exclusive sums of len16) of dst

@@ -77,7 +77,7 @@ __device__ __forceinline__ void sc_carry_step(u64 EQP, u64 NUL, u32 cnt, ScCarry
   { const u32 z = sc_ctz64(~LONE); n.litlen0 = (LONE & 1) ? (z >= cnt ? cnt + (c.lone0 ? c.litlen0 : 0) : z) : 0; }
   c = n;
 }
-// A column over many waves (documents of hundreds of thousands of rows: g_sv_big).  The column is cut into ranges of
+// A column over many waves (documents and changes of tens of thousands of rows: g_sv_big, g_en_big).  The column is cut into ranges of
 // rows, a wave each.  All a range needs of the rows behind it is the carry, and what a range does to the carry depends
 // on the carry it receives only in three ways: which of the three possible (start0, lone0) pairs it is, and the two
 // lengths, which are added where a run or a literal stretch reaches the range's end.  So every range first walks its
@@ -441,7 +441,8 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_encode_seg(BatchDev B) {
   const u32 lane = threadIdx.x & 63;
   u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
   const u32 d = B.c_doc[c];
-  const bool live = B.status[d] == 0;
+  const bool big = B.sv_big && B.sv_big[c];   // its columns are cut into ranges (g_en_big); lengths 0 here, set by g_sv_big_total
+  const bool live = B.status[d] == 0 && !big;
   const u32 n = live ? B.c_nops[c] : 0;
   const u32 base = B.c_op_base[c];
   const u8* chunk = B.arena + B.desc[d].chunk_off;
@@ -771,10 +772,11 @@ __global__ void __launch_bounds__(AMH_BLOCK) g_sv_big_chain(BatchDev B) {
     cur = sc_summary_apply(S, cur);
   }
 }
+template <bool SAVE>
 __global__ void __launch_bounds__(AMH_BLOCK) g_sv_big_total(BatchDev B) {
   const u32 bc = blockIdx.x * AMH_BLOCK + threadIdx.x;
   if (bc >= B.sv_nbc) return;
-  const u32 first = B.svb_first[bc], nr = B.svb_nr[bc], d = B.svb_doc[bc], col = B.svb_col[bc];
+  const u32 first = B.svb_first[bc], nr = B.svb_nr[bc], d = B.svb_doc[bc], col = B.svb_col[bc];   // d: document (save) / change (re-encode)
   u32 run = 0, any = 0;
   for (u32 k = nr; k-- > 0;) {
     const u64 j = (u64)first + k;
@@ -783,19 +785,112 @@ __global__ void __launch_bounds__(AMH_BLOCK) g_sv_big_total(BatchDev B) {
     any |= B.svj_any[j];
   }
   // a column of nothing but nulls (rle.rs:33) / a MaybeBoolean column without a true (boolean.rs:131-137) is not written
-  const bool always = col == 16 || col == 19;
-  B.sv_col_len[(u64)d * AMH_SV_NCOLS + col] = (always || any) ? run : 0;
+  if (SAVE) {
+    const bool always = col == 16 || col == 19;   // insert, raw values
+    B.sv_col_len[(u64)d * AMH_SV_NCOLS + col] = (always || any) ? run : 0;
+  } else {
+    const bool always = col == 5 || col == 8;
+    B.c_col_len[(u64)d * AMH_NCOLS + col] = (always || any) ? run : 0;
+  }
+}
+// The change re-encode over many waves: g_sv_big with the columns of a change (the unit of a big column is a change;
+// sources as in g_encode_seg).  Modes as above.
+template <int MODE>
+__global__ void __launch_bounds__(64 * SD_WAVES) g_en_big(BatchDev B) {
+  const u32 wave = sd_uniform(threadIdx.x >> 6);
+  const u32 j = blockIdx.x * SD_WAVES + wave;
+  if (j >= B.sv_nj) return;
+  const u32 lane = threadIdx.x & 63;
+  const u32 bc = B.svj_bc[j], k = B.svj_k[j];
+  const u32 c = B.svb_doc[bc], col = B.svb_col[bc];
+  const u32 d = B.c_doc[c];
+  const bool live = B.status[d] == 0;
+  const u32 n = live ? B.c_nops[c] : 0;
+  const u32 base = B.c_op_base[c];
+  u32 pb = 0, pn = 0;
+  if (n) { pb = B.j_pred_base[base]; pn = B.j_pred_base[base + n] - pb; }
+  u32 ncol = (col == 10 || col == 11) ? pn : n;
+  if (col == 13 && B.desc[d].ocol[OC_MARK_NAME].len == 0) ncol = 0;
+  ScSummary S;
+  sc_summary_init(S);
+  bool any = false;
+  u32 total = 0;
+  ScRange rg;
+  rg.lo = k * B.sv_range;
+  rg.hi = ncol - rg.lo < B.sv_range ? ncol : rg.lo + B.sv_range;
+  const bool work = rg.lo < ncol;
+  u8* out = (u8*)0;
+  u32 col_len = 0;
+  if (MODE != 0) { rg.carry = sv_carry_unpack(B.svj_cin + 3 * (u64)j); rg.total0 = 0; }
+  if (MODE == 2) {
+    if (!work) return;
+    const u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
+    col_len = cl[col];
+    if (col_len == 0) return;
+    u64 o = (u64)B.c_out_off[c] + B.c_cols_off[c];
+    for (u32 q = 0; q < col; q++) o += cl[q];
+    out = B.out_arena + o;
+    rg.total0 = B.svj_tail[j];
+  }
+  if (work) {
+    const u8* chunk = B.arena + B.desc[d].chunk_off;
+    ScCached<uint2> cobj, cmisc;
+    ScCached<uint4> ckey, cval;
+    cobj.init((const uint2*)B.cv[0] + base, 0, false); ckey.init((const uint4*)B.cv[2] + base, 0, false);
+    cmisc.init((const uint2*)B.cv[6] + base, 0, false); cval.init((const uint4*)B.cv[8] + base, 0, false);
+#define EN_NUM(SIGNED, src) { if constexpr (MODE == 0) sc_rle_summary(src, rg.lo, rg.hi, lane, S, any); \
+      else if constexpr (MODE == 1) total = sc_rle_range<SIGNED, false>(src, rg, (u8*)0, 0, lane, any); \
+      else sc_rle_range<SIGNED, true>(src, rg, out, col_len, lane, any); }
+#define EN_BOOL(src) { if constexpr (MODE == 0) sc_bool_summary(src, rg.lo, rg.hi, lane, S, any); \
+      else if constexpr (MODE == 1) total = sc_bool_range<false>(src, rg, (u8*)0, 0, lane, any); \
+      else sc_bool_range<true>(src, rg, out, col_len, lane, any); }
+#define EN_STR(src) { if constexpr (MODE == 0) sc_str_summary(src, rg.lo, rg.hi, lane, S, any); \
+      else if constexpr (MODE == 1) total = sc_str_range<false>(src, rg, (u8*)0, 0, lane, any); \
+      else sc_str_range<true>(src, rg, out, col_len, lane, any); }
+    switch (col) {
+      case 0:  { ScObjSrc s{cobj, false}; EN_NUM(false, s) } break;
+      case 1:  { ScObjSrc s{cobj, true}; EN_NUM(false, s) } break;
+      case 2:  { ScKeyActorSrc s{ckey}; EN_NUM(false, s) } break;
+      case 3:  { ScKeyCtrSrc s{ckey}; EN_NUM(true, s) } break;
+      case 4:  { ScKeyStrSrc s{ckey, chunk}; EN_STR(s) } break;
+      case 5:  { ScInsertSrc s{cmisc}; EN_BOOL(s) } break;
+      case 6:  { ScActionSrc s{cmisc}; EN_NUM(false, s) } break;
+      case 7:  { ScValMetaSrc s{cval}; EN_NUM(false, s) } break;
+      case 8:  { ScValRawSrc s{cval, chunk};
+                 if constexpr (MODE == 1) total = sc_raw_range<false>(s, rg, (u8*)0, 0, lane);
+                 else if constexpr (MODE == 2) sc_raw_range<true>(s, rg, out, col_len, lane); } break;
+      case 9:  { ScPredNumSrc s{cmisc}; EN_NUM(false, s) } break;
+      case 10: { ScPredActorSrc s; s.ids = B.pred_ids + pb; s.amap = B.chg_actor_map + B.c_map_base[c]; EN_NUM(false, s) } break;
+      case 11: { ScPredCtrSrc s; s.ids = B.pred_ids + pb; s.amap = B.chg_actor_map + B.c_map_base[c]; EN_NUM(true, s) } break;
+      case 12: { ScExpandSrc s{cmisc}; EN_BOOL(s) } break;
+      default: { ScMarkSrc s{B, B.ops_sorted + base, chunk}; EN_STR(s) } break;
+    }
+#undef EN_NUM
+#undef EN_BOOL
+#undef EN_STR
+  }
+  if (lane == 0) {
+    if (MODE == 0) { u32* w = B.svj_sum + 9 * (u64)j; sv_carry_pack(S.h[0], w); sv_carry_pack(S.h[1], w + 3); sv_carry_pack(S.h[2], w + 6); }
+    if (MODE == 1) { B.svj_total[j] = total; B.svj_any[j] = any ? 1u : 0u; }
+  }
 }
 void amh_launch_save_big(const BatchDev& B, int phase, void* stream) {
   if (B.sv_nj == 0) return;
   hipStream_t s = (hipStream_t)stream;
   const dim3 gj((B.sv_nj + SD_WAVES - 1) / SD_WAVES), bj(64 * SD_WAVES), gc((B.sv_nbc + AMH_BLOCK - 1) / AMH_BLOCK), bcb(AMH_BLOCK);
-  if (phase == 0) {
+  if (phase == 0) {          // save: column lengths
     hipLaunchKernelGGL((g_sv_big<0>), gj, bj, 0, s, B);
     hipLaunchKernelGGL(g_sv_big_chain, gc, bcb, 0, s, B);
     hipLaunchKernelGGL((g_sv_big<1>), gj, bj, 0, s, B);
-    hipLaunchKernelGGL(g_sv_big_total, gc, bcb, 0, s, B);
-  } else {
+    hipLaunchKernelGGL((g_sv_big_total<true>), gc, bcb, 0, s, B);
+  } else if (phase == 1) {   // save: bytes
     hipLaunchKernelGGL((g_sv_big<2>), gj, bj, 0, s, B);
+  } else if (phase == 2) {   // change re-encode: column lengths
+    hipLaunchKernelGGL((g_en_big<0>), gj, bj, 0, s, B);
+    hipLaunchKernelGGL(g_sv_big_chain, gc, bcb, 0, s, B);
+    hipLaunchKernelGGL((g_en_big<1>), gj, bj, 0, s, B);
+    hipLaunchKernelGGL((g_sv_big_total<false>), gc, bcb, 0, s, B);
+  } else {                   // change re-encode: bytes
+    hipLaunchKernelGGL((g_en_big<2>), gj, bj, 0, s, B);
   }
 }

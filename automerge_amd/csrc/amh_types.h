@@ -180,8 +180,10 @@ struct BatchDev {
   u32* sv_body_len;              // [n_docs]
   u32* sv_off;                   // [n_docs + 1] chunk offsets in sv_out
   u8* sv_out;
-  // save of documents with hundreds of thousands of rows: their op columns are cut into ranges of sv_range rows, a wave
+  // save of documents with 64k rows and more: their op columns are cut into ranges of sv_range rows, a wave
   // each (g_sv_big).  A "big column" is one op column (9..24) of one such document; a job is one range of it.
+  // The change re-encode of a load uses the same tables for changes of tens of thousands of ops (g_en_big): a big
+  // column is then one of the 14 columns of such a change, svb_doc names the change and sv_big is per change.
   u32 sv_nj, sv_nbc, sv_range;
   const u32 *svj_bc, *svj_k;                            // [sv_nj] big column of the job, its range index
   const u32 *svb_doc, *svb_col, *svb_first, *svb_nr;    // [sv_nbc] document, column, first job, ranges

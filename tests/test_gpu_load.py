@@ -136,11 +136,17 @@ def test_device_arrays_match_host_emulation(engine, golden_dir):
         assert np.array_equal(a, b), name
 
 
-@pytest.mark.parametrize("form", ["seg", "lane"])
+@pytest.mark.parametrize("form", ["seg", "lane", "ranges", "ranges-lane"])
 def test_both_encoder_forms(engine, golden_dir, monkeypatch, form):
     """the change re-encode has a wave-per-change form (large changes) and a lane-per-change form (batches of small
-    changes), chosen by the batch's average change size: every document shape through both"""
-    monkeypatch.setenv("AMH_ENCODE_FORM", form)
+    changes), chosen by the batch's average change size: every document shape through both, and with every column of
+    every change cut into ranges of 64 values, a wave each, as changes of tens of thousands of ops are encoded"""
+    if form.startswith("ranges"):
+        monkeypatch.setenv("AMH_BIGENC_ROWS", "1")
+        monkeypatch.setenv("AMH_BIGENC_RANGE", "64")
+        monkeypatch.setenv("AMH_ENCODE_FORM", "lane" if form == "ranges-lane" else "seg")
+    else:
+        monkeypatch.setenv("AMH_ENCODE_FORM", form)
     docs = [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(golden_dir, "docs", "*.automerge")))]
     docs += _docs_map(engine, 24, 77)
     blob, offs = engine.gen_text_docs(0xF00D, 3, 3, 150, 900, 300, 2)
