@@ -710,6 +710,9 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   rt_memset(B.chg_actor_map, 0, ((size_t)b->tot_map + 1) * 4, ctx->stream);
   launch(ctx, AK_ACTORS, B, n);
   launch(ctx, AK_CHG_INIT, B, B.tot_chg);
+  B.cd_err = balloc<u32>(b, (size_t)n * 8 + 1, &ok); B.cd_code = balloc<u32>(b, (size_t)n * 8 + 1, &ok); B.cd_none = balloc<u32>(b, (size_t)n * 8 + 1, &ok);
+  if (!ok) return fail("device out of memory");
+  launch(ctx, AK_DECODE_CHG_COLS, B, n * 8);
   launch(ctx, AK_DECODE_CHG, B, n);
 #ifndef AMH_EMU
   B.fr_n = nullptr;

@@ -411,83 +411,122 @@ AMH_DEV void k_actors(const BatchDev& B, u32 d) {
 // K4  change metadata rows in lock-step — doc_change_columns.rs:183-270, deps.rs:45-102.
 //     Thread per document.
 // ------------------------------------------------------------------------------------------
-AMH_DEV void k_decode_chg(const BatchDev& B, u32 d) {
+// The eight change-metadata columns are decoded by a thread each (index = column * n_docs + document: the lanes of a
+// wave run the same decoder over 64 documents), every thread walking its own run-length stream from the start; what a
+// column cannot say on its own (a change's place among the dependency indexes, levels, ordering) is left to
+// k_decode_chg, one thread per document, which reads the decoded arrays.  The reference reads the columns change by
+// change and stops at the first error (doc_change_columns.rs:196-270): every column records the first change (for the
+// dependency indexes: the first entry) it cannot deliver, and k_decode_chg fails the document where the reference's
+// loop would have met the earliest of them.
+#define CD_COLS 8u   // 0 actor, 1 seq, 2 max op, 3 time, 4 message, 5 deps num, 6 deps index, 7 extra
+AMH_DEV void k_decode_chg_cols(const BatchDev& B, u32 idx) {
+  const u32 col = idx / B.n_docs, d = idx % B.n_docs;
+  u32* err = B.cd_err + (u64)d * CD_COLS + col;
+  u32* code = B.cd_code + (u64)d * CD_COLS + col;
+  u32* none = B.cd_none + (u64)d * CD_COLS + col;
+  *err = AMH_NULL32; *code = AMH_E_READ_CHANGE; *none = 0;
   if (B.status[d]) return;
   const DocDesc& D = B.desc[d];
   const DocCounts& C = B.cnt[d];
   if (D.chunk_len == 0) return;
   const u8* p = B.arena + D.chunk_off;
-  RleDec actors, dnum, msg, emeta;
-  DeltaDec seq, maxop, time, didx;
-  rle_init(actors, p, D.ccol[CC_ACTOR].off, D.ccol[CC_ACTOR].len);
-  rle_init(dnum, p, D.ccol[CC_DEPS_NUM].off, D.ccol[CC_DEPS_NUM].len);
-  rle_init(msg, p, D.ccol[CC_MESSAGE].off, D.ccol[CC_MESSAGE].len);
-  rle_init(emeta, p, D.ccol[CC_EXTRA_META].off, D.ccol[CC_EXTRA_META].len);
-  delta_init(seq, p, D.ccol[CC_SEQ].off, D.ccol[CC_SEQ].len);
-  delta_init(maxop, p, D.ccol[CC_MAX_OP].off, D.ccol[CC_MAX_OP].len);
-  delta_init(time, p, D.ccol[CC_TIME].off, D.ccol[CC_TIME].len);
-  delta_init(didx, p, D.ccol[CC_DEPS_IDX].off, D.ccol[CC_DEPS_IDX].len);
-  bool has_msg = D.ccol[CC_MESSAGE].len != 0;
+  const u32 cb = B.chg_base[d], nc = C.n_chg;
+  u64 v; u32 aux; bool isnull; i64 sv;
+  if (col == 0) {
+    RleDec r; rle_init(r, p, D.ccol[CC_ACTOR].off, D.ccol[CC_ACTOR].len);
+    for (u32 i = 0; i < nc; i++) {
+      if (rle_next<0>(r, v, aux, isnull) != 0 || isnull) { *err = i; return; }
+      if (v >= D.n_actors) { *err = i; *code = AMH_E_COLLECT_MISSING_ACTOR; return; }  // change_collector.rs:185-192
+      B.c_actor[cb + i] = (u32)v;
+    }
+  } else if (col == 1 || col == 2 || col == 3) {
+    const int cc = col == 1 ? CC_SEQ : (col == 2 ? CC_MAX_OP : CC_TIME);
+    DeltaDec r; delta_init(r, p, D.ccol[cc].off, D.ccol[cc].len);
+    for (u32 i = 0; i < nc; i++) {
+      if (delta_next(r, sv, isnull) != 0 || isnull || (col != 3 && sv < 0)) { *err = i; return; }
+      if (col == 1) B.c_seq[cb + i] = (u64)sv; else if (col == 2) B.c_max_op[cb + i] = (u64)sv; else B.c_time[cb + i] = sv;
+    }
+    *none = delta_next(r, sv, isnull) == 1;
+  } else if (col == 4) {
+    const bool has_msg = D.ccol[CC_MESSAGE].len != 0;
+    RleDec r; rle_init(r, p, D.ccol[CC_MESSAGE].off, D.ccol[CC_MESSAGE].len);
+    for (u32 i = 0; i < nc; i++) {
+      B.c_msg_off[cb + i] = 0;
+      B.c_msg_len[cb + i] = AMH_NULL32;
+      if (has_msg) {
+        int rc = rle_next<2>(r, v, aux, isnull);
+        if (rc < 0) { *err = i; return; }
+        if (rc == 0 && !isnull) { B.c_msg_off[cb + i] = (u32)v; B.c_msg_len[cb + i] = aux; }
+      }
+    }
+  } else if (col == 5) {
+    RleDec r; rle_init(r, p, D.ccol[CC_DEPS_NUM].off, D.ccol[CC_DEPS_NUM].len);
+    for (u32 i = 0; i < nc; i++) {
+      if (rle_next<0>(r, v, aux, isnull) != 0 || isnull) { *err = i; return; }
+      B.c_ndeps[cb + i] = v > 0xFFFFFFFFull ? AMH_NULL32 : (u32)v;   // (more than the column can hold either way)
+    }
+    *none = rle_next<0>(r, v, aux, isnull) == 1;
+  } else if (col == 6) {
+    DeltaDec r; delta_init(r, p, D.ccol[CC_DEPS_IDX].off, D.ccol[CC_DEPS_IDX].len);
+    const u32 db = B.dep_base[d];
+    for (u32 e = 0; e < C.n_deps; e++) {   // err = the first ENTRY that does not read
+      if (delta_next(r, sv, isnull) != 0 || isnull || sv < 0) { *err = e; return; }
+      B.dep_idx[db + e] = sv > 0xFFFFFFFFll ? AMH_NULL32 : (u32)sv;
+    }
+  } else {
+    // extra bytes: must be a Bytes value when present (doc_change_columns.rs:256-270)
+    RleDec r; rle_init(r, p, D.ccol[CC_EXTRA_META].off, D.ccol[CC_EXTRA_META].len);
+    u64 extra_off = 0;
+    for (u32 i = 0; i < nc; i++) {
+      B.c_extra_off[cb + i] = 0;
+      B.c_extra_len[cb + i] = 0;
+      int rc = rle_next<0>(r, v, aux, isnull);
+      if (rc < 0) { *err = i; return; }
+      if (rc == 0) {
+        if (isnull || (v & 15) != 7) { *err = i; return; }
+        u64 el = v >> 4;
+        if (el > D.ccol[CC_EXTRA_RAW].len || extra_off > D.ccol[CC_EXTRA_RAW].len - el) { *err = i; return; }
+        B.c_extra_off[cb + i] = (u32)(D.ccol[CC_EXTRA_RAW].off + extra_off);
+        B.c_extra_len[cb + i] = (u32)el;
+        extra_off += el;
+      }
+    }
+  }
+}
+AMH_DEV void k_decode_chg(const BatchDev& B, u32 d) {
+  if (B.status[d]) return;
+  const DocDesc& D = B.desc[d];
+  const DocCounts& C = B.cnt[d];
+  if (D.chunk_len == 0) return;
   u32 cb = B.chg_base[d], db = B.dep_base[d];
   u32 ndep = 0, max_lvl = 0;
-  u64 extra_off = 0;
-  u64 v; u32 aux; bool isnull; i64 sv;
+  u32 err[CD_COLS];
+  for (u32 k = 0; k < CD_COLS; k++) err[k] = B.cd_err[(u64)d * CD_COLS + k];
+  const i32* code = (const i32*)(B.cd_code + (u64)d * CD_COLS);
   for (u32 i = 0; i < C.n_chg; i++) {
     u32 c = cb + i;
-    if (rle_next<0>(actors, v, aux, isnull) != 0 || isnull) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
-    if (v >= D.n_actors) { amh_fail(B, d, AMH_E_COLLECT_MISSING_ACTOR); return; }  // change_collector.rs:185-192
-    B.c_actor[c] = (u32)v;
-    if (delta_next(seq, sv, isnull) != 0 || isnull || sv < 0) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
-    B.c_seq[c] = (u64)sv;
-    if (delta_next(maxop, sv, isnull) != 0 || isnull || sv < 0) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
-    B.c_max_op[c] = (u64)sv;
-    if (delta_next(time, sv, isnull) != 0 || isnull) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
-    B.c_time[c] = sv;
-    B.c_msg_off[c] = 0;
-    B.c_msg_len[c] = AMH_NULL32;
-    if (has_msg) {
-      int rc = rle_next<2>(msg, v, aux, isnull);
-      if (rc < 0) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
-      if (rc == 0 && !isnull) { B.c_msg_off[c] = (u32)v; B.c_msg_len[c] = aux; }
-    }
-    if (rle_next<0>(dnum, v, aux, isnull) != 0 || isnull) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
-    B.c_ndeps[c] = (u32)v;
+    for (u32 k = 0; k < 6; k++) if (err[k] == i) { amh_fail(B, d, code[k]); return; }   // the columns in the order the reference reads them
+    const u32 v = B.c_ndeps[c];
     B.c_dep_base[c] = db + ndep;
     u32 lvl = 0;
-    for (u64 k = 0; k < v; k++) {
-      if (ndep >= C.n_deps) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
-      if (delta_next(didx, sv, isnull) != 0 || isnull || sv < 0) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
-      if ((u64)sv >= i) { amh_fail(B, d, AMH_E_MISSING_CHANGE); return; }  // change_collector.rs:163-177
-      B.dep_idx[db + ndep] = (u32)sv;
-      B.c_is_dep[cb + (u32)sv] = 1;
-      u32 dl = B.c_level[cb + (u32)sv] + 1;
+    for (u32 k = 0; k < v; k++) {
+      if (ndep >= C.n_deps || ndep == err[6]) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+      const u32 sv = B.dep_idx[db + ndep];
+      if (sv >= i) { amh_fail(B, d, AMH_E_MISSING_CHANGE); return; }  // change_collector.rs:163-177
+      B.c_is_dep[cb + sv] = 1;
+      u32 dl = B.c_level[cb + sv] + 1;
       if (dl > lvl) lvl = dl;
       ndep++;
     }
     B.c_level[c] = lvl;
     if (lvl > max_lvl) max_lvl = lvl;
-    // extra bytes: must be a Bytes value when present (doc_change_columns.rs:256-270)
-    B.c_extra_off[c] = 0;
-    B.c_extra_len[c] = 0;
-    int rc = rle_next<0>(emeta, v, aux, isnull);
-    if (rc < 0) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
-    if (rc == 0) {
-      if (isnull || (v & 15) != 7) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
-      u64 el = v >> 4;
-      if (el > D.ccol[CC_EXTRA_RAW].len || extra_off > D.ccol[CC_EXTRA_RAW].len - el) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
-      B.c_extra_off[c] = (u32)(D.ccol[CC_EXTRA_RAW].off + extra_off);
-      B.c_extra_len[c] = (u32)el;
-      extra_off += el;
-    }
+    if (err[7] == i) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
   }
   // termination quirk (doc_change_columns.rs:196-207, 243-253): the actor column ran out or produced
   // a null; the row set is complete only if at least one other column is exhausted as well
   {
-    bool s_none = delta_next(seq, sv, isnull) == 1;
-    bool m_none = delta_next(maxop, sv, isnull) == 1;
-    bool t_none = delta_next(time, sv, isnull) == 1;
-    bool d_none = rle_next<0>(dnum, v, aux, isnull) == 1;
-    if (!(s_none || m_none || t_none || d_none)) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
+    const u32* none = B.cd_none + (u64)d * CD_COLS;
+    if (!(none[1] || none[2] || none[3] || none[5])) { amh_fail(B, d, AMH_E_READ_CHANGE); return; }
   }
   B.doc_level[d] = max_lvl;
   amh_atomic_max(B.max_level, max_lvl);
