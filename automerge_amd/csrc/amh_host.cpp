@@ -2466,10 +2466,10 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   ap.n_chunks = NCH;
   pt.mark("apply: stage copy");
   // what comes back per chunk lands in pinned memory (pageable copies run at a fraction of the link's rate)
-  PinSpan<i32> u_status; PinSpan<ChgHdr> hdr; PinSpan<DocCounts> u_cnt; PinSpan<u8> u_hash; PinSpan<u32> u_row_base, h_head_len, h_head_off;
+  PinSpan<i32> u_status, u_status2; PinSpan<ChgHdr> hdr; PinSpan<DocCounts> u_cnt; PinSpan<u8> u_hash; PinSpan<u32> u_row_base, h_head_len, h_head_off;
   {
     auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };
-    const size_t need = al((size_t)NCH * sizeof(i32)) + al((size_t)NCH * sizeof(ChgHdr)) + al((size_t)NCH * sizeof(DocCounts)) + al((size_t)NCH * 32 + 32) + 3 * al(((size_t)NCH + 1) * sizeof(u32)) + 64;
+    const size_t need = 2 * al((size_t)NCH * sizeof(i32)) + al((size_t)NCH * sizeof(ChgHdr)) + al((size_t)NCH * sizeof(DocCounts)) + al((size_t)NCH * 32 + 32) + 3 * al(((size_t)NCH + 1) * sizeof(u32)) + 64;
     if (need > ctx->res_cap) {
       rt_sync(ctx->stream);
       if (ctx->res) rt_host_free(ctx->res);
@@ -2479,6 +2479,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     }
     u8* q = ctx->res;
     u_status.p = (i32*)q; q += al((size_t)NCH * sizeof(i32));
+    u_status2.p = (i32*)q; q += al((size_t)NCH * sizeof(i32));
     hdr.p = (ChgHdr*)q; q += al((size_t)NCH * sizeof(ChgHdr));
     u_cnt.p = (DocCounts*)q; q += al((size_t)NCH * sizeof(DocCounts));
     u_hash.p = q; q += al((size_t)NCH * 32 + 32);
@@ -2591,6 +2592,17 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     U.s_actor = balloc<u32>(hb, NS, &ok); U.s_ctr = balloc<u32>(hb, NS, &ok); U.s_row = balloc<u32>(hb, NS, &ok);
     ap.d_u_chg = balloc<u32>(hb, NR, &ok); ap.d_u_fill = balloc<u32>(hb, NR, &ok);
     if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+    // What the decisions need is there once the chunks are parsed, hashed and counted: it comes back now, and the ops
+    // are decoded and verified (k_ap_verify can still fail a chunk) WHILE the host decides; the decisions are checked
+    // against the final statuses afterwards and made again in the rare case that a chunk failed late.
+    if (!seg_src.empty() && (!rt_d2h(ctx->heads, d_heads, (size_t)heads_total, ctx->stream) || !rt_d2h(h_head_len.data(), d_hl, (size_t)NCH * sizeof(u32), ctx->stream) ||
+                             !rt_d2h(h_head_off.data(), d_ho, (size_t)NCH * sizeof(u32), ctx->stream)))
+      return faild("D2H copy failed");
+    if (!rt_d2h(u_status.data(), U.status, NCH * sizeof(i32), ctx->stream) || !rt_d2h(hdr.data(), ap.d_hdr, NCH * sizeof(ChgHdr), ctx->stream) ||
+        !rt_d2h(u_cnt.data(), U.cnt, NCH * sizeof(DocCounts), ctx->stream) ||
+        !rt_d2h(u_hash.data(), U.doc_hash, (size_t)NCH * 32, ctx->stream) || !rt_d2h(u_row_base.data(), U.row_base, (NCH + 1) * sizeof(u32), ctx->stream) ||
+        !rt_sync(ctx->stream))
+      return faild("device pipeline failed");
     rt_memset(U.r_doc, 0xFF, NR * 4, ctx->stream);
     rt_memset(U.r_key_off, 0, NR * 4, ctx->stream); rt_memset(U.r_key_len, 0xFF, NR * 4, ctx->stream);
     rt_memset(U.r_mark_off, 0, NR * 4, ctx->stream); rt_memset(U.r_mark_len, 0xFF, NR * 4, ctx->stream);
@@ -2602,28 +2614,26 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     rt_memset(U.s_row, 0xFF, NS * 4, ctx->stream);
     launch(ctx, AK_DECODE_OPS, U, NCH * OC_COUNT);
     mg0(MK_AP_VERIFY, tot_rows);
-    if (!seg_src.empty() && (!rt_d2h(ctx->heads, d_heads, (size_t)heads_total, ctx->stream) || !rt_d2h(h_head_len.data(), d_hl, (size_t)NCH * sizeof(u32), ctx->stream) ||
-                             !rt_d2h(h_head_off.data(), d_ho, (size_t)NCH * sizeof(u32), ctx->stream)))
-      return faild("D2H copy failed");
-    if (!rt_d2h(u_status.data(), U.status, NCH * sizeof(i32), ctx->stream) || !rt_d2h(hdr.data(), ap.d_hdr, NCH * sizeof(ChgHdr), ctx->stream) ||
-        !rt_d2h(u_cnt.data(), U.cnt, NCH * sizeof(DocCounts), ctx->stream) ||
-        !rt_d2h(u_hash.data(), U.doc_hash, (size_t)NCH * 32, ctx->stream) || !rt_d2h(u_row_base.data(), U.row_base, (NCH + 1) * sizeof(u32), ctx->stream) ||
-        !rt_sync(ctx->stream))
-      return faild("device pipeline failed");
-    collect_profile(ctx);
     if (!seg_src.empty())   // the heads go to their places in the host's picture of the arena
       host_parallel_for(NCH, [&](u32 u) {
         if (chunks[staged_of[u]].dev && h_head_len[u]) memcpy(h_arena.data() + doc_off[2 * (size_t)u], ctx->heads + h_head_off[u], h_head_len[u]);
       });
   }
-  pt.mark("apply: U decode + verify", &ctx->stream);
+  pt.mark("apply: U parse + count (decode + verify launched)");
   view_thread.join();
   if (!view_ok) { set_error(ctx, std::string(who) + ": D2H copy failed"); return AMH_ERR_DEVICE; }
   pt.mark("apply: wait for dst's host view");
   // ---- host: which changes apply, in which order (automerge.rs:797-858); actors; merged history -----
   MgPlan pl;
-  mg_plan_init(pl, P, DB.n_docs, P, NCH);
   MG_REFS(pl)
+  std::vector<std::vector<u32>> new_queue;
+  std::vector<u8> queue_dirty;
+  bool verify_pending = NCH != 0;
+  for (int pass = 0;; pass++) {
+  pl = MgPlan();
+  mg_plan_init(pl, P, DB.n_docs, P, NCH);
+  results.assign(P, 0);
+  ap.ix_actor.clear(); ap.ix_start.clear(); ap.ix_nops.clear(); ap.ix_row.clear(); ap.amap.clear();
   ap.c_applied.assign((size_t)NCH + 1, 0);
   ap.h_start_op.resize(NCH); ap.h_nops.resize(NCH);
   ap.h_chunk_off.resize(NCH); ap.h_chunk_len.resize(NCH);
@@ -2634,8 +2644,8 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   ap.all_dev = NCH != 0 && n_host_staged == 0 && seg_src.size() == NCH;
   ap.amap_base.assign((size_t)NCH + 1, 0);
   ap.ix_base.assign(P + 1, 0);
-  std::vector<std::vector<u32>> new_queue(P);
-  std::vector<u8> queue_dirty(P, 0);
+  new_queue.assign(P, std::vector<u32>());
+  queue_dirty.assign(P, 0);
   typedef std::pair<const u8*, u32> Bytes;
   auto bcmp = [](Bytes x, Bytes y) { int c = memcmp(x.first, y.first, std::min(x.second, y.second)); return c ? c : (x.second < y.second ? -1 : (x.second > y.second ? 1 : 0)); };
   // per staged chunk: author + other actors as byte ranges of h_arena
@@ -2898,6 +2908,14 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   mapa_base[P] = (u32)map_a.size(); mapb_base[P] = (u32)map_b.size();
   m_actor_base[P] = (u32)m_actor_off.size(); m_chg_base[P] = (u32)mc_from.size();
   ap.ix_base[P] = (u32)ap.ix_actor.size();
+  if (!verify_pending) break;
+  // the ops are decoded and verified by now: the statuses the decisions were made with against the final ones
+  verify_pending = false;
+  if (!rt_d2h(u_status2.data(), ap.U.status, (size_t)NCH * sizeof(i32), ctx->stream) || !rt_sync(ctx->stream)) { set_error(ctx, std::string(who) + ": device pipeline failed"); collect_profile(ctx); return AMH_ERR_DEVICE; }
+  collect_profile(ctx);
+  if (memcmp(u_status.data(), u_status2.data(), (size_t)NCH * sizeof(i32)) == 0) break;
+  memcpy(u_status.data(), u_status2.data(), (size_t)NCH * sizeof(i32));
+  }
   bool queue_fetch_failed = false;
   auto commit_queues = [&]() {
     for (u32 p = 0; p < P; p++) {
