@@ -101,6 +101,8 @@ struct amh_ctx {
   size_t heads_cap = 0;
   u8* res = nullptr;              // pinned: per-chunk results of an apply's decode pass (headers, counts, hashes)
   size_t res_cap = 0;
+  u8* bigc = nullptr;             // pinned: the re-derived change chunks of a large document on their way to the host's SHA-256
+  size_t bigc_cap = 0;
   u8* pin[2] = {nullptr, nullptr};   // pinned staging buffers of amh_stage_batch (double-buffered H2D), kept for the context's life
   rt_event ev_pin[2]{};
   bool profiling = false;
@@ -501,7 +503,14 @@ static bool big_hash_changes(amh_batch* b, u32 d) {
   std::vector<u32> dep_idx(cnt.n_deps + 1);
   if (cnt.n_deps && !rt_d2h(dep_idx.data(), B.dep_idx + db2[0], (size_t)cnt.n_deps * 4, ctx->stream)) return false;
   const size_t lo = out_off[0], hi = out_off[nc];
-  std::vector<u8> bytes(hi - lo + 1), hashes((size_t)nc * 32);
+  if (hi - lo + 1 > ctx->bigc_cap) {
+    if (ctx->bigc) rt_host_free(ctx->bigc);
+    ctx->bigc_cap = (hi - lo + 1) + (hi - lo + 1) / 4;
+    ctx->bigc = (u8*)rt_host_alloc(ctx->bigc_cap);
+    if (!ctx->bigc) { ctx->bigc_cap = 0; return false; }
+  }
+  struct { u8* p; u8* data() const { return p; } } bytes{ctx->bigc};
+  std::vector<u8> hashes((size_t)nc * 32);
   if (!rt_d2h(bytes.data(), B.out_arena + lo, hi - lo, ctx->stream)) return false;
   // changes grouped by level (counting sort; file order inside a level)
   u32 max_lvl = 0;
@@ -523,13 +532,33 @@ static bool big_hash_changes(amh_batch* b, u32 d) {
     amh_host_sha256(out + 8, hdr - 8, out + hdr, body_len[i], h);
     memcpy(out + 4, h, 4);
   };
-  for (u32 l = 0; l <= max_lvl; l++) {
-    const u32 a = start[l], e = start[l + 1];
-    if (e - a == 1) one(order[a]);
-    else host_parallel_for(e - a, [&](u32 k) { one(order[a + k]); }, 2, 1);
+  // One set of threads for all levels: a level's changes are dealt out by a counter, and a thread goes on to the next
+  // level once every change of this one is hashed (the hashes of a level are the dependencies of later ones).
+  {
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
+    if (const char* e = getenv("OMP_NUM_THREADS")) { int v = atoi(e); if (v > 0) nt = std::min<unsigned>(nt, (unsigned)v); }
+    if (nc < 4) nt = 1;
+    std::atomic<u32> next{0}, done{0};
+    auto work = [&]() {
+      for (u32 l = 0; l <= max_lvl; l++) {
+        const u32 e = start[l + 1];
+        for (;;) {
+          u32 k = next.load(std::memory_order_relaxed);
+          if (k >= e) break;
+          if (!next.compare_exchange_weak(k, k + 1)) continue;
+          one(order[k]);
+          done.fetch_add(1, std::memory_order_release);
+        }
+        while (done.load(std::memory_order_acquire) < e) std::this_thread::yield();
+      }
+    };
+    std::vector<std::thread> ts;
+    for (unsigned t = 1; t < nt; t++) ts.emplace_back(work);
+    work();
+    for (auto& th : ts) th.join();
   }
-  return rt_h2d(B.out_arena + lo, bytes.data(), hi - lo, ctx->stream) && rt_h2d(B.c_hash + (size_t)cb * 32, hashes.data(), (size_t)nc * 32, ctx->stream) &&
-         rt_sync(ctx->stream);
+  // the hashes go back; the dependency hashes and checksums are written into the device's chunks by k_chg_patch
+  return rt_h2d(B.c_hash + (size_t)cb * 32, hashes.data(), (size_t)nc * 32, ctx->stream) && rt_sync(ctx->stream);
 }
 
 // merge: the change chunks of a merged document are those of its sources (already verified when they were loaded /
@@ -556,6 +585,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   st->refs++;
   BatchDev& B = b->B;
   u32 n = st->n_docs;
+  PhaseTimer pt("load");
   B.n_docs = n;
   B.check_heads = opts ? (opts->verify_heads != 0) : 1;
   B.max_doc_rows = ctx->max_doc_rows;
@@ -724,6 +754,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   }
 #endif
   launch(ctx, AK_DECODE_OPS, B, n * OC_COUNT);
+  pt.mark("load: parse .. decode launched");
   return load_tail(ctx, b, big, opts, trailing, false, nullptr);
 }
 
@@ -736,6 +767,7 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
   const u32 n = B.n_docs;
   const size_t NC = (size_t)B.tot_chg + 2;
   bool ok = true;
+  PhaseTimer pt("load tail");
   auto fail = [&](const std::string& m) -> amh_batch* {
     big.join();
     set_error(ctx, m);
@@ -871,8 +903,10 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
     launch(ctx, AK_CHG_HASH, B, lvl_start[lvl + 1] - lvl_start[lvl]);
   }
   if (lvl_start[AMH_LEVEL_CAP_HOST + 1] > lvl_start[AMH_LEVEL_CAP_HOST]) launch(ctx, AK_CHG_HASH_SEQ, B, n);
+  pt.mark("tail: rows .. change hashes launched");
   if (B.sha_host_min) {   // large documents: their changes are hashed by the host
     big.join();
+    pt.mark("tail: wait for the host's document checksums");
     for (size_t k = 0; k < big.docs.size(); k++) {
       if (big.chunk_len[k] < AMH_HOST_SHA_MIN) continue;
       i32 stt = 0;
@@ -880,6 +914,8 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
       if (stt == 0 && !big_hash_changes(b, big.docs[k])) return fail(std::string("device pipeline failed: ") + rt_last_error());
     }
   }
+  if (B.sha_host_min && !big.docs.empty()) launch(ctx, AK_CHG_PATCH, B, B.tot_chg);
+  pt.mark("tail: host change hashes");
   if (expect_hash) { B.expect_hash = expect_hash; launch(ctx, AK_VERIFY_HASH, B, B.tot_chg); }
   }
   launch(ctx, AK_HEADS, B, n);
@@ -888,6 +924,7 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
   b->fail_line.resize(n);
   if (!rt_d2h(b->status.data(), B.status, n * sizeof(i32), ctx->stream) || !rt_d2h(b->fail_line.data(), B.fail_line, n * sizeof(u32), ctx->stream) || !rt_sync(ctx->stream))
     return fail(std::string("device pipeline failed: ") + rt_last_error());
+  pt.mark("tail: heads, statuses back");
   // the host-side checksums of the large chunks: a mismatch outranks whatever the pipeline made of the damaged bytes
   big.join();
   for (size_t k = 0; k < big.docs.size(); k++) {
@@ -3404,6 +3441,7 @@ extern "C" void amh_ctx_destroy(amh_ctx* ctx) {
   if (ctx->stage) rt_host_free(ctx->stage);
   if (ctx->heads) rt_host_free(ctx->heads);
   if (ctx->res) rt_host_free(ctx->res);
+  if (ctx->bigc) rt_host_free(ctx->bigc);
 #ifndef AMH_EMU
   if (ctx->comm) { amh_comm_close(ctx->comm); ctx->comm = nullptr; }
 #endif

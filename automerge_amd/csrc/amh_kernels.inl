@@ -1809,6 +1809,29 @@ AMH_DEV u32 chg_level_bucket(const BatchDev& B, u32 c) {
   if (B.sha_host_min && B.desc[d].chunk_len >= B.sha_host_min) return AMH_LEVEL_CAP;   // hashed by the host (amh_host.cpp, big_hash_changes)
   return B.c_level[c];
 }
+// changes hashed by the host (big_hash_changes: documents of AMH_HOST_SHA_MIN bytes and more): the host sends the hashes
+// back, the dependency hashes and the checksum go into the chunks here.  Thread per change.
+AMH_DEV void k_chg_patch(const BatchDev& B, u32 c) {
+  const u32 d = B.c_doc[c];
+  if (B.status[d] || !B.sha_host_min || B.desc[d].chunk_len < B.sha_host_min) return;
+  const u32 cb = B.chg_base[d];
+  u8* out = B.out_arena + B.c_out_off[c];
+  const u32 hdr = B.c_out_len[c] - B.c_body_len[c], nd = B.c_ndeps[c];
+  u8* deps = out + hdr + uleb_size(nd);
+  for (u32 k = 0; k < nd; k++) {
+    Hash4 h = hash4_load(B.c_hash + (u64)(cb + B.dep_idx[B.c_dep_base[c] + k]) * 32);
+    u32 j = k;
+    while (j > 0) {
+      Hash4 prev = hash4_load(deps + 32 * (j - 1));
+      if (!hash4_greater(prev, h)) break;
+      hash4_store(deps + 32 * j, prev);
+      j--;
+    }
+    hash4_store(deps + 32 * j, h);
+  }
+  const u8* h = B.c_hash + (u64)c * 32;
+  out[4] = h[0]; out[5] = h[1]; out[6] = h[2]; out[7] = h[3];
+}
 AMH_DEV void k_chg_hash(const BatchDev& B, u32 i) {   // i-th change of the current level (lvl_order is grouped by level)
   u32 c = B.lvl_order[B.cur_level + i];
   chg_hash_one(B, c, B.chg_base[B.c_doc[c]]);
