@@ -3224,7 +3224,20 @@ extern "C" int amh_save_batch(amh_ctx* ctx, const amh_batch* bc, const amh_save_
   launch(ctx, AK_SAVE_STORE, B, n * 25);
   save_big_launch(ctx, B, 1);
   launch(ctx, AK_SAVE_FINISH, B, n);
-  std::vector<u8> host((size_t)total);
+  // the saved bytes come back through the context's pinned area when they fit a modest one (pageable copies run at a
+  // fraction of the link's rate), else into pageable memory
+  std::vector<u8> host_pageable;
+  struct { u8* p; u8* data() const { return p; } } host{nullptr};
+  if ((size_t)total + 1 <= ((size_t)256 << 20)) {
+    if ((size_t)total + 1 > ctx->bigc_cap) {
+      if (ctx->bigc) rt_host_free(ctx->bigc);
+      ctx->bigc_cap = ((size_t)total + 1) + ((size_t)total + 1) / 4;
+      ctx->bigc = (u8*)rt_host_alloc(ctx->bigc_cap);
+      if (!ctx->bigc) ctx->bigc_cap = 0;
+    }
+    host.p = ctx->bigc;
+  }
+  if (!host.p) { host_pageable.resize((size_t)total + 1); host.p = host_pageable.data(); }
   std::vector<u32> off(n + 1), body(n);
   std::vector<i32> st(n);
   if (!rt_d2h(host.data(), B.sv_out, total, ctx->stream) || !rt_d2h(off.data(), B.sv_off, (n + 1) * sizeof(u32), ctx->stream) ||

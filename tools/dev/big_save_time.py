@@ -16,4 +16,4 @@ os.environ["AMH_BIGSAVE_ROWS"] = "4000000000"
 t = time.time(); ref = b.save_all(deflate=False); dt = time.time() - t
 print("one wave per column group: %.1f ms, same bytes: %s" % (dt * 1e3, ref[0] == out[0]))
 b2 = e.load_batch([out[0]])
-print("reload ok:", b2.status(0) == 0, b2.get_heads(0) == b.get_heads(0))
+print("reload ok:", b2.status(0)[0] == 0, b2.get_heads(0) == b.get_heads(0))
