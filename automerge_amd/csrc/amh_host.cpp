@@ -806,6 +806,10 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
   rt_memset(B.t_pred_cnt, 0, ((size_t)T + 2) * 4, ctx->stream);
   rt_memset(B.t_pred_fill, 0, ((size_t)T + 2) * 4, ctx->stream);
   launch(ctx, AK_SUCC_LINK, B, B.tot_succ);
+  B.a_tab_base = balloc<u32>(b, (size_t)B.tot_actors + 2, &ok); B.a_tab = balloc<u32>(b, (size_t)B.tot_chg + 2, &ok);
+  if (!ok) return fail("device out of memory");
+  launch(ctx, AK_ATAB_BASE, B, n);
+  launch(ctx, AK_ATAB_FILL, B, B.tot_chg);
   launch(ctx, AK_BUCKET, B, T);
   launch(ctx, AK_CHG_FINISH, B, B.tot_chg);
   // ops grouped by change

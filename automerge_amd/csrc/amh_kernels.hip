@@ -42,6 +42,8 @@ AMH_GLOBAL(k_chg_init)
 AMH_GLOBAL(k_decode_chg)
 AMH_GLOBAL(k_decode_chg_cols)
 AMH_GLOBAL(k_chg_patch)
+AMH_GLOBAL(k_atab_base)
+AMH_GLOBAL(k_atab_fill)
 AMH_GLOBAL(k_decode_ops)
 AMH_GLOBAL(k_rows)
 AMH_GLOBAL(k_obj_order)
@@ -817,7 +819,7 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
 #define L(id, name) case id: hipLaunchKernelGGL(g_##name, grid, block, 0, s, B, n); break;
   switch (k) {
     L(AK_PARSE, k_parse) L(AK_SHA_DOC, k_sha_doc) L(AK_COUNT, k_count) L(AK_EXTRACT, k_extract)
-    L(AK_ACTORS, k_actors) L(AK_CHG_INIT, k_chg_init) L(AK_DECODE_CHG, k_decode_chg) L(AK_DECODE_CHG_COLS, k_decode_chg_cols) L(AK_CHG_PATCH, k_chg_patch)
+    L(AK_ACTORS, k_actors) L(AK_CHG_INIT, k_chg_init) L(AK_DECODE_CHG, k_decode_chg) L(AK_DECODE_CHG_COLS, k_decode_chg_cols) L(AK_CHG_PATCH, k_chg_patch) L(AK_ATAB_BASE, k_atab_base) L(AK_ATAB_FILL, k_atab_fill)
     L(AK_DECODE_OPS, k_decode_ops) L(AK_ROWS, k_rows) L(AK_OBJ_ORDER, k_obj_order) L(AK_SUCC, k_succ)
     L(AK_BUCKET, k_bucket) L(AK_CHG_FINISH, k_chg_finish) L(AK_PLACE, k_place) L(AK_PRED_SLOT_CNT, k_pred_slot_cnt) L(AK_PRED_SLOT_BASE, k_pred_slot_base) L(AK_PRED_FILL, k_pred_fill)
     L(AK_PRED_SORT, k_pred_sort) L(AK_ACTOR_MARK, k_actor_mark) L(AK_ACTOR_RANK, k_actor_rank) L(AK_CHANGE_VIEW, k_change_view)

@@ -1011,6 +1011,25 @@ AMH_DEV u32 op_key_row(const BatchDev& B, u32 t) { return t < B.tot_rows ? t : B
 //     Also checks the delete's first pred is a Put/Make (reconstruct_document.rs:270, 317-320).
 //     Thread per op t.
 // ------------------------------------------------------------------------------------------
+// The changes of every actor as an array (a_tab, in the document's stretch of the change index space: an actor's
+// changes at a_tab_base[actor], the change with sequence number s at + s - 1; the chains were checked to run 1, 2, ...
+// with non-decreasing max_op), so that k_bucket finds an op's change by binary search instead of walking the actor's
+// chain: a document typed one keystroke per change has as many changes as ops.  Thread per document / per change.
+AMH_DEV void k_atab_base(const BatchDev& B, u32 d) {
+  if (B.status[d]) return;
+  const u32 ab = B.actor_base[d], na = B.desc[d].n_actors;
+  u32 run = B.chg_base[d];
+  for (u32 a = 0; a < na; a++) {
+    B.a_tab_base[ab + a] = run;
+    const u32 last = B.a_last_chg[ab + a];
+    if (last != AMH_EMPTY32) run += (u32)B.c_seq[last];
+  }
+}
+AMH_DEV void k_atab_fill(const BatchDev& B, u32 c) {
+  const u32 d = B.c_doc[c];
+  if (d >= B.n_docs || B.status[d]) return;
+  B.a_tab[B.a_tab_base[B.actor_base[d] + B.c_actor[c]] + (u32)B.c_seq[c] - 1] = c;
+}
 AMH_DEV void k_bucket(const BatchDev& B, u32 t) {
   B.t_chg[t] = AMH_EMPTY32;
   if (op_is_del(B, t) && B.dt_key[t - B.tot_rows] == 0) return;
@@ -1023,10 +1042,17 @@ AMH_DEV void k_bucket(const BatchDev& B, u32 t) {
   }
   u32 ctr, actor;
   op_id(B, t, ctr, actor);
-  u32 c = B.a_first_chg[B.actor_base[d] + actor];
-  if (c == AMH_EMPTY32) { amh_fail(B, d, AMH_E_COLLECT_MISSING_ACTOR); return; }
-  while (c != AMH_EMPTY32 && B.c_max_op[c] < ctr) c = B.c_next_same_actor[c];
-  if (c == AMH_EMPTY32) { amh_fail(B, d, AMH_E_MISSING_CHANGE); return; }
+  const u32 a = B.actor_base[d] + actor;
+  const u32 last = B.a_last_chg[a];
+  if (last == AMH_EMPTY32) { amh_fail(B, d, AMH_E_COLLECT_MISSING_ACTOR); return; }
+  const u32* tab = B.a_tab + B.a_tab_base[a];
+  u32 lo = 0, hi = (u32)B.c_seq[last];   // first change of the actor with max_op >= ctr
+  while (lo < hi) {
+    const u32 mid = lo + (hi - lo) / 2;
+    if (B.c_max_op[tab[mid]] < ctr) lo = mid + 1; else hi = mid;
+  }
+  if (lo == (u32)B.c_seq[last]) { amh_fail(B, d, AMH_E_MISSING_CHANGE); return; }
+  const u32 c = tab[lo];
   B.t_chg[t] = c;
   amh_atomic_inc_grouped(B.c_nops, c);
 }

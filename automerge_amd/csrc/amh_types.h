@@ -87,6 +87,7 @@ struct BatchDev {
   // the note into the document's status, ahead of whatever the count made of the damaged bytes — the order the
   // reference checks in — and before anything is sized or decoded.  Null = the kernel fails the document itself
   // (apply's change chunks).
+  u32 *a_tab_base, *a_tab;            // [tot_actors + 1] / [tot_chg + 1] an actor's changes by sequence number (k_atab_*)
   u32 *cd_err, *cd_code, *cd_none;   // [n_docs * 8] change-metadata columns (k_decode_chg_cols): first change / entry that does not read, its error, "column exhausted behind the last change"
   const i32* sha_gate;
   u32 sha_host_min;        // != 0: chunks of at least this many bytes are hashed by the host (one message is a serial chain: a lone lane is ~50x slower than a core)

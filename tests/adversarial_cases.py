@@ -99,7 +99,18 @@ def typed_run(n=5000, base=100):
     return [c0, c1]
 
 
-CASES = {"deep_nesting": deep_nesting, "wide_overwrite": wide_overwrite, "overwritten_key": overwritten_key, "counter_increments": counter_increments, "new_map_keys": new_map_keys,
+def keystrokes(n=20000):
+    """a text typed one character per change by one actor: as many changes as ops, one dependency chain n deep"""
+    a0 = actor_id(0)
+    c, h = build_change(a0, 1, 1, [], [op(MAKE_TEXT, key="t")])
+    chunks = [c]
+    for i in range(n):
+        c, h = build_change(a0, 2 + i, 2 + i, [h], [op(SET, obj=(1, 0), elem=(0, None) if i == 0 else (1 + i, 0), insert=True, value=v_str(chr(97 + i % 26)))])
+        chunks.append(c)
+    return chunks
+
+
+CASES = {"keystrokes": keystrokes, "deep_nesting": deep_nesting, "wide_overwrite": wide_overwrite, "overwritten_key": overwritten_key, "counter_increments": counter_increments, "new_map_keys": new_map_keys,
          "head_siblings": head_siblings, "siblings_behind_one_element": siblings_behind_one_element, "typed_run": typed_run}
 
 

@@ -305,7 +305,7 @@ def test_repeated_save_and_summaries_do_not_grow_the_batch(emu):
 
 
 @pytest.mark.parametrize("name,args", [("overwritten_key", (300,)), ("new_map_keys", (300,)), ("head_siblings", (3, 50)), ("typed_run", (300, 20)),
-                                       ("siblings_behind_one_element", (3, 50)), ("counter_increments", (200,)), ("wide_overwrite", (120, 3)), ("deep_nesting", (600,))])
+                                       ("siblings_behind_one_element", (3, 50)), ("counter_increments", (200,)), ("wide_overwrite", (120, 3)), ("deep_nesting", (600,)), ("keystrokes", (300,))])
 def test_adversarial_shapes_small(emu, name, args):
     """the shapes of tests/test_gpu_adversarial.py at sizes the thread-by-thread emulation runs quickly"""
     import adversarial_cases as adv

@@ -25,6 +25,7 @@ def engine():
     ("siblings_behind_one_element", (8, 1250)), # 10k children of one element that arrives in the same call
     ("counter_increments", (20000,)),           # one op gaining 20k successors
     ("wide_overwrite", (3000, 4)),              # one op with 3k preds
+    ("keystrokes", (20000,)),                   # one change per character: 20k changes of one actor, a dependency chain 20k deep
     ("deep_nesting", (600,)),                   # maps nested 600 deep (hydrate walks with an explicit stack)
 ])
 def test_adversarial_shape(engine, name, args):
