@@ -29,6 +29,7 @@
 #define AMH_BIGCOL_HOST (32u << 10)   // = AMH_BIGCOL / AMH_SEG of amh_segdec.inl
 #define AMH_SEG_HOST 4096u
 #define AMH_LEVEL_CAP_HOST 48u   // = AMH_LEVEL_CAP of amh_kernels.inl
+#define AMH_HOST_CHAIN_MIN 2048u
 
 static thread_local std::string g_last_error;
 
@@ -538,6 +539,7 @@ static bool big_hash_changes(amh_batch* b, u32 d) {
     unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
     if (const char* e = getenv("OMP_NUM_THREADS")) { int v = atoi(e); if (v > 0) nt = std::min<unsigned>(nt, (unsigned)v); }
     if (nc < 4) nt = 1;
+    nt = std::max(1u, std::min<unsigned>(nt, nc / (max_lvl + 1)));   // a chain: one thread (a level's hand-over costs more than its one hash)
     std::atomic<u32> next{0}, done{0};
     auto work = [&]() {
       for (u32 l = 0; l <= max_lvl; l++) {
@@ -898,6 +900,9 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
   B.lvl_start = balloc<u32>(b, AMH_LEVEL_CAP_HOST + 4, &ok);
   u32* lvl_tmp = balloc<u32>(b, amh_level_sort_tmp_words(B.tot_chg), &ok);
   if (!ok) return fail("device out of memory");
+#ifndef AMH_EMU
+  B.host_chain_min = AMH_HOST_CHAIN_MIN;
+#endif
   amh_level_sort(B, lvl_tmp, (void*)ctx->stream);
   u32 lvl_start[AMH_LEVEL_CAP_HOST + 2] = {0};
   if (!rt_d2h(lvl_start, B.lvl_start, sizeof(lvl_start), ctx->stream)) return fail("device pipeline failed");
@@ -918,7 +923,25 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
       if (stt == 0 && !big_hash_changes(b, big.docs[k])) return fail(std::string("device pipeline failed: ") + rt_last_error());
     }
   }
-  if (B.sha_host_min && !big.docs.empty()) launch(ctx, AK_CHG_PATCH, B, B.tot_chg);
+  bool chain_docs = false;
+  if (B.host_chain_min && lvl_start[AMH_LEVEL_CAP_HOST + 1] > lvl_start[AMH_LEVEL_CAP_HOST]) {
+    // documents with a long chain of dependency levels (a text typed one change per keystroke): the host walks the chain
+    std::vector<u32> lvl(n);
+    std::vector<DocCounts> cn(n);
+    std::vector<i32> stt(n);
+    if (!rt_d2h(lvl.data(), B.doc_level, (size_t)n * sizeof(u32), ctx->stream) || !rt_d2h(cn.data(), B.cnt, (size_t)n * sizeof(DocCounts), ctx->stream) ||
+        !rt_d2h(stt.data(), B.status, (size_t)n * sizeof(i32), ctx->stream))
+      return fail("device pipeline failed");
+    for (u32 d = 0; d < n; d++) {
+      if (stt[d] || lvl[d] < AMH_LEVEL_CAP_HOST || cn[d].n_chg < B.host_chain_min) continue;
+      bool done_above = false;   // a large chunk: hashed in the loop above already
+      if (B.sha_host_min) for (size_t k = 0; k < big.docs.size(); k++) done_above = done_above || (big.docs[k] == d && big.chunk_len[k] >= AMH_HOST_SHA_MIN);
+      if (done_above) continue;
+      chain_docs = true;
+      if (!big_hash_changes(b, d)) return fail(std::string("device pipeline failed: ") + rt_last_error());
+    }
+  }
+  if ((B.sha_host_min && !big.docs.empty()) || chain_docs) launch(ctx, AK_CHG_PATCH, B, B.tot_chg);
   pt.mark("tail: host change hashes");
   if (expect_hash) { B.expect_hash = expect_hash; launch(ctx, AK_VERIFY_HASH, B, B.tot_chg); }
   }
@@ -942,6 +965,7 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
     }
   }
   if (!big.docs.empty() && !rt_sync(ctx->stream)) return fail("device pipeline failed");
+  B.host_chain_min = 0;
   B.sha_host_min = 0;   // a property of this load, not of the batch (merge / save run the kernels with settings of their own)
   B.skip_doc_sha = 0;
   collect_profile(ctx);

@@ -1828,18 +1828,23 @@ AMH_DEV void chg_hash_one(const BatchDev& B, u32 c, u32 cb) {
   sha256_contig(out + 8, (u64)(hdr - 8) + body_len, h);
   out[4] = h[0]; out[5] = h[1]; out[6] = h[2]; out[7] = h[3];
 }
+// the changes of document d are hashed by the host (amh_host.cpp, big_hash_changes): a large chunk, or a long chain
+AMH_DEV bool chg_host_hashed(const BatchDev& B, u32 d) {
+  if (B.sha_host_min && B.desc[d].chunk_len >= B.sha_host_min) return true;
+  return B.host_chain_min && B.doc_level[d] >= AMH_LEVEL_CAP && B.cnt[d].n_chg >= B.host_chain_min;
+}
 // bucket of a change in the level sort: its level, or AMH_LEVEL_CAP = "not hashed by k_chg_hash"
 AMH_DEV u32 chg_level_bucket(const BatchDev& B, u32 c) {
   u32 d = B.c_doc[c];
   if (B.status[d] || B.doc_level[d] >= AMH_LEVEL_CAP) return AMH_LEVEL_CAP;
-  if (B.sha_host_min && B.desc[d].chunk_len >= B.sha_host_min) return AMH_LEVEL_CAP;   // hashed by the host (amh_host.cpp, big_hash_changes)
+  if (chg_host_hashed(B, d)) return AMH_LEVEL_CAP;
   return B.c_level[c];
 }
 // changes hashed by the host (big_hash_changes: documents of AMH_HOST_SHA_MIN bytes and more): the host sends the hashes
 // back, the dependency hashes and the checksum go into the chunks here.  Thread per change.
 AMH_DEV void k_chg_patch(const BatchDev& B, u32 c) {
   const u32 d = B.c_doc[c];
-  if (B.status[d] || !B.sha_host_min || B.desc[d].chunk_len < B.sha_host_min) return;
+  if (B.status[d] || !chg_host_hashed(B, d)) return;
   const u32 cb = B.chg_base[d];
   u8* out = B.out_arena + B.c_out_off[c];
   const u32 hdr = B.c_out_len[c] - B.c_body_len[c], nd = B.c_ndeps[c];
@@ -1864,7 +1869,7 @@ AMH_DEV void k_chg_hash(const BatchDev& B, u32 i) {   // i-th change of the curr
 }
 AMH_DEV void k_chg_hash_seq(const BatchDev& B, u32 d) {
   if (B.status[d] || B.doc_level[d] < AMH_LEVEL_CAP) return;
-  if (B.sha_host_min && B.desc[d].chunk_len >= B.sha_host_min) return;
+  if (chg_host_hashed(B, d)) return;
   u32 cb = B.chg_base[d], nchg = B.cnt[d].n_chg;
   for (u32 i = 0; i < nchg; i++) chg_hash_one(B, cb + i, cb);
 }

@@ -90,6 +90,7 @@ struct BatchDev {
   u32 *a_tab_base, *a_tab;            // [tot_actors + 1] / [tot_chg + 1] an actor's changes by sequence number (k_atab_*)
   u32 *cd_err, *cd_code, *cd_none;   // [n_docs * 8] change-metadata columns (k_decode_chg_cols): first change / entry that does not read, its error, "column exhausted behind the last change"
   const i32* sha_gate;
+  u32 host_chain_min;      // != 0: the changes of a document with more dependency levels than the level-parallel hashing handles and at least this many changes are hashed by the host (a chain of hashes is serial: ~8 us per change on a lone lane, ~0.3 us on a core)
   u32 sha_host_min;        // != 0: chunks of at least this many bytes are hashed by the host (one message is a serial chain: a lone lane is ~50x slower than a core)
   u8* sha_bad;
   u32 cur_level;           // start, in lvl_order, of the dependency level hashed by the current k_chg_hash launch
