@@ -1447,15 +1447,18 @@ static bool save_big_prepare(amh_ctx* ctx, amh_batch* b, BatchDev& B, const std:
   range = std::max<u64>(64, range & ~(u64)63);
   if (thr == 0) thr = 1;
   const u32 n = B.n_docs;
-  if (n == 0 || ((u64)B.tot_rows < thr && (u64)B.tot_succ < thr)) return true;
+  const u64 cthr = std::min<u64>(thr, 8192);   // change-metadata columns: documents with this many changes
+  if (n == 0 || ((u64)B.tot_rows < thr && (u64)B.tot_succ < thr && (u64)B.tot_chg < cthr)) return true;
   H.cnt.resize(n);
   if (!rt_d2h(H.cnt.data(), B.cnt, (size_t)n * sizeof(DocCounts), ctx->stream)) return false;
   H.big.assign(n, 0);
   for (u32 d = 0; d < n; d++) {
-    if ((d < status.size() && status[d]) || ((u64)H.cnt[d].n_rows < thr && (u64)H.cnt[d].n_succ < thr)) continue;
-    H.big[d] = 1;
-    for (u32 col = 9; col < 25; col++) {
-      const u64 ncol = (col == 21 || col == 22) ? H.cnt[d].n_succ : H.cnt[d].n_rows;
+    if (d < status.size() && status[d]) continue;
+    const bool ops_big = (u64)H.cnt[d].n_rows >= thr || (u64)H.cnt[d].n_succ >= thr, chg_big = (u64)H.cnt[d].n_chg >= cthr;
+    if (!ops_big && !chg_big) continue;
+    H.big[d] = (ops_big ? 1 : 0) | (chg_big ? 2 : 0);
+    for (u32 col = chg_big ? 0 : 9; col < (ops_big ? 25u : 9u); col++) {
+      const u64 ncol = col < 9 ? (col == 6 ? H.cnt[d].n_deps : H.cnt[d].n_chg) : ((col == 21 || col == 22) ? H.cnt[d].n_succ : H.cnt[d].n_rows);
       const u64 nr = (ncol + range - 1) / range;
       if (nr == 0) continue;
       if (H.j_bc.size() + nr >= 0x7FFFFFFFull) return false;

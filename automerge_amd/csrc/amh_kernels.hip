@@ -501,7 +501,8 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
   const u32 d = blockIdx.x * 64 + lane;
   const bool live = d < B.n_docs && B.status[d] == 0 && B.sv_status[d] == 0;
   const u32 dd = d < B.n_docs ? d : 0;
-  const bool big = B.sv_big && d < B.n_docs && B.sv_big[dd];   // op columns: g_sv_big (their lengths are 0 here, set by g_sv_big_total)
+  const bool big = B.sv_big && d < B.n_docs && (B.sv_big[dd] & 1);    // op columns: g_sv_big (their lengths are 0 here, set by g_sv_big_total)
+  const bool bigc = B.sv_big && d < B.n_docs && (B.sv_big[dd] & 2);   // change-metadata columns: g_sv_big
   const u32 n = (live && !big) ? B.cnt[dd].n_rows : 0, ns = (live && !big) ? B.cnt[dd].n_succ : 0;
   const u8* chunk = B.arena + B.desc[dd].chunk_off;
   u32* cl = B.sv_col_len + (u64)dd * AMH_SV_NCOLS;
@@ -516,7 +517,7 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
   u32 wide = 0;
   const u64 data0 = (STORE && live) ? (u64)B.sv_off[dd] + sv_data_start(B, dd) : 0;
   auto out_ptr = [&](u32 k) -> u8* {   // where column k goes (store pass), null = not written here
-    if (!STORE || !live || cl[k] == 0 || ((wide_in >> k) & 1) || (big && k >= AMH_SV_CHG_COLS)) return (u8*)0;
+    if (!STORE || !live || cl[k] == 0 || ((wide_in >> k) & 1) || (big && k >= AMH_SV_CHG_COLS) || (bigc && k < AMH_SV_CHG_COLS)) return (u8*)0;
     u64 off = data0;
     for (u32 q = 0; q < k; q++) off += cl[q];
     return B.sv_out + off;
@@ -531,7 +532,7 @@ __global__ void __launch_bounds__(64) g_save_lds(BatchDev B) {
   // ---- change metadata, columns 0..8 ------------------------------------------------------------
   if (grp == 0) for (u32 k = 0; k < AMH_SV_CHG_COLS; k++) {
     W w; w_init(w, out_ptr(k));
-    if (live) save_encode_chg_col(B, dd, k, w);
+    if (live && !bigc) save_encode_chg_col(B, dd, k, w);
     done(w, k);
   }
   // ---- object id (columns 9, 10) ---------------------------------------------------------------------

@@ -606,6 +606,47 @@ struct SvMarkSrc {
   }
 };
 
+// change-metadata columns 0..8 (doc_change_columns.rs:87-162; the values save_encode_chg_col feeds its encoders), for
+// documents with thousands of changes (g_sv_big)
+struct SvChgCtx { const BatchDev& B; u32 cb, db, nc; const u32* rank; const u8* chunk; };
+struct SvChgNumSrc {   // which: 0 author (actor rank), 5 number of deps, 7 extra-bytes meta
+  const SvChgCtx& c; u32 which;
+  __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const {
+    isnull = false;
+    v = which == 0 ? c.rank[c.B.c_actor[c.cb + e]] : (which == 5 ? c.B.c_ndeps[c.cb + e] : (((u64)c.B.c_extra_len[c.cb + e] << 4) | 7));
+  }
+};
+struct SvChgDeltaSrc {   // which: 1 seq, 2 max op, 3 time
+  const SvChgCtx& c; u32 which;
+  __device__ __forceinline__ i64 at(u32 e) const { return which == 1 ? (i64)c.B.c_seq[c.cb + e] : (which == 2 ? (i64)c.B.c_max_op[c.cb + e] : c.B.c_time[c.cb + e]); }
+  __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const { isnull = false; v = (u64)(at(e) - (e ? at(e - 1) : 0)); }
+};
+struct SvChgMsgSrc {
+  const SvChgCtx& c;
+  __device__ __forceinline__ ScStr load(u32 e) const {
+    const u32 ml = c.B.c_msg_len[c.cb + e];
+    ScStr s; s.bytes = 0; s.inl = false; s.isnull = ml == AMH_NULL32 || ml == 0; s.len = s.isnull ? 0 : ml;
+    s.p = c.chunk + (s.isnull ? 0 : c.B.c_msg_off[c.cb + e]);
+    return s;
+  }
+};
+struct SvChgDepSrc {   // the flattened dependency indexes, every change's in the order of the dependencies' hashes
+  const SvChgCtx& c;
+  __device__ __forceinline__ i64 at(u32 e) const {
+    u32 lo = 0, hi = c.nc;   // the last change whose entries start at or in front of e (changes without deps share a start: the last one owns it)
+    while (hi - lo > 1) { const u32 mid = lo + (hi - lo) / 2; if (c.B.c_dep_base[c.cb + mid] - c.db <= e) lo = mid; else hi = mid; }
+    return (i64)sv_dep_sorted(c.B, c.cb + lo, c.cb, e - (c.B.c_dep_base[c.cb + lo] - c.db));
+  }
+  __device__ __forceinline__ void load(u32 e, u64& v, bool& isnull) const { isnull = false; v = (u64)(at(e) - (e ? at(e - 1) : 0)); }
+};
+struct SvChgExtraSrc {
+  const SvChgCtx& c;
+  __device__ __forceinline__ ScRaw load(u32 e) const {
+    ScRaw r; r.len = c.B.c_extra_len[c.cb + e]; r.kind = r.len ? 1 : 0; r.x = 0; r.p = c.chunk + c.B.c_extra_off[c.cb + e];
+    return r;
+  }
+};
+
 #define SV_GROUPS 7
 template <bool STORE>
 __global__ void __launch_bounds__(64 * SD_WAVES) g_save_seg(BatchDev B) {
@@ -613,7 +654,7 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_save_seg(BatchDev B) {
   const u32 d = blockIdx.x * SD_WAVES + wave;
   if (d >= B.n_docs) return;
   const u32 lane = threadIdx.x & 63;
-  const bool big = B.sv_big && B.sv_big[d];   // its op columns are cut into ranges (g_sv_big); lengths 0 here, set by g_sv_big_total
+  const bool big = B.sv_big && (B.sv_big[d] & 1);   // its op columns are cut into ranges (g_sv_big); lengths 0 here, set by g_sv_big_total
   const bool live = B.status[d] == 0 && B.sv_status[d] == 0 && !big;
   u32* cl = B.sv_col_len + (u64)d * AMH_SV_NCOLS;
   if (STORE && !live) return;
@@ -694,7 +735,8 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_sv_big(BatchDev B) {
   const u32 d = B.svb_doc[bc], col = B.svb_col[bc];
   const bool live = B.status[d] == 0 && B.sv_status[d] == 0;
   const u32 n = live ? B.cnt[d].n_rows : 0, ns = live ? B.cnt[d].n_succ : 0;
-  u32 ncol = (col == 21 || col == 22) ? ns : n;
+  const u32 nchg = live ? B.cnt[d].n_chg : 0, ndeps = live ? B.cnt[d].n_deps : 0;
+  u32 ncol = col < AMH_SV_CHG_COLS ? (col == 6 ? ndeps : nchg) : ((col == 21 || col == 22) ? ns : n);
   if (col == 24 && B.desc[d].ocol[OC_MARK_NAME].len == 0) ncol = 0;   // only documents with a mark column
   ScSummary S;
   sc_summary_init(S);
@@ -719,6 +761,7 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_sv_big(BatchDev B) {
   }
   if (work) {
     SvCtx c{B, B.row_base[d], B.actor_base[d], B.arena + B.desc[d].chunk_off};
+    SvChgCtx cc{B, B.chg_base[d], B.dep_base[d], nchg, B.actor_rank + B.actor_base[d], B.arena + B.desc[d].chunk_off};
 #define SV_NUM(SIGNED, src) { if constexpr (MODE == 0) sc_rle_summary(src, rg.lo, rg.hi, lane, S, any); \
       else if constexpr (MODE == 1) total = sc_rle_range<SIGNED, false>(src, rg, (u8*)0, 0, lane, any); \
       else sc_rle_range<SIGNED, true>(src, rg, out, col_len, lane, any); }
@@ -729,6 +772,13 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_sv_big(BatchDev B) {
       else if constexpr (MODE == 1) total = sc_str_range<false>(src, rg, (u8*)0, 0, lane, any); \
       else sc_str_range<true>(src, rg, out, col_len, lane, any); }
     switch (col) {
+      case 0: case 5: case 7: { SvChgNumSrc s{cc, col}; SV_NUM(false, s) } break;
+      case 1: case 2: case 3: { SvChgDeltaSrc s{cc, col}; SV_NUM(true, s) } break;
+      case 4:  { SvChgMsgSrc s{cc}; SV_STR(s) } break;
+      case 6:  { SvChgDepSrc s{cc}; SV_NUM(true, s) } break;
+      case 8:  { SvChgExtraSrc s{cc};
+                 if constexpr (MODE == 1) total = sc_raw_range<false>(s, rg, (u8*)0, 0, lane);
+                 else if constexpr (MODE == 2) sc_raw_range<true>(s, rg, out, col_len, lane); } break;
       case 9:  { SvObjSrc s{c, false}; SV_NUM(false, s) } break;
       case 10: { SvObjSrc s{c, true}; SV_NUM(false, s) } break;
       case 11: { SvKeyActorSrc s{c}; SV_NUM(false, s) } break;
@@ -786,7 +836,7 @@ __global__ void __launch_bounds__(AMH_BLOCK) g_sv_big_total(BatchDev B) {
   }
   // a column of nothing but nulls (rle.rs:33) / a MaybeBoolean column without a true (boolean.rs:131-137) is not written
   if (SAVE) {
-    const bool always = col == 16 || col == 19;   // insert, raw values
+    const bool always = col == 16 || col == 19 || col == 8;   // insert, raw values, extra bytes
     B.sv_col_len[(u64)d * AMH_SV_NCOLS + col] = (always || any) ? run : 0;
   } else {
     const bool always = col == 5 || col == 8;
