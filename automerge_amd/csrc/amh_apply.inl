@@ -483,6 +483,20 @@ AMH_DEV void k_ap_weight(const MergeDev& G, u32 r) {
   A.o_tmp[(u32)me & ~AP_RANK_TOP] = (u32)(me >> 32) + 1;
 }
 // A6e  top rows per gap: rows in front of a dst row (gap_cnt, scanned next) and the list of top rows sharing the gap.
+// Where two top rows of one gap and one object go relative to each other, as one number (ap_top_less from the anchor
+// on: deeper anchor first, updates before child elements, updates by ascending and elements by descending counter);
+// equal numbers (same counter, different actors) and map rows are left to ap_top_less.  Kept in o_rank of the top row,
+// which the ranking is done with by then.
+#define AP_KEY_NONE (1ull << 63)
+AMH_DEV u64 ap_top_key(const MergeDev& G, u32 r) {
+  const BatchDev& S = G.S;
+  if (row_is_prop(S, r)) return AP_KEY_NONE;
+  const u32 ax = G.A.anchor[r] + 1;   // AMH_NULL32 + 1 = 0
+  if (ax > 0x0FFFFFFFu) return AP_KEY_NONE;
+  const bool xi = S.r_insert[r] != 0;
+  const u32 ctr = S.r_id_ctr[r];
+  return ((u64)(0x0FFFFFFFu - ax) << 33) | ((u64)(xi ? 1 : 0) << 32) | (u64)(xi ? ~ctr : ctr);
+}
 AMH_DEV void k_ap_top_place(const MergeDev& G, u32 r) {
   const ApplyDev& A = G.A;
   if (!ap_row_new(G, r) || A.parent[r] != AMH_NULL32) return;
@@ -493,6 +507,7 @@ AMH_DEV void k_ap_top_place(const MergeDev& G, u32 r) {
   u32 slot = G.gap_base[p] + g;
   amh_atomic_add(&G.gap_cnt[slot], A.o_tmp[r]);
   A.o_next[r] = amh_atomic_exch(&A.g_head[slot], r);
+  A.o_rank[r] = ap_top_key(G, r);
 }
 // A6e'  gaps shared by more than AMH_BIG_LIST top rows: the list's head row records the gap; a block then sorts its
 //       top rows and leaves, in o_top of each (unused for a top row otherwise), the rows that go in front of it within
@@ -524,9 +539,23 @@ AMH_DEV void k_ap_top_k(const MergeDev& G, u32 r) {
   const u32* pre = G.gap_cnt + G.gap_base[p];
   u32 k = G.new_idx[S.row_base[p]] + (pre[g] - pre[0]);
   if (A.o_top[r] != AMH_NULL32) k += A.o_top[r];   // a long list: ranked by g_big_mg<BIGK_TIES>
-  else
-  for (u32 m = A.g_head[G.gap_base[p] + g]; m != AMH_NULL32; m = A.o_next[m])
-    if (m != r && ap_top_less(G, p, m, r)) k += A.o_tmp[m];
+  else {
+    u32 rc, rr;
+    mg_s_obj(G, p, r, rc, rr);
+    const u64 kr = A.o_rank[r];
+    for (u32 m = A.g_head[G.gap_base[p] + g]; m != AMH_NULL32; m = A.o_next[m]) {
+      if (m == r) continue;
+      const u64 km = A.o_rank[m];
+      bool less;
+      if (((km | kr) >> 63) == 0) {
+        u32 mc, mr;
+        mg_s_obj(G, p, m, mc, mr);
+        const int c = mg_lam(mc, mr, rc, rr);
+        less = c ? c < 0 : (km != kr ? km < kr : ap_top_less(G, p, m, r));
+      } else less = ap_top_less(G, p, m, r);
+      if (less) k += A.o_tmp[m];
+    }
+  }
   A.o_stack[r] = k;
 }
 // A6g  emit: every new row goes behind its top row by its place in the subtree's preorder list.  Thread per row of U.
@@ -535,9 +564,10 @@ AMH_DEV void k_ap_emit(const MergeDev& G, u32 r) {
   if (!ap_row_new(G, r)) return;
   u32 p = G.S.r_doc[r];
   if (!mg_pair_ok(G, p)) return;
-  u64 me = A.o_rank[r];
-  u32 t = (u32)me & ~AP_RANK_TOP;
-  u32 k = A.o_stack[t] + (u32)(me >> 32);
+  const bool top = A.parent[r] == AMH_NULL32;   // (o_rank of a top row holds its ordering key by now)
+  const u64 me = top ? 0 : A.o_rank[r];
+  const u32 t = top ? r : ((u32)me & ~AP_RANK_TOP);
+  const u32 k = A.o_stack[t] + (u32)(me >> 32);
   G.new_src[k] = r; G.new_gap[k] = A.gap[t];
 }
 
