@@ -367,6 +367,77 @@ def bench_bigdoc(args, eng, rank, world, dist, torch, red_dev):
         dist.destroy_process_group()
 
 
+def bench_trace(args, eng, rank, world, dist, torch, red_dev):
+    """configs[0]: the automerge-perf editing trace (259,778 edits) as the reference's edit-trace driver leaves it: ONE change
+    of ~260k ops, saved, then Automerge::load (rust/edit-trace/src/main.rs:20-54).  The document is the committed fixture
+    tests/golden/edit_trace.automerge.gz (made from the reference's edits.json by tools/golden/make_edit_trace.py).
+    One step = one load (change re-derived over many waves and hashed, heads verified); the save is timed beside it."""
+    import gzip
+    doc = gzip.open(os.path.join(ROOT, "tests", "golden", "edit_trace.automerge.gz")).read()
+    staged = eng.stage([doc])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.load_staged(staged).close()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        b = eng.load_staged(staged)
+        b.close()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.set_profiling(True)
+    eng.reset_profile()
+    batch = eng.load_staged(staged)
+    eng.set_profiling(False)
+    kt = eng.kernel_times()
+    batch.check(0)
+    st = batch.stats()
+    batch.save_all(deflate=False)
+    t1 = time.perf_counter()
+    resaved = batch.save_all(deflate=False)[0]
+    save_ms = (time.perf_counter() - t1) * 1e3
+    assert resaved == doc, "save(load(x)) != x"
+    ops = st["ops_loaded"]
+    tot = torch.tensor([float(elapsed)], dtype=torch.float64, device=red_dev)
+    if dist is not None:
+        dist.all_reduce(tot, op=dist.ReduceOp.MAX)
+    elapsed_max = float(tot[0])
+    if rank == 0:
+        st["actors"] = 1
+        st["actor_map"] = st["changes"]
+        model = algorithmic_bytes(st, column_bytes(eng, batch, 1))
+        OVERLAPPED = ("sha_doc", "visible")
+        dom = max((k for k in kt if kt[k][1] > 0 and k not in OVERLAPPED and k in model), key=lambda k: kt[k][0])
+        dom_ms, dom_calls = kt[dom]
+        achieved = model[dom] / (dom_ms * 1e-3) / 1e9
+        out = {"metric": "ops loaded+merged/sec (node)", "value": world * ops * args.steps / elapsed_max, "unit": "ops/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64", "data": "the reference's edit trace (tests/golden fixture)",
+               "config": {"workload": f"configs[0]: the automerge-perf editing trace as one change of {ops} ops: load", "encoded_bytes": len(doc),
+                          "save_ms": round(save_ms, 2), "sharding": "replicas only",
+                          "checks": "the change re-derived and hashed (hash pinned by the fixture), heads verified, save(load(x)) == x"},
+               "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                            "traffic": None, "algorithmic_bytes_per_launch": model[dom] / dom_calls, "launch_ms": dom_ms / dom_calls,
+                            "kernel_ms_total": sum(v[0] for k, v in kt.items() if k not in OVERLAPPED)},
+               "kernels": {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0]) if v[1] > 0}}
+        if not args.no_cpu and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as o   # CPU oracle: the reported baseline only (never the measured path)
+            t0 = time.perf_counter()
+            d = o.Doc.load(doc)
+            secs = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": d.num_ops() / secs, "unit": "ops/s", "cores": 1, "kind": "port",
+                                   "sample": "the same document, one load (CPU restatement in oracle/, not the Rust reference: no toolchain)"}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def bench_sync(args, eng, rank, world, dist, torch, red_dev):
     """configs[4]: sync-server sweep.  `--docs` documents per GPU (default 125k = 1M over 8 GPUs) of 8 changes x 20 map puts.
     One step = load the rank's documents (every change re-derived and SHA-256 hashed, heads), heads + Bloom summary per
@@ -523,7 +594,7 @@ def main():
     ap.add_argument("--docs", type=int, default=None, help="documents per GPU (default: 10k for merge = configs[2]; 100k for load = configs[1])")
     ap.add_argument("--cpu-sample", type=int, default=16000, help="documents of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", default="merge", choices=["merge", "load", "bigdoc", "sync", "apply"],
+    ap.add_argument("--workload", default="merge", choices=["merge", "load", "bigdoc", "sync", "apply", "trace"],
                     help="merge = configs[2] (the headline line: BASELINE.json quotes the metric on it): 10k text documents x 8 divergent replicas, "
                          "load 8 + merge 7; load = configs[1]: 100k JSON-map documents; bigdoc = configs[3]: one 10M-op text document")
     ap.add_argument("--slice", type=int, default=10000, help="merge workload: documents streamed through the pipeline at a time")
@@ -532,7 +603,7 @@ def main():
     ap.add_argument("--sequential-merges", action="store_true", help="merge workload: R-1 amh_merge_batch calls instead of one amh_merge_many")
     args = ap.parse_args()
     if args.docs is None:
-        args.docs = {"load": 100000, "merge": 10000, "sync": 125000, "apply": 100000, "bigdoc": 1}[args.workload]
+        args.docs = {"load": 100000, "merge": 10000, "sync": 125000, "apply": 100000, "bigdoc": 1, "trace": 1}[args.workload]
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -562,6 +633,8 @@ def main():
         if args.replicas == 8:
             args.replicas = 16
         return bench_bigdoc(args, eng, rank, world, dist, torch, red_dev)
+    if args.workload == "trace":
+        return bench_trace(args, eng, rank, world, dist, torch, red_dev)
     if args.workload == "sync":
         return bench_sync(args, eng, rank, world, dist, torch, red_dev)
     if args.workload == "apply":

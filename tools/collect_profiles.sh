@@ -28,5 +28,6 @@ if [ $PART = all ] || [ $PART = other ]; then
 timeout -k 10 600 python3 $R/bench.py --workload bigdoc > $O/${TAG}_bench_bigdoc.json 2> $O/${TAG}_bench_bigdoc.err
 timeout -k 10 300 python3 $R/bench.py --workload sync --steps 3 --warmup 1 > $O/${TAG}_bench_sync.json 2> $O/${TAG}_bench_sync.err
 timeout -k 10 300 python3 $R/bench.py --workload apply --steps 3 --warmup 1 --no-cpu > $O/${TAG}_bench_apply.json 2> $O/${TAG}_bench_apply.err
+timeout -k 10 300 python3 $R/bench.py --workload trace --steps 20 --warmup 3 > $O/${TAG}_bench_trace.json 2> $O/${TAG}_bench_trace.err
 fi
 ls $O | grep ${TAG} | head -40
