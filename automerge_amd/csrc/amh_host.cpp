@@ -863,20 +863,33 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
   rt_memset(B.big_n, 0, 4 * sizeof(u32), ctx->stream);
   launch(ctx, AK_PRED_SORT, B, T);   // + the actors each op refers to (k_actor_mark), in the same pass over the pred lists
   launch(ctx, AK_ACTOR_RANK, B, B.tot_chg);
+  SaveBigHost ebh;   // changes of tens of thousands of ops: their columns are cut into ranges, a wave each (g_en_big)
+  if (!enc_big_prepare(ctx, b, B, ebh)) return fail("device pipeline failed: job tables of the change re-encode");
   for (int k = 0; k < 12; k++) B.cv[k] = nullptr;   // one interleaved array per column group: obj (2 fields), key (4), misc (2), value (4)
-  B.cv[0] = balloc<u32>(b, 2 * ((size_t)tot_ops + 1), &ok); B.cv[2] = balloc<u32>(b, 4 * ((size_t)tot_ops + 1), &ok);
-  B.cv[6] = balloc<u32>(b, 2 * ((size_t)tot_ops + 1), &ok); B.cv[8] = balloc<u32>(b, 4 * ((size_t)tot_ops + 1), &ok);
-  if (!ok) return fail("device out of memory");
+  B.enc_tmp = nullptr;
+  bool need_view = true;
+#ifndef AMH_EMU
+  if (amh_encode_one_pass(B)) {
+    // changes of a few hundred ops and more: one walk per change straight from the op rows into per-column slots
+    // (amh_segenc1.inl); the change view is only built for changes whose columns are cut into ranges
+    need_view = B.sv_nj != 0;
+    B.enc_tmp = balloc<u8>(b, (size_t)amh_encode_tmp_bytes(B), &ok);
+    if (!ok) return fail("device out of memory");
+  }
+#endif
   rt_memset(B.c_wide, 0, NC * 4, ctx->stream);
-  launch(ctx, AK_CHANGE_VIEW, B, tot_ops);
+  if (need_view) {
+    B.cv[0] = balloc<u32>(b, 2 * ((size_t)tot_ops + 1), &ok); B.cv[2] = balloc<u32>(b, 4 * ((size_t)tot_ops + 1), &ok);
+    B.cv[6] = balloc<u32>(b, 2 * ((size_t)tot_ops + 1), &ok); B.cv[8] = balloc<u32>(b, 4 * ((size_t)tot_ops + 1), &ok);
+    if (!ok) return fail("device out of memory");
+    launch(ctx, AK_CHANGE_VIEW, B, tot_ops);
+  }
   // visibility only needs the linked rows: it runs on the side stream next to the change encode and hashing, whose
   // per-lane state machines leave the memory system mostly idle (joined before the statuses are read)
   rt_event_record(&ctx->ev_fork2, ctx->stream);
   rt_stream_wait(ctx->side, &ctx->ev_fork2);
   launch_on(ctx, ctx->side, AK_VISIBLE, B, B.tot_rows);
   rt_event_record(&ctx->ev_join, ctx->side);
-  SaveBigHost ebh;   // changes of tens of thousands of ops: their columns are cut into ranges, a wave each (g_en_big)
-  if (!enc_big_prepare(ctx, b, B, ebh)) return fail("device pipeline failed: job tables of the change re-encode");
   launch(ctx, AK_ENCODE_SIZE, B, B.tot_chg * AMH_NCOLS);
   save_big_launch(ctx, B, 2);
   launch(ctx, AK_CHG_LAYOUT, B, B.tot_chg);

@@ -457,16 +457,23 @@ __global__ void __launch_bounds__(64) g_encode_grp(BatchDev B) {
   (void)chunk; (void)pn;
 }
 #include "amh_segenc.inl"
+#include "amh_segenc1.inl"
 // Two forms of the change re-encode.  Batches of small changes (the headline: 50 ops per change): lane = change, 64
 // changes per wave in step (g_encode_grp) — a wave per change would spend itself on per-column set-up, and the
 // scalar unit of a CU, shared by its four SIMDs, would be the limit.  Larger changes: one wave per (change, column
 // group), 64 values per step (g_encode_seg), whose cost does not depend on how the ops are spread over the changes.
-template <bool STORE>
-static void launch_encode(const BatchDev& B, hipStream_t s) {
+static bool encode_lane_form(const BatchDev& B) {
   // AMH_ENCODE_FORM=seg | lane forces one form (tests run every document shape through both)
   const char* form = getenv("AMH_ENCODE_FORM");
-  const bool lane_form = form ? form[0] == 'l' : (u64)B.tot_ops < (u64)B.tot_chg * 192;
-  if (lane_form) {
+  return form ? form[0] == 'l' : (u64)B.tot_ops < (u64)B.tot_chg * 192;
+}
+bool amh_encode_one_pass(const BatchDev& B) { return !encode_lane_form(B); }
+u64 amh_encode_tmp_bytes(const BatchDev& B) {
+  return (u64)B.tot_ops * SC1_OP_SUM + (u64)B.tot_succ * SC1_PRED_SUM + (u64)B.tot_chg * (AMH_NCOLS * SC1_PAD) + 256;
+}
+template <bool STORE>
+static void launch_encode(const BatchDev& B, hipStream_t s) {
+  if (encode_lane_form(B)) {
     const dim3 g((B.tot_chg + 63) / 64), b(64);
     hipLaunchKernelGGL((g_encode_grp<STORE, 1>), g, b, 0, s, B);
     hipLaunchKernelGGL((g_encode_grp<STORE, 2>), g, b, 0, s, B);
@@ -476,8 +483,16 @@ static void launch_encode(const BatchDev& B, hipStream_t s) {
     hipLaunchKernelGGL((g_encode_grp<STORE, 6>), g, b, 0, s, B);
     return;
   }
+  // one pass (amh_segenc1.inl): "size" = the walk that writes every column into its slot and leaves the lengths;
+  // "store" (behind the layout) = the copy into the chunks + a second walk for the columns that outgrew their slots
   const u32 parts = (u64)B.tot_ops >= (u64)B.tot_chg * 1024 ? SC_GROUPS : 1;
-  hipLaunchKernelGGL((g_encode_seg<STORE>), dim3((B.tot_chg + SD_WAVES - 1) / SD_WAVES, parts), dim3(64 * SD_WAVES), 0, s, B);
+  const dim3 g((B.tot_chg + SD_WAVES - 1) / SD_WAVES, parts), g1((B.tot_chg + SD_WAVES - 1) / SD_WAVES), b(64 * SD_WAVES);
+  if (!STORE) {
+    hipLaunchKernelGGL((g_encode_one<0>), g, b, 0, s, B);
+  } else {
+    hipLaunchKernelGGL(g_encode_place, g1, b, 0, s, B);
+    hipLaunchKernelGGL((g_encode_one<1>), g, b, 0, s, B);
+  }
 }
 
 

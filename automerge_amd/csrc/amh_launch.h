@@ -41,6 +41,12 @@ void amh_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst,
 // phase 0 after AK_SAVE_SIZE (column lengths of the big columns), phase 1 after AK_SAVE_STORE (their bytes).  The
 // change re-encode of very large changes: phase 2 after AK_ENCODE_SIZE, phase 3 after AK_ENCODE_STORE.
 void amh_launch_save_big(const BatchDev& B, int phase, void* stream);
+// The change re-encode of a load (device build): which form the batch takes.  Batches of small changes keep the lane-per-change
+// form over the change view (k_change_view); larger changes are encoded in one pass straight from the op rows into
+// per-column slots of B.enc_tmp (amh_segenc1.inl), which must hold amh_encode_tmp_bytes(B) bytes; the view is then only
+// needed by changes whose columns are cut into ranges (B.sv_nj != 0).
+bool amh_encode_one_pass(const BatchDev& B);
+u64 amh_encode_tmp_bytes(const BatchDev& B);
 // heads of staged change chunks: len16[u] = bytes in front of chunk u's column metadata rounded up to 16 (0 for failed
 // chunks); the copy packs them at off[u] (exclusive sums of len16) of dst
 // actor tables of a batch's documents packed for the host: len[d] = bytes from the first actor id of document d to the

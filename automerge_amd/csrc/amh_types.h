@@ -177,6 +177,7 @@ struct BatchDev {
   // 8 value meta lo  9 value meta hi | kind << 8  10, 11 raw offset + length, or the i64 of a re-encoded increment
   u32* cv[12];
   u8* out_arena;                 // re-derived change chunks
+  u8* enc_tmp;                   // one-pass change re-encode (amh_segenc1.inl): a slot per (change, column), written right-aligned
   i32* sv_status;                // [n_docs] save: 0 ok, else why the document has no saved form
   u32* sv_col_len;               // [n_docs * 25]
   u32* sv_wide;                  // [n_docs] bit k: column k holds a literal run of more than 64 values (left to k_save_store)
