@@ -840,10 +840,8 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
     if ((nc && (!rt_h2d(d_src, adopt->src.data(), (size_t)nc * sizeof(u64), ctx->stream) || !rt_h2d(B.c_out_len, adopt->len.data(), (size_t)nc * sizeof(u32), ctx->stream))) ||
         !rt_h2d(B.c_out_off, off.data(), ((size_t)nc + 1) * sizeof(u32), ctx->stream))
       return fail("H2D copy failed");
-    rt_event_record(&ctx->ev_fork2, ctx->stream);
-    rt_stream_wait(ctx->side, &ctx->ev_fork2);
-    launch_on(ctx, ctx->side, AK_VISIBLE, B, B.tot_rows);
-    rt_event_record(&ctx->ev_join, ctx->side);
+    launch(ctx, AK_VISIBLE, B, B.tot_rows);
+    rt_event_record(&ctx->ev_join, ctx->stream);
     amh_copy_bytes(d_src, B.c_out_len, B.c_out_off, B.out_arena, nc, (void*)ctx->stream);
   } else {
   B.ops_sorted = balloc<u32>(b, (size_t)tot_ops + 1, &ok);
@@ -884,12 +882,6 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
     if (!ok) return fail("device out of memory");
     launch(ctx, AK_CHANGE_VIEW, B, tot_ops);
   }
-  // visibility only needs the linked rows: it runs on the side stream next to the change encode and hashing, whose
-  // per-lane state machines leave the memory system mostly idle (joined before the statuses are read)
-  rt_event_record(&ctx->ev_fork2, ctx->stream);
-  rt_stream_wait(ctx->side, &ctx->ev_fork2);
-  launch_on(ctx, ctx->side, AK_VISIBLE, B, B.tot_rows);
-  rt_event_record(&ctx->ev_join, ctx->side);
   launch(ctx, AK_ENCODE_SIZE, B, B.tot_chg * AMH_NCOLS);
   save_big_launch(ctx, B, 2);
   launch(ctx, AK_CHG_LAYOUT, B, B.tot_chg);
@@ -908,6 +900,19 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
   save_big_launch(ctx, B, 3);
   B.sv_nj = 0; B.sv_nbc = 0; B.sv_big = nullptr;   // (the tables were this pass's)
   launch(ctx, AK_CHG_HEADER, B, B.tot_chg);
+  // Visibility only needs the linked rows.  It runs on the side stream beside the hashing of the changes: one launch per
+  // dependency level, a lane per change — a chain of launches that each occupy a fraction of the SIMDs and leave the memory
+  // system idle (round 2 ran it beside the change encode; the one-pass encoder is bound by the memory system itself and
+  // the pair then took as long as one after the other).  AMH_VISIBLE_MAIN=1: on the main stream, for its standalone time.
+  if (getenv("AMH_VISIBLE_MAIN")) {
+    launch(ctx, AK_VISIBLE, B, B.tot_rows);
+    rt_event_record(&ctx->ev_join, ctx->stream);
+  } else {
+    rt_event_record(&ctx->ev_fork2, ctx->stream);
+    rt_stream_wait(ctx->side, &ctx->ev_fork2);
+    launch_on(ctx, ctx->side, AK_VISIBLE, B, B.tot_rows);
+    rt_event_record(&ctx->ev_join, ctx->side);
+  }
   // hash the changes level by level: every change of a level only needs hashes of earlier levels
   B.lvl_order = balloc<u32>(b, (size_t)B.tot_chg + 1, &ok);
   B.lvl_start = balloc<u32>(b, AMH_LEVEL_CAP_HOST + 4, &ok);
@@ -1842,9 +1847,17 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
   rt_memset(M.fail_line, 0, (P + 1) * 4, ctx->stream);
   rt_memset(G.x_cnt, 0, NRD * 4, ctx->stream); rt_memset(G.x_fill, 0, NRD * 4, ctx->stream);
   if (ok) rt_memset(G.sub_min2, 0xFF, (NRD / 4096 + 2) * 4, ctx->stream);
+  // the block is sent again only when the host changed it since the last launch (it is ~6 KB: 45 launches of a call
+  // used to make 45 small copies)
+  std::unique_ptr<MergeDev> G_sent(new MergeDev);
+  bool G_any = false;
   auto mg = [&](int k, u32 n) {
     if (n == 0) return true;
-    if (!rt_h2d(Gdev, &G, sizeof(MergeDev), ctx->stream)) return false;
+    if (!G_any || memcmp(G_sent.get(), &G, sizeof(MergeDev)) != 0) {
+      if (!rt_h2d(Gdev, &G, sizeof(MergeDev), ctx->stream)) return false;
+      memcpy(G_sent.get(), &G, sizeof(MergeDev));
+      G_any = true;
+    }
 #ifdef AMH_EMU
     launch_mg_timed(ctx, k, &G, n);
 #else
@@ -2602,15 +2615,24 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       if (!rt_h2d(d_src, seg_src.data(), ns * sizeof(u64), ctx->stream) || !rt_h2d(d_dst, seg_dst.data(), ns * sizeof(u64), ctx->stream) ||
           !rt_h2d(d_len, seg_len.data(), ns * sizeof(u32), ctx->stream))
         return faild("H2D copy failed");
-      amh_copy_segments(d_src, d_len, d_dst, d_arena, ns, (void*)ctx->stream);
+      // the sources are re-derived chunks where they lie in a loaded batch's out_arena (k_chg_layout packs them back to
+      // back: any alignment), so the copy is the byte-exact one: nothing behind a chunk's last byte is read, and the
+      // alignment gap behind its copy keeps the zeros of the memset above (g_ap_head_copy relies on them)
+      amh_copy_bytes64(d_src, d_len, d_dst, d_arena, ns, (void*)ctx->stream);
     }
     rt_memset(U.status, 0, (NCH + 1) * sizeof(i32), ctx->stream);
     rt_memset(U.fail_line, 0, (NCH + 1) * sizeof(u32), ctx->stream);
     rt_memset(U.doc_max_op, 0, (NCH + 1) * sizeof(u32), ctx->stream);
+    std::unique_ptr<MergeDev> G0_sent(new MergeDev);
+    bool G0_any = false;
     auto mg0 = [&](int k, u32 n) {
       if (n == 0) return true;
       G0.U = U; G0.A.hdr = ap.d_hdr; G0.A.u_chg = ap.d_u_chg; G0.A.u_fill = ap.d_u_fill;
-      if (!rt_h2d(G0dev, &G0, sizeof(MergeDev), ctx->stream)) return false;
+      if (!G0_any || memcmp(G0_sent.get(), &G0, sizeof(MergeDev)) != 0) {
+        if (!rt_h2d(G0dev, &G0, sizeof(MergeDev), ctx->stream)) return false;
+        memcpy(G0_sent.get(), &G0, sizeof(MergeDev));
+        G0_any = true;
+      }
 #ifdef AMH_EMU
       launch_mg_timed(ctx, k, &G0, n);
 #else
@@ -3343,9 +3365,6 @@ extern "C" int amh_sync_summaries(amh_ctx* ctx, const amh_batch* bc, amh_bytes_o
   return AMH_SUCCESS;
 }
 
-// The same records written into the caller's device buffer, with nothing allocated on the host or the device: no pool,
-// no event, no copy to the host (include/automerge_hip.h).  Returns when the kernels are queued on the context's stream
-// and waits for them (hipStreamSynchronize allocates nothing), so d_out / d_meta are complete on return.
 // == the exchange step of the sync path across GPUs: every rank's summaries, gathered on every rank.
 // The collective runs on device buffers (RCCL over xGMI): sizes by one all-gather of a u64 per rank, the records by an
 // all-gather(v) into one device buffer, which then comes to the host once.  rank_off[world + 1] = where each rank's
@@ -3449,6 +3468,10 @@ extern "C" int amh_partition_docs(const size_t* lens, size_t n, int world, size_
   first[world] = n;
   return AMH_SUCCESS;
 }
+// The records of amh_sync_summaries written into the caller's device buffer, with nothing allocated on the host or the
+// device: no pool, no event, no copy to the host (include/automerge_hip.h).  Queues the kernels on the context's own
+// stream and waits for them (hipStreamSynchronize allocates nothing), so d_out / d_meta are complete on return; because
+// of that wait and the private stream the call cannot itself be captured into a HIP graph.
 extern "C" int amh_sync_summaries_noalloc(amh_ctx* ctx, const amh_batch* b, uint8_t* d_out, size_t cap, uint32_t* d_meta) {
   if (!ctx || !b || !d_meta || (cap && !d_out)) { set_error(ctx, "invalid argument"); return AMH_ERR_INVALID_ARG; }
 #ifdef AMH_EMU

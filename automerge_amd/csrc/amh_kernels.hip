@@ -486,12 +486,14 @@ static void launch_encode(const BatchDev& B, hipStream_t s) {
   // one pass (amh_segenc1.inl): "size" = the walk that writes every column into its slot and leaves the lengths;
   // "store" (behind the layout) = the copy into the chunks + a second walk for the columns that outgrew their slots
   const u32 parts = (u64)B.tot_ops >= (u64)B.tot_chg * 1024 ? SC_GROUPS : 1;
-  const dim3 g((B.tot_chg + SD_WAVES - 1) / SD_WAVES, parts), g1((B.tot_chg + SD_WAVES - 1) / SD_WAVES), b(64 * SD_WAVES);
+  const dim3 g(((B.tot_chg + SD_WAVES - 1) / SD_WAVES) * parts), g1((B.tot_chg + SD_WAVES - 1) / SD_WAVES), b(64 * SD_WAVES);
+  const char* gm = getenv("AMH_ENC_GMASK");
+  const u32 gmask = gm ? (u32)atoi(gm) : 0x1Fu;
   if (!STORE) {
-    hipLaunchKernelGGL((g_encode_one<0>), g, b, 0, s, B);
+    hipLaunchKernelGGL((g_encode_one<0>), g, b, 0, s, B, gmask, parts);
   } else {
     hipLaunchKernelGGL(g_encode_place, g1, b, 0, s, B);
-    hipLaunchKernelGGL((g_encode_one<1>), g, b, 0, s, B);
+    hipLaunchKernelGGL((g_encode_one<1>), g, b, 0, s, B, gmask, parts);
   }
 }
 
@@ -779,6 +781,86 @@ __global__ void __launch_bounds__(AMH_BLOCK) g_big_pred(const BatchDev B) {
                 [&](u32 i, u32 j) { u64 x = v[i]; v[i] = v[j]; v[j] = x; });
   }
 }
+// ------------------------------------------------------------------------------------------
+// Visibility and winners (types.rs:712-720, iter/top_ops.rs:58-65), device form of k_visible: the winner of a key /
+// element group is its LAST visible row, i.e. a wave-level segmented reduction over the rows in document order.
+// One wave per tile of 64 rows: every lane loads its own row (coalesced), the group boundaries come from comparing
+// each row with the one in front (the neighbour's fields by DPP, lane 0 reads row r - 1), and two ballots — VIS
+// (visible rows) and GS (rows that start a group) — decide every lane at once: a visible row wins iff a group starts
+// before the next visible row behind it.  Lanes whose group runs past the tile look at the following tiles together
+// (ballots again); that loop ends at the first tile with a visible row or a group start, so the work stays linear in
+// the rows (one key overwritten 50k times: only its last row is visible).
+// ------------------------------------------------------------------------------------------
+struct VisRow { u32 doc, oc, oa, kl, ko, ea, ec; bool prop, vis; };
+__device__ __forceinline__ VisRow vis_load(const BatchDev& B, u32 r) {
+  VisRow v;
+  v.doc = B.r_doc[r]; v.oc = B.r_obj_ctr[r]; v.oa = B.r_obj_actor[r];
+  v.kl = B.r_key_len[r];
+  const bool ins = B.r_insert[r] != 0;
+  v.prop = v.kl != AMH_NULL32 && !ins;
+  v.ko = v.prop ? B.r_key_off[r] : 0u;
+  v.ea = ins ? B.r_id_actor[r] : B.r_key_actor[r];
+  v.ec = ins ? B.r_id_ctr[r] : B.r_key_ctr[r];
+  v.vis = v.doc < B.n_docs && B.status[v.doc] == 0 && row_visible(B, r);
+  return v;
+}
+// rows a (in front) and b in the same key / element group (same_group of amh_kernels.inl)
+__device__ __forceinline__ bool vis_same(const BatchDev& B, const VisRow& a, const VisRow& b) {
+  if (a.doc != b.doc || a.oc != b.oc || a.oa != b.oa || a.prop != b.prop) return false;
+  if (!a.prop) return a.ea == b.ea && a.ec == b.ec;
+  if (a.kl != b.kl) return false;
+  if (a.ko == b.ko) return true;   // rows of one run of the key column share the string
+  const u8* chunk = B.arena + B.desc[a.doc].chunk_off;
+  RleVal x, y;
+  x.v = 0; x.s = chunk + a.ko; x.n = a.kl;
+  y.v = 0; y.s = chunk + b.ko; y.n = b.kl;
+  return rv_eq<2>(x, y);
+}
+__global__ void __launch_bounds__(AMH_BLOCK) g_visible_seg(BatchDev B, u32 n) {
+  const u32 r = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  const u32 lane = threadIdx.x & 63;
+  const u32 tb = r - lane;
+  if (tb >= n) return;
+  const bool valid = r < n;
+  VisRow me;
+  me.doc = AMH_NULL32; me.oc = me.oa = me.kl = me.ko = me.ea = me.ec = 0; me.prop = false; me.vis = false;
+  if (valid) me = vis_load(B, r);
+  // the row in front: lane - 1's by DPP, lane 0 reads it
+  VisRow pv;
+  pv.doc = sd_prev(me.doc); pv.oc = sd_prev(me.oc); pv.oa = sd_prev(me.oa); pv.kl = sd_prev(me.kl); pv.ko = sd_prev(me.ko);
+  pv.ea = sd_prev(me.ea); pv.ec = sd_prev(me.ec); pv.prop = sd_prev((u32)me.prop) != 0; pv.vis = false;
+  bool gs = true;
+  if (lane == 0) { if (valid && r > 0) { pv = vis_load(B, r - 1); gs = !vis_same(B, pv, me); } }
+  else if (valid) gs = !vis_same(B, pv, me);
+  const u64 VALID = __ballot(valid);
+  const u64 VIS = __ballot(me.vis), GS = __ballot(gs && valid) | ~VALID;   // rows behind the last one end every group
+  bool win = false, open = false;
+  if (me.vis) {
+    const u64 behind = lane == 63 ? 0 : (~(u64)0 << (lane + 1));
+    const u64 later = VIS & behind, gsl = GS & behind;
+    if (later) { const u32 j = (u32)__builtin_ctzll(later); win = (gsl & sd_low_bits(j + 1)) != 0; }
+    else if (gsl) win = true;
+    else open = true;
+  }
+  // groups that run past the tile: the following tiles, the open lanes together
+  for (u32 nb = tb + 64; __ballot(open) != 0; nb += 64) {
+    if (nb >= n) { if (open) { win = true; open = false; } break; }
+    const u32 q = nb + lane;
+    const bool v2 = q < n;
+    VisRow x;
+    x.doc = AMH_NULL32; x.vis = false;
+    bool g2 = true;
+    if (v2) { x = vis_load(B, q); const VisRow px = vis_load(B, q - 1); g2 = !vis_same(B, px, x); }
+    const u64 VALID2 = __ballot(v2);
+    const u64 VIS2 = __ballot(x.vis), GS2 = __ballot(g2 && v2) | ~VALID2;
+    if (open) {
+      if (VIS2) { const u32 j = (u32)__builtin_ctzll(VIS2); win = (GS2 & sd_low_bits(j + 1)) != 0; open = false; }
+      else if (GS2) { win = true; open = false; }
+    }
+  }
+  if (valid) { B.r_visible[r] = me.vis ? 1 : 0; B.r_winner[r] = win ? 1 : 0; }
+}
+
 void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
   if (n == 0) return;
   hipStream_t s = (hipStream_t)stream;
@@ -815,6 +897,7 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
     }
     return;
   }
+  if (k == AK_VISIBLE) { hipLaunchKernelGGL(g_visible_seg, dim3((n + AMH_BLOCK - 1) / AMH_BLOCK), dim3(AMH_BLOCK), 0, s, B, n); return; }
   if (k == AK_ENCODE_SIZE) { launch_encode<false>(B, s); return; }
   if (k == AK_ENCODE_STORE) {
     launch_encode<true>(B, s);
@@ -1208,7 +1291,8 @@ __global__ void __launch_bounds__(AMH_BLOCK) g_copy_segments(const u64* src, con
   for (u32 k = threadIdx.x; k < n; k += AMH_BLOCK) d[k] = s[k];
 }
 // one block per segment, any alignment: dwords where source and destination share their phase, bytes otherwise
-__global__ void __launch_bounds__(AMH_BLOCK) g_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst) {
+template <class OFF>
+__global__ void __launch_bounds__(AMH_BLOCK) g_copy_bytes(const u64* src, const u32* len, const OFF* dst_off, u8* dst) {
   const u32 i = blockIdx.x;
   const u8* s = (const u8*)(uintptr_t)src[i];
   u8* d = dst + dst_off[i];
@@ -1229,7 +1313,11 @@ __global__ void __launch_bounds__(AMH_BLOCK) g_copy_bytes(const u64* src, const 
 }
 void amh_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst, u32 n, void* stream) {
   if (n == 0) return;
-  hipLaunchKernelGGL(g_copy_bytes, dim3(n), dim3(AMH_BLOCK), 0, (hipStream_t)stream, src, len, dst_off, dst);
+  hipLaunchKernelGGL((g_copy_bytes<u32>), dim3(n), dim3(AMH_BLOCK), 0, (hipStream_t)stream, src, len, dst_off, dst);
+}
+void amh_copy_bytes64(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void* stream) {
+  if (n == 0) return;
+  hipLaunchKernelGGL((g_copy_bytes<u64>), dim3(n), dim3(AMH_BLOCK), 0, (hipStream_t)stream, src, len, dst_off, dst);
 }
 void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void* stream) {
   if (n == 0) return;
@@ -1301,7 +1389,7 @@ static u32* g_scratch_ptr[AMH_NOALLOC_MAX_DEVICES];                // device add
 __global__ void g_sync_meta(const u32* total, u32 cap, u32* meta) {
   u32 t = *total;
   meta[0] = t;
-  meta[1] = t > cap ? 1u : 0u;
+  meta[1] = (t > cap || t == 0xFFFFFFFFu) ? 1u : 0u;   // does not fit, or the record offsets saturated (more than 4 GiB - 1 of records)
 }
 
 int amh_sync_noalloc_run(const BatchDev& B0, int device, u8* d_out, u32 cap, u32* d_meta, void* stream, const char** err) {

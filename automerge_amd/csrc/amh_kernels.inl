@@ -1965,7 +1965,8 @@ AMH_DEV void k_sync_size(const BatchDev& B, u32 d) {
 }
 AMH_DEV void sync_put32(u8* o, u32 v) { o[0] = (u8)v; o[1] = (u8)(v >> 8); o[2] = (u8)(v >> 16); o[3] = (u8)(v >> 24); }
 AMH_DEV void k_sync_fill(const BatchDev& B, u32 d) {
-  if (B.sync_cap && B.sync_off[d + 1] > B.sync_cap) return;   // caller-provided buffer too small (amh_sync_summaries_noalloc)
+  // caller-provided buffer too small, or the record offsets saturated (amh_sync_summaries_noalloc): nothing is written
+  if (B.sync_cap && (B.sync_off[d + 1] > B.sync_cap || B.sync_off[d + 1] == 0xFFFFFFFFu)) return;
   u8* o = B.sync_out + B.sync_off[d];
   u32 rec_len = B.sync_off[d + 1] - B.sync_off[d];
   sync_put32(o, d);

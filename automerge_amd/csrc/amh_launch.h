@@ -37,6 +37,7 @@ void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream);
 void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void* stream);
 // the same for segments of any alignment and length (change chunks into an out_arena)
 void amh_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst, u32 n, void* stream);
+void amh_copy_bytes64(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void* stream);   // 64-bit places
 // columns encoded over many waves (device build only; nothing when B.sv_nj == 0).  Save of very large documents:
 // phase 0 after AK_SAVE_SIZE (column lengths of the big columns), phase 1 after AK_SAVE_STORE (their bytes).  The
 // change re-encode of very large changes: phase 2 after AK_ENCODE_SIZE, phase 3 after AK_ENCODE_STORE.

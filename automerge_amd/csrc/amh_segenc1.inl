@@ -171,7 +171,10 @@ __device__ __forceinline__ void sc1_raw(Sc1Col& o, const ScRaw& v, u32 cnt, u32 
   }
 }
 
-// the walk: tiles of 64 values from the last to the first, the tile in front loaded one step ahead
+// the walk: tiles of 64 values from the last to the first.  The tile in front is loaded before the current one is
+// encoded: the step needs its last value anyway, and its gathers (ops_sorted -> row -> fields -> actor map, three or four
+// dependent loads) are in flight during the ballots and scans.  Two tiles ahead was measured: 18 more registers, one
+// wave per SIMD fewer, 4.77 -> 5.26 ms.
 template <class V, class Load, class Step>
 __device__ __forceinline__ void sc1_walk(u32 n, u32 lane, Load load, Step step) {
   if (n == 0) return;
@@ -194,11 +197,15 @@ struct Sc1Pred { u32 pa; u64 delta; };
 
 // MODE 0: every column into its slot, lengths -> c_col_len, columns that outgrew their slot -> c_wide.
 // MODE 1 (behind k_chg_layout): the flagged columns again, straight into the chunk.
-// blockIdx.y of gridDim.y deals the column groups over waves as in g_encode_seg.
+// The column groups of a change are dealt over `parts` workgroups (1 = one wave encodes all the columns of a change:
+// batches of smaller changes; SC_GROUPS = a wave per group).  The group is the FAST index of the grid: workgroups that
+// are resident together then work on different groups, so the waves that mostly wait for their gathers (object ids: every
+// tile a continued run) share a SIMD with the ones that mostly compute (keys, values) — with the group as the slow index
+// the launch ran group after group, 8.1 ms of group times against 4.8 ms; mixed: see DESIGN 5.
 template <int MODE>
-__global__ void __launch_bounds__(64 * SD_WAVES) g_encode_one(BatchDev B) {
+__global__ void __launch_bounds__(64 * SD_WAVES) g_encode_one(BatchDev B, u32 gmask, u32 parts) {
   const u32 wave = sd_uniform(threadIdx.x >> 6);
-  const u32 c = blockIdx.x * SD_WAVES + wave;
+  const u32 c = (blockIdx.x / parts) * SD_WAVES + wave;
   if (c >= B.tot_chg) return;
   const u32 lane = threadIdx.x & 63;
   u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
@@ -233,8 +240,8 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_encode_one(BatchDev B) {
     cl[k] = len;
     if (len > o.cap) atomicOr(&B.c_wide[c], 1u << k);
   };
-  const bool all = gridDim.y == 1;
-  for (u32 G = blockIdx.y; G < SC_GROUPS; G += gridDim.y) {
+  for (u32 G = blockIdx.x % parts; G < SC_GROUPS; G += parts) {
+    if (!((gmask >> G) & 1)) continue;   // (development: AMH_ENC_GMASK times the column groups one by one)
     if (MODE == 1) {   // groups without a flagged column
       const u32 gm = G == 0 ? 0x2003u : G == 1 ? 0x001Cu : G == 2 ? 0x1260u : G == 3 ? 0x0180u : 0x0C00u;
       if (!(flags & gm)) continue;
@@ -372,7 +379,6 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_encode_one(BatchDev B) {
       close(ca, 10, false); close(cc, 11, false);
     }
   }
-  (void)all;
 }
 
 // The columns from the tails of their slots to their places in the chunk (behind k_chg_layout; columns flagged in c_wide

@@ -184,10 +184,11 @@ int amh_merge_many(amh_ctx*, amh_batch* dst, const amh_batch* const* srcs, size_
  * changes[i] = one change chunk, plain or compressed (what Change::try_from takes, change.rs:161-180: the stored
  * checksum is not compared).  Changes the document already has are skipped; changes whose dependencies are missing
  * wait in the document's queue (amh_doc_queue_len) and apply when a later call brings the missing ones; save keeps
- * them behind the document chunk (retain_orphans).  Returns AMH_ERR_DOC_FAILED and leaves the document unchanged when
- * a chunk does not parse or a change repeats a sequence number (DuplicateSeqNumber: unlike the reference, which has
- * applied the changes in front of the offending one by then).  This is the n = 1 form of amh_apply_batch and, like
- * it, reloads the whole batch: apply to many documents with one amh_apply_batch call. */
+ * them behind the document chunk (retain_orphans).  Returns AMH_ERR_DOC_FAILED when a chunk does not parse (the
+ * document is unchanged) or a change repeats a sequence number (DuplicateSeqNumber: as in the reference,
+ * automerge.rs:804-812, the changes in front of the offending one stay applied and queued ones stay queued).  This is
+ * the n = 1 form of amh_apply_batch and, like it, reloads the whole batch: apply to many documents with one
+ * amh_apply_batch call. */
 int amh_apply_changes(amh_ctx*, amh_batch*, uint32_t doc, const uint8_t* const* changes, const size_t* lens, size_t n);
 /* Batched form.  Buffer i holds one or more concatenated chunks for document doc_idx[i]; several buffers may name
  * the same document: each buffer is one apply_changes / load_incremental call on it, in the order given (the queue
@@ -221,12 +222,14 @@ int amh_save_after(const amh_batch*, uint32_t doc, const uint8_t* heads32, size_
  * (sync.rs:243-250 make_bloom_filter with last_sync = [], sync/bloom.rs:38-47,69-90,125-146).
  * Record layout per document (little-endian): u32 doc, u32 status (0 = loaded), u32 n_heads,
  * heads[32 x n], u32 bloom_len, bloom bytes (BloomFilter::to_bytes: uleb n, uleb 10, uleb 7, bits).
- * The all-gather across ranks is done by the caller's torch.distributed group. */
+ * Across ranks: amh_sync_summaries_all below gathers the records of every rank inside the library (RCCL over xGMI). */
 int amh_sync_summaries(amh_ctx*, const amh_batch*, amh_bytes_out* out);
-/* No counterpart in the reference.  For callers that cannot allocate: code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc.  The records of amh_sync_summaries, byte for byte, written into the
+/* No counterpart in the reference.  For callers that cannot allocate: tight serving loops, harnesses that forbid
+ * hipMalloc, code between the captures of a HIP graph (the call itself runs on the context's own stream and waits for
+ * it, so it cannot be captured).  The records of amh_sync_summaries, byte for byte, written into the
  * caller's DEVICE buffer d_out (cap bytes); d_meta (device, 2 x u32) receives {total bytes of all records, 1 if cap
- * was too small}: a record that would end beyond cap is not written, the ones in front of it are.  The call allocates
+ * was too small, or the records exceed 4 GiB - 1: nothing is written then}: a record that would end beyond cap is not
+ * written, the ones in front of it are.  The call allocates
  * nothing on the host or the device (no pool, no event, no host copy): record offsets and scan temporaries live in a
  * static device array inside the library (4 MiB per GPU the library runs on, held until the process ends).
  * Limit: at most 1,048,576 documents in the batch (AMH_ERR_BATCH_TOO_LARGE beyond).  Calls on one GPU share that

@@ -55,6 +55,9 @@ void amh_launch_mg(int k, const MergeDev* G, u32 n, void*) {
 void amh_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst, u32 n, void*) {
   for (u32 i = 0; i < n; i++) memcpy(dst + dst_off[i], (const u8*)(uintptr_t)src[i], len[i]);
 }
+void amh_copy_bytes64(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void*) {
+  for (u32 i = 0; i < n; i++) memcpy(dst + dst_off[i], (const u8*)(uintptr_t)src[i], len[i]);
+}
 void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void*) {
   for (u32 i = 0; i < n; i++) memcpy(dst + dst_off[i], (const u8*)(uintptr_t)src[i], len[i]);
 }
