@@ -44,7 +44,7 @@ EXPORTS = [
     "amh_sync_summaries", "amh_ctx_set_profiling", "amh_ctx_num_kernels", "amh_ctx_kernel_name", "amh_ctx_kernel_time",
     "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free", "amh_apply_batch", "amh_doc_queue_len", "amh_merge_many", "amh_save_after",
     "amh_sync_summaries_noalloc", "amh_ctx_pool_bytes", "amh_ctx_set_limits", "amh_batch_release_ops", "amh_comm_unique_id", "amh_comm_init", "amh_sync_summaries_all",
-    "amh_partition_docs",
+    "amh_partition_docs", "amh_text_batch",
 ]
 
 DOC_ERRORS = {
@@ -98,6 +98,7 @@ def bind(lib):
                                       C.POINTER(BytesOut), C.POINTER(C.POINTER(C.c_uint64))]
     lib.amh_u64_free.argtypes = [C.POINTER(C.c_uint64)]
     lib.amh_sync_summaries.argtypes = [vp, vp, C.POINTER(BytesOut)]
+    lib.amh_text_batch.argtypes = [vp, vp, C.POINTER(BytesOut), C.POINTER(C.POINTER(C.c_uint64))]
     lib.amh_sync_summaries_noalloc.argtypes = [vp, vp, vp, C.c_size_t, vp]
     lib.amh_save_batch.argtypes = [vp, vp, C.POINTER(SaveOpts), C.POINTER(BytesOut)]
     lib.amh_merge_batch.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]
@@ -374,6 +375,24 @@ class Batch:
             res.append(C.string_at(outs[i].data, outs[i].len) if outs[i].data else None)
             self.engine.lib.amh_bytes_free(C.byref(outs[i]))
         return res
+
+    def text_all(self, decode=True):
+        """amh_text_batch: the text of every document (ReadDoc::text of its text objects, back to back).  decode=False
+        returns (bytes, offsets) without building Python strings."""
+        o = BytesOut()
+        offs = C.POINTER(C.c_uint64)()
+        rc = self.engine.lib.amh_text_batch(self.engine.ctx, self.h, C.byref(o), C.byref(offs))
+        if rc != 0:
+            raise EngineError(f"amh_text_batch failed: {rc} {self.engine._err()}")
+        n = self.n
+        raw = C.string_at(o.data, o.len) if o.len else b""
+        ofs = [offs[i] for i in range(n + 1)] if decode else None
+        total = offs[n]
+        self.engine.lib.amh_bytes_free(C.byref(o))
+        self.engine.lib.amh_u64_free(offs)
+        if not decode:
+            return raw, total
+        return [raw[ofs[i]:ofs[i + 1]].decode("utf-8") for i in range(n)]
 
     def sync_summaries_raw(self):
         """All sync summary records of the batch as one bytes object (amh_sync_summaries)."""

@@ -2007,8 +2007,11 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
     if (all_ok) {
       adopt_merged_arrays(mb, nb, m_arena);
     } else {
-      // A document merged from loaded documents always verifies: anything else is an engine bug, never a silent
-      // result.  A change handed to apply may not survive the document format (a pred naming no op, a non-canonical
+      // A document merged from loaded documents verifies whenever its changes are re-derived (amh_merge_batch,
+      // AMH_VERIFY_MERGE=1): anything else is an engine bug, never a silent result.  (amh_merge_many adopts the sources'
+      // chunks by default and re-derives nothing: there all_ok only says that linking found the rows well-formed; the
+      // row placement is then covered by the test suites, which run both modes against the oracle's saved bytes.)
+      // A change handed to apply may not survive the document format (a pred naming no op, a non-canonical
       // encoding: the reference's own save + load rejects such a document too): those documents are left as they
       // were, and the rest goes through the saved form.
       if (!ap) { set_error(ctx, std::string(who) + ": a merged document failed verification"); amh_batch_free(nb); return AMH_ERR_DEVICE; }
@@ -3468,6 +3471,48 @@ extern "C" int amh_partition_docs(const size_t* lens, size_t n, int world, size_
   first[world] = n;
   return AMH_SUCCESS;
 }
+// == ReadDoc::text for every document of the batch at once (read.rs; OpSet::text op_set.rs:307-311, OpType::to_str
+// types.rs:278-286): per document the text of its text objects (in document order, back to back: a document with one text
+// object — the shape of BASELINE.json configs[2] / [3] — gives exactly text(obj)).  Winners come from the load's
+// visibility pass; per row the bytes it contributes, one scan, one fill.  out = the texts back to back (UTF-8),
+// offsets[n_docs + 1] = where each document's text starts (freed with amh_bytes_free / amh_u64_free); a failed document
+// has an empty text.
+extern "C" int amh_text_batch(amh_ctx* ctx, const amh_batch* bc, amh_bytes_out* out, uint64_t** offsets) {
+  if (!ctx || !bc || !out || !offsets) { set_error(ctx, "amh_text_batch: invalid argument"); return AMH_ERR_INVALID_ARG; }
+  AMH_NEEDS_OPS(bc, "amh_text_batch")
+  amh_batch* b = const_cast<amh_batch*>(bc);
+  BatchDev B = b->B;
+  const u32 n = B.n_docs;
+  out->data = nullptr; out->len = 0; *offsets = nullptr;
+  uint64_t* offs = (uint64_t*)calloc((size_t)n + 1, sizeof(uint64_t));
+  if (!offs) return AMH_ERR_OOM;
+  if (n == 0 || B.tot_rows == 0) { out->data = (uint8_t*)malloc(1); *offsets = offs; return out->data ? AMH_SUCCESS : AMH_ERR_OOM; }
+  bool ok = true;
+  CallScratch scratch(b);
+  B.tx_off = balloc<u32>(b, (size_t)B.tot_rows + 2, &ok);
+  B.tx_doc = balloc<u32>(b, (size_t)n + 2, &ok);
+  if (!ok) { free(offs); set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  launch(ctx, AK_TEXT_LEN, B, B.tot_rows);
+  u32 total = 0;
+  if (!scan_inplace(b, B.tx_off, B.tot_rows, &total) || !rt_sync(ctx->stream)) { free(offs); set_error(ctx, "scan failed"); return AMH_ERR_DEVICE; }
+  if (total == 0xFFFFFFFFu) { free(offs); set_error(ctx, "amh_text_batch: the texts of the batch exceed 4 GiB"); return AMH_ERR_BATCH_TOO_LARGE; }
+  B.tx_out = balloc<u8>(b, (size_t)total + 64, &ok);
+  if (!ok) { free(offs); set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  launch(ctx, AK_TEXT_FILL, B, B.tot_rows);
+  launch(ctx, AK_TEXT_DOC, B, n + 1);
+  std::vector<u32> doc32((size_t)n + 1);
+  out->data = (uint8_t*)malloc(total ? total : 1);
+  if (!out->data) { free(offs); return AMH_ERR_OOM; }
+  if (!rt_d2h(doc32.data(), B.tx_doc, ((size_t)n + 1) * sizeof(u32), ctx->stream) || (total && !rt_d2h(out->data, B.tx_out, total, ctx->stream)) || !rt_sync(ctx->stream)) {
+    free(out->data); out->data = nullptr; free(offs); set_error(ctx, "D2H copy failed"); return AMH_ERR_DEVICE;
+  }
+  for (u32 d = 0; d <= n; d++) offs[d] = doc32[d];
+  out->len = total;
+  *offsets = offs;
+  collect_profile(ctx);
+  return AMH_SUCCESS;
+}
+
 // The records of amh_sync_summaries written into the caller's device buffer, with nothing allocated on the host or the
 // device: no pool, no event, no copy to the host (include/automerge_hip.h).  Queues the kernels on the context's own
 // stream and waits for them (hipStreamSynchronize allocates nothing), so d_out / d_meta are complete on return; because

@@ -1946,6 +1946,44 @@ AMH_DEV void k_visible(const BatchDev& B, u32 r) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K18b  text materialization — ReadDoc::text = OpSet::text (op_set.rs:307-311): the winners of a text object's elements
+//       in document order, each as OpType::to_str (types.rs:278-286): a string value as it is, any other visible value
+//       (numbers, nested objects, ...) as U+FFFC; marks are never visible.  Thread per row: bytes the row contributes
+//       (k_text_len; scanned), then the bytes (k_text_fill); k_text_doc (thread per document) notes where every document's
+//       text starts.  A document's text = the texts of its text objects in document order, back to back.
+// ------------------------------------------------------------------------------------------
+AMH_DEV u32 text_row_len(const BatchDev& B, u32 r, bool& is_str) {
+  is_str = false;
+  if (!B.r_winner[r]) return 0;
+  const u32 d = B.r_doc[r];
+  const u32 oc = B.r_obj_ctr[r];
+  if (oc == 0) return 0;   // the root is a map
+  const u32 mk = ht_find(B, d, pack_id(oc, B.r_obj_actor[r]));
+  if (mk == AMH_EMPTY32 || B.r_action[mk] != 4) return 0;   // not a text object
+  if (B.r_action[r] == 1 && (B.r_vmeta[r] & 15) == 6) { is_str = true; return (u32)(B.r_vmeta[r] >> 4); }
+  return 3;   // U+FFFC
+}
+AMH_DEV void k_text_len(const BatchDev& B, u32 r) {
+  bool is_str;
+  B.tx_off[r] = B.status[B.r_doc[r]] ? 0 : text_row_len(B, r, is_str);
+}
+AMH_DEV void k_text_fill(const BatchDev& B, u32 r) {
+  const u32 n = B.tx_off[r + 1] - B.tx_off[r];
+  if (n == 0) return;
+  bool is_str;
+  text_row_len(B, r, is_str);
+  u8* o = B.tx_out + B.tx_off[r];
+  if (is_str) {
+    const DocDesc& D = B.desc[B.r_doc[r]];
+    const u8* p = B.arena + D.chunk_off + D.ocol[OC_VAL_RAW].off + B.r_vraw_off[r];
+    for (u32 i = 0; i < n; i++) o[i] = p[i];
+  } else { o[0] = 0xEF; o[1] = 0xBF; o[2] = 0xBC; }
+}
+AMH_DEV void k_text_doc(const BatchDev& B, u32 d) {   // d in [0, n_docs]
+  B.tx_doc[d] = d < B.n_docs ? B.tx_off[B.row_base[d]] : B.tx_off[B.tot_rows];
+}
+
+// ------------------------------------------------------------------------------------------
 // K19  sync summaries: sorted heads (automerge.rs:1300-1304) and the Bloom filter over every change
 //      hash of the document (sync.rs:243-250 with last_sync = [], sync/bloom.rs:9-10, 38-47, 69-102,
 //      125-146).  Record: u32 doc, u32 status, u32 n_heads, heads[32 x n], u32 bloom_len, bloom bytes.

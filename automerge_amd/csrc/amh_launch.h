@@ -6,12 +6,12 @@
 enum AmhKernel {
   AK_PARSE = 0, AK_SHA_DOC, AK_COUNT, AK_EXTRACT, AK_ACTORS, AK_CHG_INIT, AK_DECODE_CHG, AK_DECODE_OPS, AK_ROWS,
   AK_OBJ_ORDER, AK_SUCC, AK_BUCKET, AK_CHG_FINISH, AK_PLACE, AK_PRED_SLOT_CNT, AK_PRED_SLOT_BASE, AK_PRED_FILL, AK_PRED_SORT, AK_ACTOR_MARK,
-  AK_ACTOR_RANK, AK_CHANGE_VIEW, AK_ENCODE_SIZE, AK_CHG_LAYOUT, AK_ENCODE_STORE, AK_CHG_HEADER, AK_CHG_HASH, AK_CHG_HASH_SEQ, AK_HEADS, AK_VISIBLE, AK_SYNC_SIZE, AK_SYNC_FILL, AK_SAVE_CHECK, AK_SAVE_SIZE, AK_SAVE_LAYOUT, AK_SAVE_STORE, AK_SAVE_FINISH, AK_HT_SIZE, AK_DT_SIZE, AK_SUCC_LINK, AK_SCAN, AK_M_INIT, AK_ROWS_M, AK_VERIFY_HASH, AK_DECODE_CHG_COLS, AK_CHG_PATCH, AK_ATAB_BASE, AK_ATAB_FILL, AK_NUM
+  AK_ACTOR_RANK, AK_CHANGE_VIEW, AK_ENCODE_SIZE, AK_CHG_LAYOUT, AK_ENCODE_STORE, AK_CHG_HEADER, AK_CHG_HASH, AK_CHG_HASH_SEQ, AK_HEADS, AK_VISIBLE, AK_SYNC_SIZE, AK_SYNC_FILL, AK_SAVE_CHECK, AK_SAVE_SIZE, AK_SAVE_LAYOUT, AK_SAVE_STORE, AK_SAVE_FINISH, AK_HT_SIZE, AK_DT_SIZE, AK_SUCC_LINK, AK_SCAN, AK_M_INIT, AK_ROWS_M, AK_VERIFY_HASH, AK_DECODE_CHG_COLS, AK_CHG_PATCH, AK_ATAB_BASE, AK_ATAB_FILL, AK_TEXT_LEN, AK_TEXT_FILL, AK_TEXT_DOC, AK_NUM
 };
 static const char* const AMH_KERNEL_NAMES[AK_NUM] = {
   "parse", "sha_doc", "count", "extract", "actors", "chg_init", "decode_chg", "decode_ops", "rows",
   "obj_order", "succ", "bucket", "chg_finish", "place", "pred_slot_cnt", "pred_slot_base", "pred_fill", "pred_sort", "actor_mark",
-  "actor_rank", "change_view", "encode_size", "chg_layout", "encode_store", "chg_header", "chg_hash", "chg_hash_seq", "heads", "visible", "sync_size", "sync_fill", "save_check", "save_size", "save_layout", "save_store", "save_finish", "ht_size", "dt_size", "succ_link", "scan", "m_init", "rows_m", "verify_hash", "decode_chg_cols", "chg_patch", "atab_base", "atab_fill"};
+  "actor_rank", "change_view", "encode_size", "chg_layout", "encode_store", "chg_header", "chg_hash", "chg_hash_seq", "heads", "visible", "sync_size", "sync_fill", "save_check", "save_size", "save_layout", "save_store", "save_finish", "ht_size", "dt_size", "succ_link", "scan", "m_init", "rows_m", "verify_hash", "decode_chg_cols", "chg_patch", "atab_base", "atab_fill", "text_len", "text_fill", "text_doc"};
 
 // run kernel `k` over n threads
 void amh_launch(int k, const BatchDev& B, u32 n, void* stream);

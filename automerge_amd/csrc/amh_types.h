@@ -197,6 +197,9 @@ struct BatchDev {
   u32* sync_off;                 // [n_docs + 1] record offsets of the sync summaries
   u8* sync_out;
   u32 sync_cap;                  // 0 = sync_out holds every record; else its capacity: records that end beyond it are not written
+  u32* tx_off;                   // [tot_rows + 1] amh_text_batch: bytes every row contributes to its document's text, then their exclusive sums
+  u32* tx_doc;                   // [n_docs + 1] where every document's text starts in tx_out
+  u8* tx_out;
   // lists too long for the thread that owns them (more than AMH_BIG_LIST entries): the thread-per-item kernel records
   // them here and a block per list sorts them afterwards (amh_kernels.hip, g_big_*)
   const u8* expect_hash;         // [tot_chg * 32] merge / apply: the hashes the changes of a merged document came with (k_verify_hash)

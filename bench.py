@@ -145,6 +145,8 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
         del blob, reps
     t_gen = time.time() - t0
 
+    text_s, text_total = [0.0], [0]
+
     def step(keep_stats=False):
         ops = 0
         stats = []
@@ -165,8 +167,13 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
             else:   # the same result (history order included) with one pass over the rows
                 rc = batches[0].merge_many(batches[1:], ids, [ids] * (R - 1))
                 assert rc == 0, rc
+            # ... + materialize text: ReadDoc::text of every merged document, on the device, brought to the host
+            tt = time.perf_counter()
+            _, text_bytes = batches[0].text_all(decode=False)
+            text_s[0] += time.perf_counter() - tt
+            text_total[0] = text_bytes
             st = batches[0].stats()
-            assert st["n_ok"] == hi - lo
+            assert st["n_ok"] == hi - lo and text_bytes > 0
             ops += st["ops_loaded"]
             if keep_stats:
                 stats[-1].append((st, column_bytes(eng, batches[0], hi - lo)))
@@ -182,11 +189,13 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
     for _ in range(args.warmup):
         step()
     barrier()
+    text_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ops, _ = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    text_ms = text_s[0] / args.steps * 1e3
     # one more, profiled step: HIP events around every kernel launch on the pipeline's own stream
     eng.set_profiling(True)
     eng.reset_profile()
@@ -237,7 +246,8 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
         out = {"metric": "ops loaded+merged/sec (node)", "value": ops_all * args.steps / elapsed_max, "unit": "ops/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64", "data": "synthetic",
-               "config": {"workload": f"configs[2]: {args.docs} text documents x {R} divergent replicas of 5k concurrent inserts/deletes per GPU, load {R} + merge {R - 1}",
+               "config": {"workload": f"configs[2]: {args.docs} text documents x {R} divergent replicas of 5k concurrent inserts/deletes per GPU, load {R} + merge {R - 1} + materialize text",
+                          "text_ms_per_step": round(text_ms, 2), "text_bytes_per_step": text_total[0],
                           "docs_per_gpu": args.docs, "replicas": R, "ops_per_merged_doc": ops / args.docs, "encoded_bytes_per_gpu": enc_bytes,
                           "slices_per_step": n_slices, "docs_per_slice": args.slice, "sharding": f"documents x{world} (replicas of a document co-located)",
                           "merge_call": "sequential amh_merge_batch" if args.sequential_merges else "amh_merge_many", "gen_s": round(t_gen, 2),

@@ -163,6 +163,12 @@ int amh_changes(const amh_batch*, uint32_t doc, amh_change_view* out, size_t* n)
 /* canonical materialization for parity == hydrate / get_all (automerge/src/hydrate.rs:128-167,
  * automerge.rs:1528-1565, iter/top_ops.rs:43-102); format in DESIGN.md */
 int amh_hydrate_json(const amh_batch*, uint32_t doc, amh_bytes_out* out);
+/* == ReadDoc::text (read.rs; OpSet::text op_set.rs:307-311, OpType::to_str types.rs:278-286) for every document of the
+ * batch at once: the winners of the text objects' elements in document order, string values as they are, any other
+ * visible value as U+FFFC.  A document's text = the texts of its text objects in document order, back to back (one
+ * text object per document, as in BASELINE.json configs[2] / [3]: exactly text(obj)).  out = all texts back to back
+ * (UTF-8), offsets[n_docs + 1] = where each document's starts; freed with amh_bytes_free / amh_u64_free. */
+int amh_text_batch(amh_ctx*, const amh_batch*, amh_bytes_out* out, uint64_t** offsets);
 /* max op counter of the document (Automerge::max_op, automerge.rs:181) */
 int amh_doc_max_op(const amh_batch*, uint32_t doc, uint64_t* max_op);
 
@@ -176,8 +182,14 @@ int amh_merge_batch(amh_ctx*, amh_batch* dst, const amh_batch* src, const uint32
 /* == dst.merge(&mut s0); dst.merge(&mut s1); ... per pair with ONE pass over the rows (same result, history order
  * included, as the sequential amh_merge_batch calls: the changes each source adds, automerge.rs:1311-1334, go through
  * the apply path as one apply_changes call per source).  src_idx[s * n_pairs + p] = document of srcs[s] merged into
- * dst[dst_idx[p]], or 0xFFFFFFFF for none.  Built for configs[2] (8 replicas per document): rows are placed, saved and
- * re-verified once instead of 7 times.  On DuplicateSeqNumber in any source the document is left untouched. */
+ * dst[dst_idx[p]], or 0xFFFFFFFF for none.  Built for configs[2] (8 replicas per document): rows are placed once instead
+ * of 7 times.  A source whose added changes repeat an (actor, seq) of the document ends that document's merges where
+ * the reference's sequential calls would (DuplicateSeqNumber from the middle of apply_changes, automerge.rs:804-812):
+ * the sources in front of it and its own changes in front of the offender stay applied, later sources are not merged,
+ * and the call returns AMH_ERR_DOC_FAILED (tests/merge_cases.py check_merge_many_duplicate_seq, against the oracle).
+ * History: when every source is a loaded batch, the merged document ADOPTS the sources' change chunks and hashes (each
+ * was re-derived from its ops and hashed when its source was loaded), as the reference's merge keeps the stored
+ * changes; they are not derived again from the merged rows unless AMH_VERIFY_MERGE=1 is set (the test suites run both). */
 int amh_merge_many(amh_ctx*, amh_batch* dst, const amh_batch* const* srcs, size_t n_srcs, const uint32_t* dst_idx,
                    const uint32_t* src_idx, size_t n_pairs);
 /* == Automerge::apply_changes (automerge.rs:785-858; AMapplyChanges, automerge-c/src/doc.rs:84) on one document:

@@ -6,7 +6,7 @@ import struct
 
 import oracle_lib as o
 
-MAKE_MAP, SET, MAKE_LIST, DEL, MAKE_TEXT, INC = 0, 1, 2, 3, 4, 5
+MAKE_MAP, SET, MAKE_LIST, DEL, MAKE_TEXT, INC, MAKE_TABLE, MARK = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 def uleb(n):
@@ -52,10 +52,26 @@ def v_counter(n):
     return (len(raw) << 4) | 8, raw
 
 
-def op(action, obj=None, key=None, elem=None, insert=False, value=None, pred=()):
+def v_null():
+    return 0, b""
+
+
+def v_bool(b):
+    return (2 if b else 1), b""
+
+
+def op(action, obj=None, key=None, elem=None, insert=False, value=None, pred=(), expand=False, mark_name=None):
     """obj: None (root) or (ctr, actor index); key: map key, or elem: (ctr, actor index) with (0, None) = HEAD;
-    value: (meta, raw) from v_*; pred: [(ctr, actor index)].  Actor index 0 is the change's author."""
-    return dict(action=action, obj=obj, key=key, elem=elem, insert=insert, value=value, pred=list(pred))
+    value: (meta, raw) from v_*; pred: [(ctr, actor index)].  Actor index 0 is the change's author.
+    Marks (marks.rs, transaction/inner.rs:716-735): two insert ops of action MARK in a sequence — the begin carries
+    mark_name, the value and expand = "expand before"; the end carries no name, no value and expand = "expand after"."""
+    return dict(action=action, obj=obj, key=key, elem=elem, insert=insert, value=value, pred=list(pred), expand=expand, mark_name=mark_name)
+
+
+def mark_ops(obj, start_elem, end_elem, name, value, expand_before=False, expand_after=False):
+    """the op pair of Transaction::mark: begin inserted behind start_elem, end behind end_elem"""
+    return [op(MARK, obj=obj, elem=start_elem, insert=True, value=value, expand=expand_before, mark_name=name),
+            op(MARK, obj=obj, elem=end_elem, insert=True, expand=expand_after)]
 
 
 def build_change(actor, seq, start_op, deps, ops, others=(), time=0, message=b""):
@@ -77,6 +93,9 @@ def build_change(actor, seq, start_op, deps, ops, others=(), time=0, message=b""
     add(112, o.codec_encode(0, [len(p["pred"]) for p in ops]))
     add(113, o.codec_encode(0, [a for p in ops for (_, a) in p["pred"]]))
     add(115, o.codec_encode(1, [c for p in ops for (c, _) in p["pred"]]))
+    add(148, o.codec_encode(4, [p.get("expand", False) for p in ops]))                      # 0x94 expand (MaybeBoolean)
+    if any(p.get("mark_name") is not None for p in ops):
+        add(165, o.codec_encode(3, [p.get("mark_name") for p in ops]))                       # 0xA5 mark name
     body = bytearray()
     body += uleb(len(deps))
     for d in sorted(deps):

@@ -18,6 +18,7 @@ void amh_launch(int k, const BatchDev& B, u32 n, void*) {
     L(AK_PRED_SORT, k_pred_sort) L(AK_ACTOR_MARK, k_actor_mark) L(AK_ACTOR_RANK, k_actor_rank) L(AK_CHANGE_VIEW, k_change_view)
     L(AK_ENCODE_SIZE, k_encode_size) L(AK_CHG_LAYOUT, k_chg_layout) L(AK_ENCODE_STORE, k_encode_store)
     L(AK_CHG_HEADER, k_chg_header) L(AK_CHG_HASH, k_chg_hash) L(AK_CHG_HASH_SEQ, k_chg_hash_seq) L(AK_HEADS, k_heads) L(AK_SYNC_SIZE, k_sync_size) L(AK_SYNC_FILL, k_sync_fill) L(AK_SAVE_CHECK, k_save_check) L(AK_SAVE_SIZE, k_save_size) L(AK_SAVE_LAYOUT, k_save_layout) L(AK_SAVE_STORE, k_save_store) L(AK_SAVE_FINISH, k_save_finish) L(AK_VISIBLE, k_visible) L(AK_HT_SIZE, k_ht_size) L(AK_DT_SIZE, k_dt_size) L(AK_SUCC_LINK, k_succ_link) L(AK_M_INIT, k_m_init) L(AK_ROWS_M, k_rows_m) L(AK_VERIFY_HASH, k_verify_hash)
+    L(AK_TEXT_LEN, k_text_len) L(AK_TEXT_FILL, k_text_fill) L(AK_TEXT_DOC, k_text_doc)
     default: break;
   }
 #undef L

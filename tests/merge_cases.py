@@ -117,3 +117,49 @@ def check_merge_into_queued(engine, docs_pairs):
         assert bd.get_heads(i) == ref.get_heads(), i
         assert [c["hash"] for c in bd.get_changes(i)] == [c["hash"] for c in ref.changes()], i
         assert saved[i] == ref.save(deflate=False), i
+
+
+def check_merge_many_duplicate_seq(engine):
+    """amh_merge_many where the SECOND of three sources holds a change that repeats an (actor, seq) of the document with
+    other content.  The sequential reference merges: merge(s0) succeeds, merge(s1) returns DuplicateSeqNumber from the
+    middle of apply_changes (automerge.rs:804-812) with the changes in front of the offender applied, and a caller that
+    stops at the error never merges s2.  amh_merge_many hands every source over as one apply_changes call and stops the
+    same way: the document equals the oracle's after merge(s0) + the failed merge(s1); a second document of the same call
+    merges all three of its (clean) sources."""
+    from change_builder import SET, actor_id, build_change, op, v_uint
+    a0, a1, a2, a3 = (actor_id(i) for i in range(4))
+    c0, h0 = build_change(a0, 1, 1, [], [op(SET, key="a", value=v_uint(1))])
+    c1, h1 = build_change(a0, 2, 2, [h0], [op(SET, key="b", value=v_uint(2))])
+    A, hA = build_change(a1, 1, 2, [h0], [op(SET, key="s0", value=v_uint(10))])                 # source 0: clean
+    G, hG = build_change(a2, 1, 2, [h0], [op(SET, key="s1", value=v_uint(11))])                 # source 1: a good change ...
+    D, _ = build_change(a0, 2, 2, [h0], [op(SET, key="z", value=v_uint(26))])                   # ... and (a0, seq 2) again, other content
+    B, _ = build_change(a3, 1, 2, [h0], [op(SET, key="s2", value=v_uint(12))])                  # source 2: clean, never reached
+
+    def doc(chs):
+        d = o.Doc(); d.apply_changes(chs)
+        return d.save(deflate=False)
+
+    dst, s0, s1, s2 = doc([c0, c1]), doc([c0, A]), doc([c0, G, D]), doc([c0, B])
+    s1_clean = doc([c0, G])
+    ref = o.Doc.load(dst)
+    ref.merge(o.Doc.load(s0))
+    try:
+        ref.merge(o.Doc.load(s1))
+        raise AssertionError("the oracle accepted a duplicate seq number")
+    except o.OracleError as e:
+        assert o.KINDS.get(e.kind) == "duplicate_seq", e
+    ref_ok = o.Doc.load(dst)
+    for s in (s0, s1_clean, s2):
+        ref_ok.merge(o.Doc.load(s))
+    bd = engine.load_batch([dst, dst])
+    srcs = [engine.load_batch([s0, s0]), engine.load_batch([s1, s1_clean]), engine.load_batch([s2, s2])]
+    rc = bd.merge_many(srcs, [0, 1], [[0, 1]] * 3)
+    assert rc != 0, "a duplicate seq number must be reported"
+    import apply_cases as ac
+    ac.check_doc(bd, 0, ref)
+    ac.check_doc(bd, 1, ref_ok)
+    saved = bd.save_all(deflate=False)
+    assert saved[0] == ref.save(deflate=False) and saved[1] == ref_ok.save(deflate=False)
+    for b in srcs:
+        b.close()
+    bd.close()

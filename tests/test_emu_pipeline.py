@@ -192,7 +192,14 @@ def test_merge_text_replicas(emu):
         cur = bd.save_all(deflate=False)
 
 
-def test_merge_many_replicas_in_one_pass(emu):
+@pytest.mark.parametrize("history", ["adopted", "re-derived"])
+def test_merge_many_replicas_in_one_pass(emu, monkeypatch, history):
+    """history = adopted: the merged documents keep their sources' change chunks and hashes (the default when every
+    source is a loaded batch); re-derived (AMH_VERIFY_MERGE=1): every change is re-encoded from the MERGED rows, hashed
+    and compared with the hash it came with, so a row the merge put in the wrong place cannot go unnoticed.  Both ways
+    the saved bytes are compared with the oracle's."""
+    if history == "re-derived":
+        monkeypatch.setenv("AMH_VERIFY_MERGE", "1")
     from merge_cases import check_merge_many, split_map_doc
     n_docs, n_rep = 4, 6
     blob, offs = emu.gen_text_docs(0xE171, n_docs, n_rep, 60, 240, 40, 2)
@@ -200,6 +207,11 @@ def test_merge_many_replicas_in_one_pass(emu):
     blob, offs = emu.gen_map_docs(47, 3, 4, 5, 30, 24, 2)
     halves = [split_map_doc(bytes(blob[offs[i]:offs[i + 1]])) for i in range(3)]
     check_merge_many(emu, [[a for a, _ in halves], [b for _, b in halves], [bytes(blob[offs[i]:offs[i + 1]]) for i in range(3)]])
+
+
+def test_merge_many_stops_at_a_duplicate_seq_like_sequential_merges(emu):
+    from merge_cases import check_merge_many_duplicate_seq
+    check_merge_many_duplicate_seq(emu)
 
 
 def test_merge_into_documents_with_queued_changes(emu):
@@ -310,6 +322,34 @@ def test_adversarial_shapes_small(emu, name, args):
     """the shapes of tests/test_gpu_adversarial.py at sizes the thread-by-thread emulation runs quickly"""
     import adversarial_cases as adv
     adv.check_case(emu, adv.CASES[name](*args))
+
+
+def test_text_of_every_document(emu, golden_dir):
+    """amh_text_batch == ReadDoc::text: text replicas with deletes and concurrent inserts, merged documents, documents with
+    marks and non-string elements, map documents (no text), a failed document"""
+    import mark_cases
+    import text_cases
+    blob, offs = emu.gen_text_docs(0x7E87, 3, 3, 80, 400, 50, 2)
+    docs = [bytes(blob[offs[i]:offs[i + 1]]) for i in range(9)]
+    chunks = mark_cases.marked_text()
+    import oracle_lib as orc
+    ref = orc.Doc(); ref.apply_changes(chunks)
+    docs.append(ref.save(deflate=False))
+    blob, offs = emu.gen_map_docs(5, 2, 3, 3, 20, 16, 1)
+    docs += [bytes(blob[offs[i]:offs[i + 1]]) for i in range(2)] + [b"\x85\x6f\x4a\x83junk"]
+    docs += [open(f, "rb").read() for f in sorted(glob.glob(os.path.join(golden_dir, "docs", "*.automerge")))[:12]]
+    text_cases.check_texts(emu, docs)
+    # merged replicas
+    bs = [emu.load_batch([docs[r], docs[3 + r]]) for r in range(3)]
+    assert bs[0].merge_many(bs[1:], [0, 1], [[0, 1]] * 2) == 0
+    merged = bs[0].save_all(deflate=False)
+    assert bs[0].text_all() == [text_cases.oracle_texts(m) for m in merged]
+
+
+def test_mark_ops(emu):
+    """mark ops through every route of the host build against the oracle (tests/mark_cases.py)"""
+    import mark_cases
+    mark_cases.check_marks(emu)
 
 
 def test_hostile_documents_fail_alone(emu):
