@@ -44,7 +44,7 @@ EXPORTS = [
     "amh_sync_summaries", "amh_ctx_set_profiling", "amh_ctx_num_kernels", "amh_ctx_kernel_name", "amh_ctx_kernel_time",
     "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free", "amh_apply_batch", "amh_doc_queue_len", "amh_merge_many", "amh_save_after",
     "amh_sync_summaries_noalloc", "amh_ctx_pool_bytes", "amh_ctx_set_limits", "amh_batch_release_ops", "amh_comm_unique_id", "amh_comm_init", "amh_sync_summaries_all",
-    "amh_partition_docs", "amh_text_batch",
+    "amh_partition_docs", "amh_text_batch", "amh_text_batch_device",
 ]
 
 DOC_ERRORS = {
@@ -99,6 +99,7 @@ def bind(lib):
     lib.amh_u64_free.argtypes = [C.POINTER(C.c_uint64)]
     lib.amh_sync_summaries.argtypes = [vp, vp, C.POINTER(BytesOut)]
     lib.amh_text_batch.argtypes = [vp, vp, C.POINTER(BytesOut), C.POINTER(C.POINTER(C.c_uint64))]
+    lib.amh_text_batch_device.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]
     lib.amh_sync_summaries_noalloc.argtypes = [vp, vp, vp, C.c_size_t, vp]
     lib.amh_save_batch.argtypes = [vp, vp, C.POINTER(SaveOpts), C.POINTER(BytesOut)]
     lib.amh_merge_batch.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]
@@ -393,6 +394,15 @@ class Batch:
         if not decode:
             return raw, total
         return [raw[ofs[i]:ofs[i + 1]].decode("utf-8") for i in range(n)]
+
+    def text_device(self):
+        """amh_text_batch_device: the texts stay in device memory; returns (device address of the texts, device address of
+        the u32 offsets, total bytes)"""
+        d_text, d_off, total = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        rc = self.engine.lib.amh_text_batch_device(self.engine.ctx, self.h, C.byref(d_text), C.byref(d_off), C.byref(total))
+        if rc != 0:
+            raise EngineError(f"amh_text_batch_device failed: {rc} {self.engine._err()}")
+        return d_text.value, d_off.value, total.value
 
     def sync_summaries_raw(self):
         """All sync summary records of the batch as one bytes object (amh_sync_summaries)."""

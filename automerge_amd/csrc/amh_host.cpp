@@ -185,6 +185,8 @@ struct amh_batch {
   mutable std::string msg_buf;
   u32 tot_ht = 0, tot_map = 0, tot_out = 0;
   bool history_only = false;   // amh_batch_release_ops: the per-op arrays are gone, the history (changes, hashes, heads) stays
+  DevAlloc text_out, text_doc; // amh_text_batch_device: the texts of the last call, kept until the next one or until the batch is freed
+  u64 text_total = 0;
   mutable HostView hv;
   // changes waiting for their dependencies (Automerge::queue, automerge.rs:168): raw chunks per document
   std::unordered_map<u32, std::vector<std::vector<u8>>> queue;
@@ -402,6 +404,8 @@ extern "C" void amh_staged_free(amh_staged* s) { staged_unref(s); }
 extern "C" void amh_batch_free(amh_batch* b) {
   if (!b) return;
   for (auto& a : b->allocs) b->ctx->pool.release(a.p, a.cap);
+  if (b->text_out.p) b->ctx->pool.release(b->text_out.p, b->text_out.cap);
+  if (b->text_doc.p) b->ctx->pool.release(b->text_doc.p, b->text_doc.cap);
   staged_unref(b->staged);
   delete b;
 }
@@ -882,6 +886,22 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
     if (!ok) return fail("device out of memory");
     launch(ctx, AK_CHANGE_VIEW, B, tot_ops);
   }
+  auto launch_visible = [&]() {
+    if (getenv("AMH_VISIBLE_MAIN")) {
+      launch(ctx, AK_VISIBLE, B, B.tot_rows);
+      rt_event_record(&ctx->ev_join, ctx->stream);
+    } else {
+      rt_event_record(&ctx->ev_fork2, ctx->stream);
+      rt_stream_wait(ctx->side, &ctx->ev_fork2);
+      launch_on(ctx, ctx->side, AK_VISIBLE, B, B.tot_rows);
+      rt_event_record(&ctx->ev_join, ctx->side);
+    }
+  };
+  // batches of small changes: the lane-per-change encoders are bound by instruction issue and leave the memory system
+  // idle, so visibility runs beside them (as in round 2); the one-pass encoder is bound by the memory system itself:
+  // there visibility runs beside the hashing instead (below)
+  const bool visible_early = B.enc_tmp == nullptr;
+  if (visible_early) launch_visible();
   launch(ctx, AK_ENCODE_SIZE, B, B.tot_chg * AMH_NCOLS);
   save_big_launch(ctx, B, 2);
   launch(ctx, AK_CHG_LAYOUT, B, B.tot_chg);
@@ -904,15 +924,7 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
   // dependency level, a lane per change — a chain of launches that each occupy a fraction of the SIMDs and leave the memory
   // system idle (round 2 ran it beside the change encode; the one-pass encoder is bound by the memory system itself and
   // the pair then took as long as one after the other).  AMH_VISIBLE_MAIN=1: on the main stream, for its standalone time.
-  if (getenv("AMH_VISIBLE_MAIN")) {
-    launch(ctx, AK_VISIBLE, B, B.tot_rows);
-    rt_event_record(&ctx->ev_join, ctx->stream);
-  } else {
-    rt_event_record(&ctx->ev_fork2, ctx->stream);
-    rt_stream_wait(ctx->side, &ctx->ev_fork2);
-    launch_on(ctx, ctx->side, AK_VISIBLE, B, B.tot_rows);
-    rt_event_record(&ctx->ev_join, ctx->side);
-  }
+  if (!visible_early) launch_visible();
   // hash the changes level by level: every change of a level only needs hashes of earlier levels
   B.lvl_order = balloc<u32>(b, (size_t)B.tot_chg + 1, &ok);
   B.lvl_start = balloc<u32>(b, AMH_LEVEL_CAP_HOST + 4, &ok);
@@ -3477,39 +3489,66 @@ extern "C" int amh_partition_docs(const size_t* lens, size_t n, int world, size_
 // visibility pass; per row the bytes it contributes, one scan, one fill.  out = the texts back to back (UTF-8),
 // offsets[n_docs + 1] = where each document's text starts (freed with amh_bytes_free / amh_u64_free); a failed document
 // has an empty text.
+// the texts into device memory owned by the batch (b->text_out / text_doc); total bytes in b->text_total
+static int text_to_device(amh_ctx* ctx, amh_batch* b) {
+  BatchDev B = b->B;
+  const u32 n = B.n_docs;
+  if (b->text_out.p) { ctx->pool.release(b->text_out.p, b->text_out.cap); b->text_out = DevAlloc(); }
+  if (b->text_doc.p) { ctx->pool.release(b->text_doc.p, b->text_doc.cap); b->text_doc = DevAlloc(); }
+  b->text_total = 0;
+  b->text_doc.p = ctx->pool.alloc(((size_t)n + 2) * sizeof(u32), &b->text_doc.cap);
+  if (!b->text_doc.p) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  B.tx_doc = (u32*)b->text_doc.p;
+  if (n == 0 || B.tot_rows == 0) { rt_memset(B.tx_doc, 0, ((size_t)n + 2) * sizeof(u32), ctx->stream); return rt_sync(ctx->stream) ? AMH_SUCCESS : AMH_ERR_DEVICE; }
+  bool ok = true;
+  PhaseTimer pt("amh_text_batch");
+  CallScratch scratch(b);
+  B.tx_off = balloc<u32>(b, (size_t)B.tot_rows + 2, &ok);
+  if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  launch(ctx, AK_TEXT_LEN, B, B.tot_rows);
+  u32 total = 0;
+  if (!scan_inplace(b, B.tx_off, B.tot_rows, &total) || !rt_sync(ctx->stream)) { set_error(ctx, "scan failed"); return AMH_ERR_DEVICE; }
+  if (total == 0xFFFFFFFFu) { set_error(ctx, "amh_text_batch: the texts of the batch exceed 4 GiB"); return AMH_ERR_BATCH_TOO_LARGE; }
+  pt.mark("len + scan", &ctx->stream);
+  b->text_out.p = ctx->pool.alloc((size_t)total + 64, &b->text_out.cap);
+  if (!b->text_out.p) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  B.tx_out = (u8*)b->text_out.p;
+  launch(ctx, AK_TEXT_FILL, B, B.tot_rows);
+  launch(ctx, AK_TEXT_DOC, B, n + 1);
+  if (!rt_sync(ctx->stream)) { set_error(ctx, std::string("device pipeline failed: ") + rt_last_error()); return AMH_ERR_DEVICE; }
+  pt.mark("fill", &ctx->stream);
+  b->text_total = total;
+  collect_profile(ctx);
+  return AMH_SUCCESS;
+}
+extern "C" int amh_text_batch_device(amh_ctx* ctx, const amh_batch* bc, const uint8_t** d_text, const uint32_t** d_doc_off, uint64_t* total) {
+  if (!ctx || !bc || !d_text || !d_doc_off || !total) { set_error(ctx, "amh_text_batch_device: invalid argument"); return AMH_ERR_INVALID_ARG; }
+  AMH_NEEDS_OPS(bc, "amh_text_batch_device")
+  amh_batch* b = const_cast<amh_batch*>(bc);
+  int rc = text_to_device(ctx, b);
+  if (rc != AMH_SUCCESS) return rc;
+  *d_text = (const uint8_t*)b->text_out.p; *d_doc_off = (const uint32_t*)b->text_doc.p; *total = b->text_total;
+  return AMH_SUCCESS;
+}
 extern "C" int amh_text_batch(amh_ctx* ctx, const amh_batch* bc, amh_bytes_out* out, uint64_t** offsets) {
   if (!ctx || !bc || !out || !offsets) { set_error(ctx, "amh_text_batch: invalid argument"); return AMH_ERR_INVALID_ARG; }
   AMH_NEEDS_OPS(bc, "amh_text_batch")
   amh_batch* b = const_cast<amh_batch*>(bc);
-  BatchDev B = b->B;
-  const u32 n = B.n_docs;
+  const u32 n = b->B.n_docs;
   out->data = nullptr; out->len = 0; *offsets = nullptr;
+  int rc = text_to_device(ctx, b);
+  if (rc != AMH_SUCCESS) return rc;
+  const size_t total = (size_t)b->text_total;
   uint64_t* offs = (uint64_t*)calloc((size_t)n + 1, sizeof(uint64_t));
-  if (!offs) return AMH_ERR_OOM;
-  if (n == 0 || B.tot_rows == 0) { out->data = (uint8_t*)malloc(1); *offsets = offs; return out->data ? AMH_SUCCESS : AMH_ERR_OOM; }
-  bool ok = true;
-  CallScratch scratch(b);
-  B.tx_off = balloc<u32>(b, (size_t)B.tot_rows + 2, &ok);
-  B.tx_doc = balloc<u32>(b, (size_t)n + 2, &ok);
-  if (!ok) { free(offs); set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
-  launch(ctx, AK_TEXT_LEN, B, B.tot_rows);
-  u32 total = 0;
-  if (!scan_inplace(b, B.tx_off, B.tot_rows, &total) || !rt_sync(ctx->stream)) { free(offs); set_error(ctx, "scan failed"); return AMH_ERR_DEVICE; }
-  if (total == 0xFFFFFFFFu) { free(offs); set_error(ctx, "amh_text_batch: the texts of the batch exceed 4 GiB"); return AMH_ERR_BATCH_TOO_LARGE; }
-  B.tx_out = balloc<u8>(b, (size_t)total + 64, &ok);
-  if (!ok) { free(offs); set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
-  launch(ctx, AK_TEXT_FILL, B, B.tot_rows);
-  launch(ctx, AK_TEXT_DOC, B, n + 1);
-  std::vector<u32> doc32((size_t)n + 1);
   out->data = (uint8_t*)malloc(total ? total : 1);
-  if (!out->data) { free(offs); return AMH_ERR_OOM; }
-  if (!rt_d2h(doc32.data(), B.tx_doc, ((size_t)n + 1) * sizeof(u32), ctx->stream) || (total && !rt_d2h(out->data, B.tx_out, total, ctx->stream)) || !rt_sync(ctx->stream)) {
+  if (!offs || !out->data) { free(offs); free(out->data); out->data = nullptr; return AMH_ERR_OOM; }
+  std::vector<u32> doc32((size_t)n + 1);
+  if (!rt_d2h(doc32.data(), b->text_doc.p, ((size_t)n + 1) * sizeof(u32), ctx->stream) || (total && !rt_d2h(out->data, b->text_out.p, total, ctx->stream)) || !rt_sync(ctx->stream)) {
     free(out->data); out->data = nullptr; free(offs); set_error(ctx, "D2H copy failed"); return AMH_ERR_DEVICE;
   }
   for (u32 d = 0; d <= n; d++) offs[d] = doc32[d];
   out->len = total;
   *offsets = offs;
-  collect_profile(ctx);
   return AMH_SUCCESS;
 }
 

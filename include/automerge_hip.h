@@ -169,6 +169,10 @@ int amh_hydrate_json(const amh_batch*, uint32_t doc, amh_bytes_out* out);
  * text object per document, as in BASELINE.json configs[2] / [3]: exactly text(obj)).  out = all texts back to back
  * (UTF-8), offsets[n_docs + 1] = where each document's starts; freed with amh_bytes_free / amh_u64_free. */
 int amh_text_batch(amh_ctx*, const amh_batch*, amh_bytes_out* out, uint64_t** offsets);
+/* The same texts left in DEVICE memory for callers that consume them on the GPU (an indexer, a tokenizer): *d_text = all
+ * texts back to back, *d_doc_off = u32[n_docs + 1] where each document's starts, *total = bytes.  The two buffers belong to
+ * the batch and stay valid until the next amh_text_batch* call on it, a merge / apply into it, or amh_batch_free. */
+int amh_text_batch_device(amh_ctx*, const amh_batch*, const uint8_t** d_text, const uint32_t** d_doc_off, uint64_t* total);
 /* max op counter of the document (Automerge::max_op, automerge.rs:181) */
 int amh_doc_max_op(const amh_batch*, uint32_t doc, uint64_t* max_op);
 

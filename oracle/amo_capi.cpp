@@ -5,6 +5,7 @@
 #include <thread>
 
 #include "amo_engine.hpp"
+#include "amo_sync.hpp"
 
 using namespace amo;
 
@@ -195,6 +196,49 @@ int amo_bloom_from_hashes(const uint8_t* hashes, size_t n, const uint8_t** out, 
   std::vector<Hash> hs(n);
   for (size_t i = 0; i < n; i++) memcpy(hs[i].b.data(), hashes + 32 * i, 32);
   return give(bloom_from_hashes(hs), out, len);
+  GUARD_END(-1)
+}
+
+// generate_sync_message (sync.rs:134-221) over a flat State (layout: amo_sync.hpp).  Returns 1 and the encoded message
+// (Message::encode, sync.rs:526-543) or 0 for None; the updated State comes back in the same flat form either way.
+static thread_local Bytes g_out2;
+int amo_generate_sync_message(const amo_doc* d, const uint8_t* state, size_t state_len, const uint8_t** msg, size_t* msg_len,
+                              const uint8_t** new_state, size_t* new_state_len) {
+  GUARD_BEGIN
+  SyncState st = state_from_blob(state, state_len);
+  SyncMessage m;
+  bool some = generate_sync_message(d->doc, st, m);
+  g_out = some ? encode_message(m) : Bytes();
+  g_out2 = state_to_blob(st);
+  *msg = g_out.data();
+  *msg_len = g_out.size();
+  *new_state = g_out2.data();
+  *new_state_len = g_out2.size();
+  return some ? 1 : 0;
+  GUARD_END(-1)
+}
+// receive_sync_message (sync.rs:223-231, 323-383): applies the message to the document and the flat State
+int amo_receive_sync_message(amo_doc* d, const uint8_t* state, size_t state_len, const uint8_t* msg, size_t msg_len,
+                             const uint8_t** new_state, size_t* new_state_len) {
+  GUARD_BEGIN
+  SyncState st = state_from_blob(state, state_len);
+  SyncMessage m = parse_message(msg, msg_len);
+  receive_sync_message(d->doc, st, m);
+  return give(state_to_blob(st), new_state, new_state_len);
+  GUARD_END(-1)
+}
+// Message::decode then Message::encode: must reproduce the bytes (sync.rs:652-659 round-trip property)
+int amo_sync_message_reencode(const uint8_t* msg, size_t msg_len, const uint8_t** out, size_t* len) {
+  GUARD_BEGIN
+  return give(encode_message(parse_message(msg, msg_len)), out, len);
+  GUARD_END(-1)
+}
+// BloomFilter::contains_hash over wire bytes (bloom.rs:49-67, 110-123)
+int amo_bloom_contains(const uint8_t* bloom, size_t len, const uint8_t* hash32) {
+  GUARD_BEGIN
+  Hash h;
+  memcpy(h.b.data(), hash32, 32);
+  return Bloom::parse(bloom, len).contains(h) ? 1 : 0;
   GUARD_END(-1)
 }
 

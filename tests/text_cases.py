@@ -37,5 +37,6 @@ def check_texts(engine, docs, expect_nonempty=True):
         want = oracle_texts(d) if kind == 0 else ""
         assert texts[i] == want, (i, texts[i][:60], want[:60])
     assert not expect_nonempty or any(texts)
+    assert b.text_device()[2] == sum(len(t.encode("utf-8")) for t in texts)   # the device-resident form: same bytes in HBM
     b.close()
     return texts
