@@ -32,6 +32,20 @@ class LoadOpts(C.Structure):
     _fields_ = [("verify_heads", C.c_int), ("on_partial_load", C.c_int)]
 
 
+class SyncHaveC(C.Structure):
+    _fields_ = [("last_sync32", C.c_char_p), ("n_last_sync", C.c_size_t), ("bloom", C.c_char_p), ("bloom_len", C.c_size_t)]
+
+
+class SyncStateC(C.Structure):
+    _fields_ = [("doc", C.c_uint32), ("flags", C.c_uint32),
+                ("shared_heads32", C.c_char_p), ("n_shared_heads", C.c_size_t),
+                ("last_sent_heads32", C.c_char_p), ("n_last_sent_heads", C.c_size_t),
+                ("their_heads32", C.c_char_p), ("n_their_heads", C.c_size_t),
+                ("their_need32", C.c_char_p), ("n_their_need", C.c_size_t),
+                ("their_have", C.POINTER(SyncHaveC)), ("n_their_have", C.c_size_t),
+                ("sent_hashes32", C.c_char_p), ("n_sent_hashes", C.c_size_t)]
+
+
 class BatchStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_docs", "n_ok", "ops_loaded", "op_rows", "succ_entries", "changes",
                                           "delete_ops", "encoded_bytes", "change_bytes")]
@@ -44,7 +58,7 @@ EXPORTS = [
     "amh_sync_summaries", "amh_ctx_set_profiling", "amh_ctx_num_kernels", "amh_ctx_kernel_name", "amh_ctx_kernel_time",
     "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free", "amh_apply_batch", "amh_doc_queue_len", "amh_merge_many", "amh_save_after",
     "amh_sync_summaries_noalloc", "amh_ctx_pool_bytes", "amh_ctx_set_limits", "amh_batch_release_ops", "amh_comm_unique_id", "amh_comm_init", "amh_sync_summaries_all",
-    "amh_partition_docs", "amh_text_batch", "amh_text_batch_device",
+    "amh_partition_docs", "amh_text_batch", "amh_text_batch_device", "amh_generate_sync_messages",
 ]
 
 DOC_ERRORS = {
@@ -108,6 +122,8 @@ def bind(lib):
                                     C.POINTER(C.c_int)]
     lib.amh_doc_queue_len.argtypes = [vp, C.c_uint32, C.POINTER(C.c_size_t)]
     lib.amh_save_after.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t, C.POINTER(BytesOut)]
+    lib.amh_generate_sync_messages.argtypes = [vp, vp, C.POINTER(SyncStateC), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(BytesOut),
+                                               C.POINTER(BytesOut)]
     lib.amh_merge_many.argtypes = [vp, vp, C.POINTER(vp), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]
     return lib
 
@@ -404,6 +420,56 @@ class Batch:
             raise EngineError(f"amh_text_batch_device failed: {rc} {self.engine._err()}")
         return d_text.value, d_off.value, total.value
 
+    def generate_sync_messages(self, states):
+        """SyncDoc::generate_sync_message (sync.rs:134-221) for every (document index, SyncState) of `states` in one
+        pass on the device.  Returns the encoded messages (None where the reference returns None) and updates the
+        States the way sync.rs:207-219 does."""
+        n = len(states)
+        arr = (SyncStateC * n)()
+        keep = []
+        for k, (doc, st) in enumerate(states):
+            c = arr[k]
+            c.doc = doc
+            c.flags = ((1 if st.their_heads is not None else 0) | (2 if st.their_need is not None else 0) |
+                       (4 if st.their_have is not None else 0) | (8 if st.in_flight else 0))
+
+            def lst(hs):
+                raw = b"".join(hs or [])
+                keep.append(raw)
+                return raw, len(hs or [])
+            c.shared_heads32, c.n_shared_heads = lst(st.shared_heads)
+            c.last_sent_heads32, c.n_last_sent_heads = lst(st.last_sent_heads)
+            c.their_heads32, c.n_their_heads = lst(st.their_heads)
+            c.their_need32, c.n_their_need = lst(st.their_need)
+            c.sent_hashes32, c.n_sent_hashes = lst(sorted(st.sent_hashes))
+            haves = st.their_have or []
+            ha = (SyncHaveC * max(len(haves), 1))()
+            for j, h in enumerate(haves):
+                ha[j].last_sync32, ha[j].n_last_sync = lst(h.last_sync)
+                keep.append(h.bloom)
+                ha[j].bloom, ha[j].bloom_len = h.bloom, len(h.bloom)
+            keep.append(ha)
+            c.their_have, c.n_their_have = ha, len(haves)
+        kinds = (C.c_uint32 * max(n, 1))()
+        msgs = (BytesOut * max(n, 1))()
+        sent = (BytesOut * max(n, 1))()
+        rc = self.engine.lib.amh_generate_sync_messages(self.engine.ctx, self.h, arr, n, kinds, msgs, sent)
+        out = []
+        for k in range(n):
+            m = C.string_at(msgs[k].data, msgs[k].len) if msgs[k].data else None
+            sh = C.string_at(sent[k].data, sent[k].len) if sent[k].data else b""
+            self.engine.lib.amh_bytes_free(C.byref(msgs[k]))
+            self.engine.lib.amh_bytes_free(C.byref(sent[k]))
+            if rc == 0 and kinds[k] == 1:
+                st = states[k][1]
+                st.last_sent_heads = SyncMessage.decode(m).heads
+                st.sent_hashes.update(sh[i:i + 32] for i in range(0, len(sh), 32))
+                st.in_flight = True
+            out.append(m)
+        if rc != 0:
+            raise EngineError(f"amh_generate_sync_messages failed: {rc} {self.engine._err()}")
+        return out
+
     def sync_summaries_raw(self):
         """All sync summary records of the batch as one bytes object (amh_sync_summaries)."""
         o = BytesOut()
@@ -430,6 +496,110 @@ class Batch:
         if rc != 0:
             raise EngineError(f"amh_batch_get_stats failed: {rc}")
         return {name: getattr(s, name) for name, _ in BatchStats._fields_}
+
+
+class SyncHave:
+    """sync::Have (sync/state.rs:59-65); bloom = the filter's wire bytes (BloomFilter::to_bytes)"""
+
+    def __init__(self, last_sync=None, bloom=b""):
+        self.last_sync, self.bloom = list(last_sync or []), bytes(bloom)
+
+    def __eq__(self, o):
+        return self.last_sync == o.last_sync and self.bloom == o.bloom
+
+
+class SyncState:
+    """sync::State (sync/state.rs:31-53): what one side knows about one peer for one document"""
+
+    def __init__(self):
+        self.shared_heads, self.last_sent_heads = [], []
+        self.their_heads = self.their_need = self.their_have = None
+        self.sent_hashes = set()
+        self.in_flight = False
+
+    def encode(self):   # state.rs:72-76: only the shared heads persist
+        return bytes([0x43]) + _uleb(len(self.shared_heads)) + b"".join(self.shared_heads)
+
+    @staticmethod
+    def decode(data):   # state.rs:87-109
+        if not data or data[0] != 0x43:
+            raise ValueError("wrong type for an encoded sync state")
+        hs, pos = _read_hashes(data, 1)
+        st = SyncState()
+        st.shared_heads, st.their_have = hs, []
+        return st
+
+
+def _uleb(n):
+    out = bytearray()
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        out.append(b | (0x80 if n else 0))
+        if not n:
+            return bytes(out)
+
+
+def _read_uleb(data, pos):
+    v = shift = 0
+    while True:
+        if pos >= len(data):
+            raise ValueError("not enough input")
+        b = data[pos]
+        pos += 1
+        v |= (b & 0x7F) << shift
+        shift += 7
+        if not b & 0x80:
+            return v, pos
+
+
+def _read_hashes(data, pos):
+    n, pos = _read_uleb(data, pos)
+    if pos + 32 * n > len(data):
+        raise ValueError("not enough input")
+    return [data[pos + 32 * i: pos + 32 * i + 32] for i in range(n)], pos + 32 * n
+
+
+class SyncMessage:
+    """sync::Message (sync.rs:433-442) in its wire form (Message::parse :482-524, encode :526-543); changes stay raw chunks"""
+
+    def __init__(self, heads=(), need=(), have=(), changes=()):
+        self.heads, self.need, self.have, self.changes = list(heads), list(need), list(have), list(changes)
+
+    @staticmethod
+    def decode(data):
+        if not data or data[0] != 0x42:
+            raise ValueError("wrong type for a sync message")
+        heads, pos = _read_hashes(data, 1)
+        need, pos = _read_hashes(data, pos)
+        nh, pos = _read_uleb(data, pos)
+        have = []
+        for _ in range(nh):
+            ls, pos = _read_hashes(data, pos)
+            bl, pos = _read_uleb(data, pos)
+            have.append(SyncHave(ls, data[pos:pos + bl]))
+            pos += bl
+        nc, pos = _read_uleb(data, pos)
+        changes = []
+        for _ in range(nc):
+            cl, pos = _read_uleb(data, pos)
+            if pos + cl > len(data):
+                raise ValueError("not enough input")
+            changes.append(data[pos:pos + cl])
+            pos += cl
+        return SyncMessage(heads, need, have, changes)
+
+    def encode(self):
+        out = bytearray([0x42])
+        for hs in (self.heads, self.need):
+            out += _uleb(len(hs)) + b"".join(hs)
+        out += _uleb(len(self.have))
+        for h in self.have:
+            out += _uleb(len(h.last_sync)) + b"".join(h.last_sync) + _uleb(len(h.bloom)) + h.bloom
+        out += _uleb(len(self.changes))
+        for c in self.changes:
+            out += _uleb(len(c)) + c
+        return bytes(out)
 
 
 class Arena:

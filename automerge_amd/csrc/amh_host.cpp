@@ -10,6 +10,8 @@
 #include <atomic>
 #include <map>
 #include <memory>
+#include <set>
+#include <cmath>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -112,8 +114,8 @@ struct amh_ctx {
   struct AmhComm* comm = nullptr;   // RCCL communicator of this process's rank (amh_comm_init); none = single GPU
   u32 max_doc_rows = AMH_MAX_ROWS_PER_DOC;
   u64 max_batch_bytes = 0;   // 0 = what the device has free (plus what the pool holds) when the batch is sized
-  double kernel_ms[AK_NUM + MK_NUM] = {0};      // load / save kernels, then the merge / apply kernels
-  uint64_t kernel_calls[AK_NUM + MK_NUM] = {0};
+  double kernel_ms[AK_NUM + MK_NUM + SK_NUM] = {0};      // load / save kernels, the merge / apply kernels, the sync message kernels
+  uint64_t kernel_calls[AK_NUM + MK_NUM + SK_NUM] = {0};
   struct Pending { int k; rt_event a, b; };
   std::vector<Pending> pending;
   std::string last_error;
@@ -3440,6 +3442,200 @@ extern "C" int amh_sync_summaries_all(amh_ctx* ctx, const amh_batch* bc, amh_byt
   return AMH_SUCCESS;
 #endif
 }
+// a sync message kernel, timed like the others when the context is profiling
+static const char* const SK_KERNEL_NAMES[SK_NUM] = {"sm_lookup", "sm_plan", "sm_fill"};
+static void launch_sm_timed(amh_ctx* ctx, int k, const SyncDev* G, u32 n) {
+  if (n == 0) return;
+  if (ctx->profiling) {
+    amh_ctx::Pending p;
+    p.k = AK_NUM + MK_NUM + k;
+    rt_event_create(&p.a);
+    rt_event_create(&p.b);
+    rt_event_record(&p.a, ctx->stream);
+    amh_launch_sm(k, G, n, (void*)ctx->stream);
+    rt_event_record(&p.b, ctx->stream);
+    ctx->pending.push_back(p);
+  } else {
+    amh_launch_sm(k, G, n, (void*)ctx->stream);
+  }
+}
+// BloomFilter::parse (sync/bloom.rs:49-67) of a Have's wire bytes: parameters and where the bit array starts
+static bool sm_parse_bloom(const u8* p, size_t n, u32& entries, u32& probes, size_t& bits_at, u32& nbytes) {
+  entries = 0; probes = 7; bits_at = 0; nbytes = 0;
+  if (n == 0) return true;
+  size_t pos = 0;
+  u64 e = 0, bpe = 0, pr = 0;
+  if (!host_uleb(p, pos, n, e) || !host_uleb(p, pos, n, bpe) || !host_uleb(p, pos, n, pr)) return false;
+  if (e > 0xFFFFFFFFull || bpe > 0xFFFFFFFFull || pr > 0xFFFFFFFFull) return false;
+  const double cap = std::ceil(((double)e * (double)bpe) / 8.0);
+  if (cap > (double)(n - pos) || cap >= (double)(1u << 28)) return false;
+  entries = (u32)e; probes = (u32)pr; bits_at = pos; nbytes = (u32)cap;
+  return !(entries != 0 && nbytes == 0);
+}
+extern "C" int amh_generate_sync_messages(amh_ctx* ctx, const amh_batch* bc, const amh_sync_state* states, size_t n, uint32_t* kinds,
+                                          amh_bytes_out* msgs, amh_bytes_out* sent) {
+  if (!ctx || !bc || (n && (!states || !kinds || !msgs)) || n >= 0x7FFFFFFFull) { set_error(ctx, "amh_generate_sync_messages: invalid argument"); return AMH_ERR_INVALID_ARG; }
+  amh_batch* b = const_cast<amh_batch*>(bc);
+  for (size_t i = 0; i < n; i++) {
+    kinds[i] = AMH_SYNC_NONE;
+    msgs[i].data = nullptr; msgs[i].len = 0;
+    if (sent) { sent[i].data = nullptr; sent[i].len = 0; }
+  }
+  if (n == 0) return AMH_SUCCESS;
+  if (!ensure_base(b)) { set_error(ctx, "amh_generate_sync_messages: D2H copy failed"); return AMH_ERR_DEVICE; }
+  const HostView& hv = b->hv;
+  const u32 R = (u32)n;
+  // ---- the States, flattened: one hash pool, per-record list bounds, the Haves and their filters ----
+  std::vector<u32> r_doc(R), r_flags(R), r_list((size_t)R * SM_LISTS + 1), r_have(R + 1), pool_rec, h_ls, h_entries, h_probes, h_nbytes;
+  std::vector<u64> h_bits, r_flag_base(R), r_clock_base(R), r_word_base(R);
+  std::vector<u8> pool, blooms;
+  u64 n_flag = 0, n_clock = 0, n_word = 0;
+  // deps of queued changes that are not queued themselves, and the hashes of the queued changes (get_missing_deps)
+  struct QInfo { std::vector<u8> deps, hashes; };
+  std::unordered_map<u32, QInfo> qinfo;
+  auto queue_of = [&](u32 d) -> const QInfo* {
+    auto qit = b->queue.find(d);
+    if (qit == b->queue.end() || qit->second.empty()) return nullptr;
+    auto it = qinfo.find(d);
+    if (it != qinfo.end()) return &it->second;
+    QInfo qi;
+    std::set<std::array<u8, 32>> in_queue, deps;
+    for (auto& q : qit->second) {
+      std::array<u8, 32> h;
+      if (q.size() < 10) continue;
+      amh_host_sha256(q.data() + 8, q.size() - 8, nullptr, 0, h.data());
+      in_queue.insert(h);
+    }
+    for (auto& q : qit->second) {
+      if (q.size() < 10) continue;
+      size_t pos = 9;
+      u64 blen = 0, nd = 0;
+      if (!host_uleb(q.data(), pos, q.size(), blen) || !host_uleb(q.data(), pos, q.size(), nd) || nd > (q.size() - pos) / 32) continue;
+      for (u64 k = 0; k < nd; k++) { std::array<u8, 32> h; memcpy(h.data(), q.data() + pos + 32 * k, 32); if (!in_queue.count(h)) deps.insert(h); }
+    }
+    for (auto& h : deps) qi.deps.insert(qi.deps.end(), h.begin(), h.end());
+    for (auto& h : in_queue) qi.hashes.insert(qi.hashes.end(), h.begin(), h.end());
+    return &qinfo.emplace(d, std::move(qi)).first->second;
+  };
+  auto add_list = [&](u32 r, const u8* h, size_t k) {
+    if (k) { pool.insert(pool.end(), h, h + 32 * k); pool_rec.insert(pool_rec.end(), k, r); }
+  };
+  for (u32 r = 0; r < R; r++) {
+    const amh_sync_state& s = states[r];
+    if (s.doc >= b->B.n_docs || (s.n_shared_heads && !s.shared_heads32) || (s.n_last_sent_heads && !s.last_sent_heads32) ||
+        (s.n_their_heads && !s.their_heads32) || (s.n_their_need && !s.their_need32) || (s.n_their_have && !s.their_have) ||
+        (s.n_sent_hashes && !s.sent_hashes32)) { set_error(ctx, "amh_generate_sync_messages: invalid sync state"); return AMH_ERR_INVALID_ARG; }
+    r_doc[r] = s.doc;
+    r_flags[r] = s.flags & 15u;
+    const bool th = s.flags & AMH_SYNC_THEIR_HEADS, tn = s.flags & AMH_SYNC_THEIR_NEED, tv = s.flags & AMH_SYNC_THEIR_HAVE;
+    const QInfo* qi = b->status[s.doc] ? nullptr : queue_of(s.doc);
+    u32* L = r_list.data() + (size_t)r * SM_LISTS;
+    L[SM_SHARED] = (u32)pool_rec.size(); add_list(r, s.shared_heads32, s.n_shared_heads);
+    L[SM_LAST_SENT] = (u32)pool_rec.size(); add_list(r, s.last_sent_heads32, s.n_last_sent_heads);
+    L[SM_THEIR_HEADS] = (u32)pool_rec.size(); if (th) add_list(r, s.their_heads32, s.n_their_heads);
+    L[SM_THEIR_NEED] = (u32)pool_rec.size(); if (tn) add_list(r, s.their_need32, s.n_their_need);
+    L[SM_SENT] = (u32)pool_rec.size(); add_list(r, s.sent_hashes32, s.n_sent_hashes);
+    L[SM_QDEPS] = (u32)pool_rec.size(); if (qi) add_list(r, qi->deps.data(), qi->deps.size() / 32);
+    L[SM_QHASH] = (u32)pool_rec.size(); if (qi) add_list(r, qi->hashes.data(), qi->hashes.size() / 32);
+    L[SM_LAST_SYNC] = (u32)pool_rec.size();
+    r_have[r] = (u32)h_entries.size();
+    for (size_t k = 0; tv && k < s.n_their_have; k++) {
+      const amh_sync_have& h = s.their_have[k];
+      if ((h.n_last_sync && !h.last_sync32) || (h.bloom_len && !h.bloom)) { set_error(ctx, "amh_generate_sync_messages: invalid sync state"); return AMH_ERR_INVALID_ARG; }
+      h_ls.push_back((u32)pool_rec.size());
+      add_list(r, h.last_sync32, h.n_last_sync);
+      h_ls.push_back((u32)pool_rec.size());
+      u32 e, pr, nb; size_t at;
+      if (!sm_parse_bloom(h.bloom, h.bloom_len, e, pr, at, nb)) { set_error(ctx, "amh_generate_sync_messages: malformed Bloom filter in a Have"); return AMH_ERR_INVALID_ARG; }
+      h_entries.push_back(e); h_probes.push_back(pr); h_nbytes.push_back(nb); h_bits.push_back(blooms.size());
+      if (nb) blooms.insert(blooms.end(), h.bloom + at, h.bloom + at + nb);
+    }
+    if (pool_rec.size() >= 0x7FFFFFFFull) { set_error(ctx, "amh_generate_sync_messages: too many hashes in one call"); return AMH_ERR_BATCH_TOO_LARGE; }
+    const u32 nc = b->status[s.doc] ? 0 : hv.cnt[s.doc].n_chg, na = b->status[s.doc] ? 0 : hv.desc[s.doc].n_actors;
+    r_flag_base[r] = n_flag; n_flag += nc;
+    r_clock_base[r] = n_clock; n_clock += na;
+    r_word_base[r] = n_word;
+    n_word += (u64)nc * 2 + (L[SM_QHASH] - L[SM_QDEPS]) + (L[SM_THEIR_NEED] - L[SM_THEIR_HEADS]) + (L[SM_SENT] - L[SM_THEIR_NEED]);
+  }
+  r_list[(size_t)R * SM_LISTS] = (u32)pool_rec.size();
+  r_have[R] = (u32)h_entries.size();
+  const u32 n_pool = (u32)pool_rec.size();
+  // ---- one upload: the tables side by side in one device block ----
+  std::vector<u8> blob;
+  auto put = [&](const void* p, size_t bytes) { size_t at = (blob.size() + 255) & ~(size_t)255; blob.resize(at + bytes); if (bytes) memcpy(blob.data() + at, p, bytes); return at; };
+  const size_t o_doc = put(r_doc.data(), R * 4), o_flags = put(r_flags.data(), R * 4), o_pool = put(pool.data(), pool.size()),
+               o_prec = put(pool_rec.data(), (size_t)n_pool * 4), o_list = put(r_list.data(), r_list.size() * 4), o_have = put(r_have.data(), r_have.size() * 4),
+               o_ls = put(h_ls.data(), h_ls.size() * 4), o_ent = put(h_entries.data(), h_entries.size() * 4), o_pr = put(h_probes.data(), h_probes.size() * 4),
+               o_bits = put(h_bits.data(), h_bits.size() * 8), o_nb = put(h_nbytes.data(), h_nbytes.size() * 4), o_bl = put(blooms.data(), blooms.size()),
+               o_fb = put(r_flag_base.data(), R * 8), o_cb = put(r_clock_base.data(), R * 8), o_wb = put(r_word_base.data(), R * 8);
+  const size_t o_G = put(nullptr, 0);
+  blob.resize(o_G + sizeof(SyncDev));
+  bool ok = true;
+  CallScratch scratch(b);
+  u8* d_blob = balloc<u8>(b, blob.size() + 256, &ok);
+  SyncDev G;
+  memset(&G, 0, sizeof G);
+  G.B = b->B;
+  G.n_rec = R; G.n_pool = n_pool;
+  G.pool_idx = balloc<u32>(b, (size_t)n_pool + 1, &ok);
+  G.c_flag = balloc<u8>(b, n_flag + 16, &ok);
+  G.clock = balloc<u64>(b, n_clock + 1, &ok);
+  G.words = balloc<u32>(b, n_word + 1, &ok);
+  G.r_kind = balloc<u32>(b, (size_t)R * 5 + 8, &ok);
+  G.msg_off = balloc<u32>(b, (size_t)R + 2, &ok);
+  G.job_base = balloc<u32>(b, (size_t)R + 2, &ok);
+  if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  G.r_nheads = G.r_kind + R; G.r_nneed = G.r_kind + 2 * (size_t)R; G.r_nsend = G.r_kind + 3 * (size_t)R; G.r_bloom_n = G.r_kind + 4 * (size_t)R;
+  G.r_doc = (const u32*)(d_blob + o_doc); G.r_flags = (const u32*)(d_blob + o_flags); G.pool = d_blob + o_pool;
+  G.pool_rec = (const u32*)(d_blob + o_prec); G.r_list = (const u32*)(d_blob + o_list); G.r_have = (const u32*)(d_blob + o_have);
+  G.h_ls = (const u32*)(d_blob + o_ls); G.h_entries = (const u32*)(d_blob + o_ent); G.h_probes = (const u32*)(d_blob + o_pr);
+  G.h_bits = (const u64*)(d_blob + o_bits); G.h_nbytes = (const u32*)(d_blob + o_nb); G.blooms = d_blob + o_bl;
+  G.r_flag_base = (const u64*)(d_blob + o_fb); G.r_clock_base = (const u64*)(d_blob + o_cb); G.r_word_base = (const u64*)(d_blob + o_wb);
+  memcpy(blob.data() + o_G, &G, sizeof G);
+  SyncDev* dG = (SyncDev*)(d_blob + o_G);
+  if (!rt_h2d(d_blob, blob.data(), blob.size(), ctx->stream)) { set_error(ctx, "H2D copy failed"); return AMH_ERR_DEVICE; }
+  launch_sm_timed(ctx, SK_LOOKUP, dG, n_pool);
+  launch_sm_timed(ctx, SK_PLAN, dG, R);
+  u32 total = 0, jobs = 0;
+  if (!scan_inplace(b, G.msg_off, R, &total) || !scan_inplace(b, G.job_base, R, &jobs)) { set_error(ctx, "scan failed"); return AMH_ERR_DEVICE; }
+  if (total == 0xFFFFFFFFu || jobs == 0xFFFFFFFFu) { set_error(ctx, "sync messages exceed 4 GiB: generate them in parts"); return AMH_ERR_BATCH_TOO_LARGE; }
+  G.msg_out = balloc<u8>(b, (size_t)total + 64, &ok);
+  G.sent_out = balloc<u8>(b, (size_t)jobs * 32 + 32, &ok);
+  G.job_src = balloc<u64>(b, (size_t)jobs + 1, &ok);
+  G.job_dst = balloc<u64>(b, (size_t)jobs + 1, &ok);
+  G.job_len = balloc<u32>(b, (size_t)jobs + 1, &ok);
+  if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  if (!rt_h2d(dG, &G, sizeof G, ctx->stream)) { set_error(ctx, "H2D copy failed"); return AMH_ERR_DEVICE; }
+  launch_sm_timed(ctx, SK_FILL, dG, R);
+  if (jobs) amh_copy_bytes64(G.job_src, G.job_len, G.job_dst, G.msg_out, jobs, (void*)ctx->stream);
+  std::vector<u8> h_msg((size_t)total + 1), h_sent((size_t)jobs * 32 + 1);
+  std::vector<u32> h_off(R + 1), h_job(R + 1), h_kind(R);
+  if (!rt_d2h(h_msg.data(), G.msg_out, total, ctx->stream) || !rt_d2h(h_sent.data(), G.sent_out, (size_t)jobs * 32, ctx->stream) ||
+      !rt_d2h(h_off.data(), G.msg_off, ((size_t)R + 1) * 4, ctx->stream) || !rt_d2h(h_job.data(), G.job_base, ((size_t)R + 1) * 4, ctx->stream) ||
+      !rt_d2h(h_kind.data(), G.r_kind, (size_t)R * 4, ctx->stream)) { set_error(ctx, "D2H copy failed"); return AMH_ERR_DEVICE; }
+  collect_profile(ctx);
+  int rc = AMH_SUCCESS;
+  for (u32 r = 0; r < R; r++) {
+    kinds[r] = h_kind[r];
+    if (h_kind[r] == SMK_FAILED) { rc = AMH_ERR_DOC_FAILED; continue; }
+    const size_t len = h_off[r + 1] - h_off[r];
+    if (len) {
+      msgs[r].data = (uint8_t*)malloc(len);
+      if (!msgs[r].data) return AMH_ERR_OOM;
+      memcpy(msgs[r].data, h_msg.data() + h_off[r], len);
+      msgs[r].len = len;
+    }
+    const size_t ns = h_job[r + 1] - h_job[r];
+    if (sent && ns) {
+      sent[r].data = (uint8_t*)malloc(ns * 32);
+      if (!sent[r].data) return AMH_ERR_OOM;
+      memcpy(sent[r].data, h_sent.data() + (size_t)h_job[r] * 32, ns * 32);
+      sent[r].len = ns * 32;
+    }
+  }
+  if (rc == AMH_ERR_DOC_FAILED) set_error(ctx, "amh_generate_sync_messages: some records name documents that failed to load");
+  return rc;
+}
 extern "C" int amh_comm_unique_id(uint8_t* id128) {
   if (!id128) return AMH_ERR_INVALID_ARG;
 #ifdef AMH_EMU
@@ -3629,10 +3825,10 @@ extern "C" int amh_ctx_set_profiling(amh_ctx* ctx, int enable) {
   ctx->profiling = enable != 0;
   return AMH_SUCCESS;
 }
-extern "C" int amh_ctx_num_kernels(void) { return AK_NUM + MK_NUM; }
-extern "C" const char* amh_ctx_kernel_name(int k) { return (k >= 0 && k < AK_NUM) ? AMH_KERNEL_NAMES[k] : (k >= AK_NUM && k < AK_NUM + MK_NUM) ? MK_KERNEL_NAMES[k - AK_NUM] : nullptr; }
+extern "C" int amh_ctx_num_kernels(void) { return AK_NUM + MK_NUM + SK_NUM; }
+extern "C" const char* amh_ctx_kernel_name(int k) { return (k >= 0 && k < AK_NUM) ? AMH_KERNEL_NAMES[k] : (k >= AK_NUM && k < AK_NUM + MK_NUM) ? MK_KERNEL_NAMES[k - AK_NUM] : (k >= AK_NUM + MK_NUM && k < AK_NUM + MK_NUM + SK_NUM) ? SK_KERNEL_NAMES[k - AK_NUM - MK_NUM] : nullptr; }
 extern "C" int amh_ctx_kernel_time(amh_ctx* ctx, int k, double* ms, uint64_t* launches) {
-  if (!ctx || k < 0 || k >= AK_NUM + MK_NUM) return AMH_ERR_INVALID_ARG;
+  if (!ctx || k < 0 || k >= AK_NUM + MK_NUM + SK_NUM) return AMH_ERR_INVALID_ARG;
   if (ms) *ms = ctx->kernel_ms[k];
   if (launches) *launches = ctx->kernel_calls[k];
   return AMH_SUCCESS;
@@ -3645,6 +3841,6 @@ extern "C" int amh_ctx_pool_bytes(const amh_ctx* ctx, uint64_t* live, uint64_t* 
 }
 extern "C" int amh_ctx_reset_profile(amh_ctx* ctx) {
   if (!ctx) return AMH_ERR_INVALID_ARG;
-  for (int k = 0; k < AK_NUM + MK_NUM; k++) { ctx->kernel_ms[k] = 0; ctx->kernel_calls[k] = 0; }
+  for (int k = 0; k < AK_NUM + MK_NUM + SK_NUM; k++) { ctx->kernel_ms[k] = 0; ctx->kernel_calls[k] = 0; }
   return AMH_SUCCESS;
 }

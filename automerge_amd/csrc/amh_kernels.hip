@@ -6,6 +6,7 @@
 #include "amh_kernels.inl"
 #include "amh_merge.inl"
 #include "amh_apply.inl"
+#include "amh_syncmsg.inl"
 #include "amh_launch.h"
 
 #define AMH_BLOCK 256
@@ -1282,6 +1283,22 @@ void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream) {
     default: break;
   }
 #undef M
+}
+
+// sync message kernels: one thread per unit, the SyncDev block lives in device memory
+#define AMH_GLOBAL_SM(name)                                                     \
+  __global__ void __launch_bounds__(AMH_BLOCK) g_##name(const SyncDev* G, u32 n) { \
+    u32 i = blockIdx.x * AMH_BLOCK + threadIdx.x;                              \
+    if (i < n) name(*G, i);                                                    \
+  }
+AMH_GLOBAL_SM(k_sm_lookup) AMH_GLOBAL_SM(k_sm_plan) AMH_GLOBAL_SM(k_sm_fill)
+void amh_launch_sm(int k, const SyncDev* G, u32 n, void* stream) {
+  if (n == 0) return;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((n + AMH_BLOCK - 1) / AMH_BLOCK), block(AMH_BLOCK);
+  if (k == SK_LOOKUP) hipLaunchKernelGGL(g_k_sm_lookup, grid, block, 0, s, G, n);
+  else if (k == SK_PLAN) hipLaunchKernelGGL(g_k_sm_plan, grid, block, 0, s, G, n);
+  else if (k == SK_FILL) hipLaunchKernelGGL(g_k_sm_fill, grid, block, 0, s, G, n);
 }
 
 // one block per segment, 16-byte copies (segments are 16-byte aligned and padded on both sides)

@@ -32,6 +32,9 @@ enum MgKernel {
   MK_AP_SUCC_FILL_U, MK_AP_SUCC_SORT_U, MK_AP_SUCC_FILL_D, MK_AP_TIES, MK_NUM
 };
 void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream);
+// sync message kernels (amh_syncmsg.inl): G is the SyncDev in device memory (host memory in the emulation)
+enum SmKernel { SK_LOOKUP = 0, SK_PLAN, SK_FILL, SK_NUM };
+void amh_launch_sm(int k, const SyncDev* G, u32 n, void* stream);
 // copy n byte segments inside device memory: segment i = len[i] bytes from address src[i] to dst + dst_off[i]
 // (16-byte aligned on both sides).  The three tables live in device memory.
 void amh_copy_segments(const u64* src, const u32* len, const u64* dst_off, u8* dst, u32 n, void* stream);

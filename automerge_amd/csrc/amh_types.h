@@ -306,5 +306,39 @@ struct MergeDev {
   u32* big_items;                  // [4 * 2 * big_cap] pairs (a, b)
   u32 big_cap;
 };
+// generate_sync_message over a batch of (document, peer) records (sync.rs:134-221).  Every hash list of a record's State sits
+// in one pool; list l of record r = pool entries [r_list[r * SM_LISTS + l], r_list[r * SM_LISTS + l + 1]).
+enum { SM_SHARED = 0, SM_LAST_SENT, SM_THEIR_HEADS, SM_THEIR_NEED, SM_SENT, SM_QDEPS, SM_QHASH, SM_LAST_SYNC, SM_LISTS };
+enum { SMF_THEIR_HEADS = 1, SMF_THEIR_NEED = 2, SMF_THEIR_HAVE = 4, SMF_IN_FLIGHT = 8 };
+enum { SMK_NONE = 0, SMK_MESSAGE = 1, SMK_RESET = 2, SMK_FAILED = 3 };
+struct SyncDev {
+  BatchDev B;
+  u32 n_rec, n_pool;
+  const u32 *r_doc, *r_flags;
+  const u8* pool;                  // [n_pool * 32]
+  const u32* pool_rec;             // [n_pool] record of the hash
+  u32* pool_idx;                   // [n_pool] place of the hash in its document's history, AMH_NULL32 = not there (k_sm_lookup)
+  const u32* r_list;               // [n_rec * SM_LISTS + 1]; SM_LAST_SYNC spans the last_sync hashes of all the record's Haves
+  const u32* r_have;               // [n_rec + 1] Haves of a record
+  const u32* h_ls;                 // [2 * n_have] last_sync of a Have: pool range {first, end}
+  const u32 *h_entries, *h_probes; // [n_have] Bloom filter parameters (sync/bloom.rs:13-18)
+  const u64* h_bits;               // [n_have] its bit array: offset in blooms
+  const u32* h_nbytes;             // [n_have] bytes of it
+  const u8* blooms;
+  // scratch, one region per record
+  const u64 *r_flag_base, *r_clock_base, *r_word_base;   // [n_rec]
+  u8* c_flag;                      // [sum n_chg] SMC_* bits per (record, change)
+  u64* clock;                      // [sum n_actors]
+  u32* words;                      // per record: heads[n_chg] | need[n_qdeps + n_their_heads] | send[n_their_need + n_chg]
+  // results
+  u32 *r_kind, *r_nheads, *r_nneed, *r_nsend, *r_bloom_n;   // [n_rec]; r_bloom_n = AMH_NULL32: no Have in the message
+  u32* msg_off;                    // [n_rec + 1] message sizes, then their exclusive scan
+  u32* job_base;                   // [n_rec + 1] r_nsend, scanned: places in the copy job tables and in sent_out
+  u8* msg_out;
+  u8* sent_out;                    // [jobs * 32] hashes of the changes in the messages
+  u64 *job_src, *job_dst;          // [jobs] copy jobs of the change chunks (amh_copy_bytes64)
+  u32* job_len;
+};
+enum { SMC_ANC_SHARED = 1, SMC_ANC_SYNC = 2, SMC_SENT = 4, SMC_SEND = 8, SMC_SINCE = 16, SMC_BLOOM = 32 };
 enum { BIGK_CHILDREN = 0, BIGK_TIES = 1, BIGK_SUCC_U = 2, BIGK_SUCC_M = 3 };
 #define AMH_BIG_LIST 48u

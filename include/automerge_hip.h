@@ -252,6 +252,43 @@ int amh_sync_summaries(amh_ctx*, const amh_batch*, amh_bytes_out* out);
  * array: calls that overlap on one GPU (two contexts, two threads) race.  Returns with the stream drained. */
 int amh_sync_summaries_noalloc(amh_ctx*, const amh_batch*, uint8_t* d_out, size_t cap, uint32_t* d_meta);
 
+/* ---- sync messages -----------------------------------------------------------------------------
+ * == SyncDoc::generate_sync_message (sync.rs:134-221) for n (document, peer) records in one pass on the device: what
+ * this side needs (get_missing_deps, automerge.rs:1776-1799), the Bloom filter of the changes since the shared heads
+ * (make_bloom_filter, sync.rs:243-250), the changes the peer lacks (get_changes_to_send, sync.rs:252-321, probing the
+ * peer's filters with BloomFilter::contains_hash, sync/bloom.rs:69-123), the reset message for a peer whose last_sync
+ * is unknown here (sync.rs:150-166), the "nothing to say" cases (:178-205), and the bytes of Message::encode
+ * (sync.rs:526-563) with the change chunks copied out of the batch's device memory.
+ * amh_sync_state is sync::State (sync/state.rs:31-53) as the reference reads it; hashes are 32 bytes each, lists in the
+ * order the State holds them (shared_heads goes into the message as it is).  flags: which of the Option fields are Some,
+ * and in_flight.  A Bloom filter is its wire form (BloomFilter::to_bytes; empty = the default filter).
+ * Results per record: kinds[i] = AMH_SYNC_NONE (generate_sync_message returned None: msgs[i] is empty),
+ * AMH_SYNC_MESSAGE (msgs[i] = the encoded message; the caller then does what sync.rs:207-219 does to the State:
+ * last_sent_heads = the document's heads, sent_hashes += the 32-byte hashes in sent[i], in_flight = true),
+ * AMH_SYNC_RESET (msgs[i] = the reset message; the State stays as it is) or AMH_SYNC_FAILED (the document failed to
+ * load).  msgs and sent are arrays of n amh_bytes_out, each freed with amh_bytes_free; sent may be NULL.
+ * A filter with entries but no bits (the reference divides by zero on it) is AMH_ERR_INVALID_ARG.
+ * The receiving side (receive_sync_message, sync.rs:323-383) is not part of the library yet: a caller applies a
+ * message's changes with amh_apply_changes and keeps the State itself (tests/sync_cases.py shows the loop). */
+typedef struct amh_sync_have {
+  const uint8_t* last_sync32; size_t n_last_sync;
+  const uint8_t* bloom; size_t bloom_len;
+} amh_sync_have;
+enum { AMH_SYNC_THEIR_HEADS = 1, AMH_SYNC_THEIR_NEED = 2, AMH_SYNC_THEIR_HAVE = 4, AMH_SYNC_IN_FLIGHT = 8 };
+enum { AMH_SYNC_NONE = 0, AMH_SYNC_MESSAGE = 1, AMH_SYNC_RESET = 2, AMH_SYNC_FAILED = 3 };
+typedef struct amh_sync_state {
+  uint32_t doc;
+  uint32_t flags;
+  const uint8_t* shared_heads32; size_t n_shared_heads;
+  const uint8_t* last_sent_heads32; size_t n_last_sent_heads;
+  const uint8_t* their_heads32; size_t n_their_heads;
+  const uint8_t* their_need32; size_t n_their_need;
+  const amh_sync_have* their_have; size_t n_their_have;
+  const uint8_t* sent_hashes32; size_t n_sent_hashes;
+} amh_sync_state;
+int amh_generate_sync_messages(amh_ctx*, const amh_batch*, const amh_sync_state* states, size_t n, uint32_t* kinds,
+                               amh_bytes_out* msgs, amh_bytes_out* sent);
+
 /* ---- measurement ------------------------------------------------------------------------------
  * HIP-event timing of every kernel launch of the context's stream (for bench.py's roofline leg). */
 int amh_ctx_set_profiling(amh_ctx*, int enable);

@@ -6,6 +6,7 @@
 #include "../../automerge_amd/csrc/amh_kernels.inl"
 #include "../../automerge_amd/csrc/amh_merge.inl"
 #include "../../automerge_amd/csrc/amh_apply.inl"
+#include "../../automerge_amd/csrc/amh_syncmsg.inl"
 #include "../../automerge_amd/csrc/amh_launch.h"
 
 void amh_launch(int k, const BatchDev& B, u32 n, void*) {
@@ -52,6 +53,13 @@ void amh_launch_mg(int k, const MergeDev* G, u32 n, void*) {
     default: break;
   }
 #undef M
+}
+void amh_launch_sm(int k, const SyncDev* G, u32 n, void*) {
+  for (u32 i = 0; i < n; i++) {
+    if (k == SK_LOOKUP) k_sm_lookup(*G, i);
+    else if (k == SK_PLAN) k_sm_plan(*G, i);
+    else if (k == SK_FILL) k_sm_fill(*G, i);
+  }
 }
 void amh_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst, u32 n, void*) {
   for (u32 i = 0; i < n; i++) memcpy(dst + dst_off[i], (const u8*)(uintptr_t)src[i], len[i]);

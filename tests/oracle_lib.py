@@ -37,6 +37,11 @@ for name in ("amo_heads", "amo_changes", "amo_hydrate", "amo_bloom"):
     getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
 lib.amo_save.argtypes = [C.c_void_p, C.c_int, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
 lib.amo_bloom_from_hashes.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+lib.amo_generate_sync_message.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_size_t), C.POINTER(_u8p),
+                                          C.POINTER(C.c_size_t)]
+lib.amo_receive_sync_message.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+lib.amo_sync_message_reencode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+lib.amo_bloom_contains.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
 lib.amo_num_ops.restype = C.c_ulong
 lib.amo_num_ops.argtypes = [C.c_void_p]
 lib.amo_max_op.restype = C.c_ulong
@@ -146,6 +151,18 @@ class Doc:
     def bloom(self) -> bytes:
         return _out(lib.amo_bloom, self.h)
 
+    def generate_sync_message(self, state_blob: bytes):
+        """generate_sync_message (sync.rs:134-221) over a flat State (oracle/amo_sync.hpp): (message or None, new State)"""
+        m, ml, st, sl = _u8p(), C.c_size_t(), _u8p(), C.c_size_t()
+        rc = lib.amo_generate_sync_message(self.h, state_blob, len(state_blob), C.byref(m), C.byref(ml), C.byref(st), C.byref(sl))
+        if rc < 0:
+            raise OracleError()
+        return (C.string_at(m, ml.value) if rc == 1 else None), C.string_at(st, sl.value)
+
+    def receive_sync_message(self, state_blob: bytes, msg: bytes) -> bytes:
+        """receive_sync_message (sync.rs:323-383): applies the message, returns the new flat State"""
+        return _out(lib.amo_receive_sync_message, self.h, state_blob, len(state_blob), msg, len(msg))
+
     def num_ops(self) -> int:
         return lib.amo_num_ops(self.h)
 
@@ -154,6 +171,17 @@ class Doc:
 
     def queue_len(self) -> int:
         return lib.amo_queue_len(self.h)
+
+
+def sync_message_reencode(msg: bytes) -> bytes:
+    return _out(lib.amo_sync_message_reencode, msg, len(msg))
+
+
+def bloom_contains(bloom: bytes, h: bytes) -> bool:
+    r = lib.amo_bloom_contains(bloom, len(bloom), h)
+    if r < 0:
+        raise OracleError()
+    return r == 1
 
 
 def sha256(data: bytes) -> bytes:

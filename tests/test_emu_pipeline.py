@@ -373,3 +373,24 @@ def test_partition_docs_balances_bytes(emu):
             if n:
                 loads = [sum(lens[first[k]:first[k + 1]]) for k in range(world)]
                 assert max(loads) <= sum(lens) / world + max(lens)
+
+
+def test_sync_conversations(emu):
+    """amh_generate_sync_messages beside the oracle's generate_sync_message through whole conversations: the reference's
+    own sync scenarios (sync.rs:662-987) restated over explicit change graphs"""
+    import sync_cases as sc
+    sc.check_basic_rules(emu)
+    sc.check_simultaneous_messages(emu)
+    sc.check_false_positive_head(emu)
+    sc.check_chains_of_false_positives(emu)
+    sc.check_branching_and_merging(emu)
+    sc.check_in_flight(emu)
+    sc.check_reset_and_queue(emu)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_sync_messages_random_states(emu, seed):
+    """random States over random change graphs: every branch of generate_sync_message against the oracle, byte for byte"""
+    import sync_cases as sc
+    kinds = sc.check_random_states(emu, 0x5C00 + seed)
+    assert sum(kinds.values()) > 0

@@ -523,3 +523,24 @@ def test_checksum_outranks_reconstruction_errors(engine):
     b = engine.load_batch([bytes(d) for d in docs])
     for i in range(3000):
         assert b.status(i)[0] == (2 if i % 7 == 0 else 0), (i, b.status(i))
+
+
+def test_sync_conversations(engine):
+    """amh_generate_sync_messages beside the oracle's generate_sync_message through whole conversations: the reference's
+    own sync scenarios (sync.rs:662-987) restated over explicit change graphs"""
+    import sync_cases as sc
+    sc.check_basic_rules(engine)
+    sc.check_simultaneous_messages(engine)
+    sc.check_false_positive_head(engine)
+    sc.check_chains_of_false_positives(engine)
+    sc.check_branching_and_merging(engine)
+    sc.check_in_flight(engine)
+    sc.check_reset_and_queue(engine)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_sync_messages_random_states(engine, seed):
+    """random States over random change graphs: every branch of generate_sync_message against the oracle, byte for byte"""
+    import sync_cases as sc
+    kinds = sc.check_random_states(engine, 0x5C00 + seed)
+    assert sum(kinds.values()) > 0

@@ -6,6 +6,7 @@
 // Nothing from the reference is copied into the repository; only the data this script prints.
 import { Encoder, Decoder, RLEEncoder, RLEDecoder, DeltaEncoder, DeltaDecoder, BooleanEncoder, BooleanDecoder } from "./encoding.mjs"
 import { encodeChange, decodeChange, decodeDocument, decodeChanges } from "./columnar.mjs"
+import { BloomFilter, encodeSyncMessage, encodeSyncState } from "./sync.mjs"
 import fs from "fs"
 
 const hex = b => Buffer.from(b).toString("hex")
@@ -271,4 +272,34 @@ if (mode === "decode_doc") {
   // argv[3] = a document written by our oracle; argv[4] = output: per re-derived change its hash and op count
   const changes = decodeDocument(fs.readFileSync(process.argv[3]))
   fs.writeFileSync(process.argv[4], JSON.stringify(changes.map(c => ({ hash: decodeChange(encodeChange(c)).hash, actor: c.actor, seq: c.seq, startOp: c.startOp, nops: c.ops.length }))))
+}
+
+if (mode === "sync") {
+  // the sync protocol's wire forms, from the reference's legacy JS implementation (javascript/test/legacy/sync.js):
+  // Bloom filters over given hashes with probe results, encoded messages, encoded states
+  const rh = () => { let h = ""; for (let j = 0; j < 64; j++) h += "0123456789abcdef"[ri(16)]; return h }
+  const hashes = n => { const out = []; for (let i = 0; i < n; i++) out.push(rh()); return out }
+  const out = { blooms: [], messages: [], states: [] }
+  for (const n of [0, 1, 2, 3, 8, 17, 64, 200, 1000]) {
+    const members = hashes(n)
+    const f = new BloomFilter(members)
+    const probes = hashes(200).map(h => ({ hash: h, contains: f.containsHash(h) }))
+    for (const h of members) if (!f.containsHash(h)) throw new Error("member not found")
+    out.blooms.push({ members, hex: hex(f.bytes), probes })
+  }
+  for (let t = 0; t < 24; t++) {
+    const have = []
+    const nh = [0, 1, 1, 2, 3][ri(5)]
+    for (let i = 0; i < nh; i++) have.push({ lastSync: hashes(ri(4)).sort(), bloom: ri(4) === 0 ? new Uint8Array(0) : new BloomFilter(hashes(1 + ri(40))).bytes })
+    const changes = []
+    const nc = ri(5)
+    for (let i = 0; i < nc; i++) { const l = [0, 1, 127, 128, 300, 20000][ri(6)]; const c = new Uint8Array(l); for (let j = 0; j < l; j++) c[j] = ri(256); changes.push(c) }
+    const msg = { heads: hashes(ri(4)).sort(), need: hashes(ri(4)).sort(), have, changes }
+    out.messages.push({ heads: msg.heads, need: msg.need, have: have.map(h => ({ lastSync: h.lastSync, bloom: hex(h.bloom) })), changes: changes.map(hex), hex: hex(encodeSyncMessage(msg)) })
+  }
+  for (let t = 0; t < 6; t++) {
+    const sharedHeads = hashes(t).sort()
+    out.states.push({ sharedHeads, hex: hex(encodeSyncState({ sharedHeads })) })
+  }
+  fs.writeFileSync(process.argv[3], JSON.stringify(out))
 }
