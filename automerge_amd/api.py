@@ -58,8 +58,10 @@ EXPORTS = [
     "amh_sync_summaries", "amh_ctx_set_profiling", "amh_ctx_num_kernels", "amh_ctx_kernel_name", "amh_ctx_kernel_time",
     "amh_ctx_reset_profile", "amh_gen_map_docs", "amh_gen_text_docs", "amh_u64_free", "amh_apply_batch", "amh_doc_queue_len", "amh_merge_many", "amh_save_after",
     "amh_sync_summaries_noalloc", "amh_ctx_pool_bytes", "amh_ctx_set_limits", "amh_batch_release_ops", "amh_comm_unique_id", "amh_comm_init", "amh_sync_summaries_all",
-    "amh_partition_docs", "amh_text_batch", "amh_text_batch_device", "amh_generate_sync_messages",
+    "amh_partition_docs", "amh_text_batch", "amh_text_batch_device", "amh_generate_sync_messages", "amh_generate_sync_messages_device", "amh_save_after_batch",
 ]
+
+AMH_ERR_DOC_FAILED = -7
 
 DOC_ERRORS = {
     0: "Ok", 1: "Parse", 2: "BadChecksum", 3: "InvalidChangeColumns", 5: "MissingDeps", 6: "DuplicateSeqNumber",
@@ -122,8 +124,12 @@ def bind(lib):
                                     C.POINTER(C.c_int)]
     lib.amh_doc_queue_len.argtypes = [vp, C.c_uint32, C.POINTER(C.c_size_t)]
     lib.amh_save_after.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_size_t, C.POINTER(BytesOut)]
+    lib.amh_save_after_batch.argtypes = [vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(BytesOut),
+                                         C.POINTER(C.POINTER(C.c_uint64))]
+    lib.amh_generate_sync_messages_device.argtypes = [vp, vp, C.POINTER(SyncStateC), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(vp),
+                                                      C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]
     lib.amh_generate_sync_messages.argtypes = [vp, vp, C.POINTER(SyncStateC), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(BytesOut),
-                                               C.POINTER(BytesOut)]
+                                               C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(BytesOut), C.POINTER(C.POINTER(C.c_uint64))]
     lib.amh_merge_many.argtypes = [vp, vp, C.POINTER(vp), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]
     return lib
 
@@ -420,12 +426,49 @@ class Batch:
             raise EngineError(f"amh_text_batch_device failed: {rc} {self.engine._err()}")
         return d_text.value, d_off.value, total.value
 
+    def save_after_many(self, items):
+        """Automerge::save_after for every (document index, heads) of `items` in one device pass (amh_save_after_batch)"""
+        n = len(items)
+        docs = (C.c_uint32 * max(n, 1))(*[d for d, _ in items])
+        raws = [b"".join(h) for _, h in items]
+        ptrs = (C.c_char_p * max(n, 1))(*raws)
+        cnts = (C.c_size_t * max(n, 1))(*[len(h) for _, h in items])
+        o, off = BytesOut(), C.POINTER(C.c_uint64)()
+        rc = self.engine.lib.amh_save_after_batch(self.engine.ctx, self.h, docs, ptrs, cnts, n, C.byref(o), C.byref(off))
+        if rc != 0 and rc != AMH_ERR_DOC_FAILED:
+            raise EngineError(f"amh_save_after_batch failed: {rc} {self.engine._err()}")
+        raw = C.string_at(o.data, o.len) if o.data and o.len else b""
+        out = [raw[off[i]:off[i + 1]] for i in range(n)]
+        self.engine.lib.amh_bytes_free(C.byref(o))
+        self.engine.lib.amh_u64_free(off)
+        return out
+
     def generate_sync_messages(self, states):
         """SyncDoc::generate_sync_message (sync.rs:134-221) for every (document index, SyncState) of `states` in one
-        pass on the device.  Returns the encoded messages (None where the reference returns None) and updates the
-        States the way sync.rs:207-219 does."""
+        pass on the device.  Returns the encoded messages (None where the reference returns None; the AutomergeError of
+        the load for a record whose document failed to load) and updates the States the way sync.rs:207-219 does."""
         n = len(states)
-        arr = (SyncStateC * n)()
+        arr, _keep = self.sync_state_array(states)
+        kinds, raw, moff, sent, soff = self.generate_sync_messages_raw(arr, n)
+        out = []
+        for k in range(n):
+            if kinds[k] == 3:   # the document failed to load: there is no Automerge to ask (the error its load gave)
+                out.append(AutomergeError(*self.status(states[k][0])))
+                continue
+            m = raw[moff[k]:moff[k + 1]] if kinds[k] in (1, 2) else None
+            if kinds[k] == 1:
+                st = states[k][1]
+                st.last_sent_heads = SyncMessage.decode(m).heads
+                st.sent_hashes.update(sent[i:i + 32] for i in range(soff[k], soff[k + 1], 32))
+                st.in_flight = True
+            out.append(m)
+        return out
+
+    @staticmethod
+    def sync_state_array(states):
+        """[(document index, SyncState)] as the amh_sync_state array of the C ABI (+ the objects that keep its pointers alive)"""
+        n = len(states)
+        arr = (SyncStateC * max(n, 1))()
         keep = []
         for k, (doc, st) in enumerate(states):
             c = arr[k]
@@ -450,25 +493,40 @@ class Batch:
                 ha[j].bloom, ha[j].bloom_len = h.bloom, len(h.bloom)
             keep.append(ha)
             c.their_have, c.n_their_have = ha, len(haves)
+        return arr, keep
+
+    def generate_sync_messages_device(self, state_array, n):
+        """amh_generate_sync_messages_device: the messages stay in HBM.  (kinds, d_msgs, d_msg_off, total bytes, d_sent,
+        d_sent_idx, changes sent), device addresses as integers, valid until the next call on this batch."""
         kinds = (C.c_uint32 * max(n, 1))()
-        msgs = (BytesOut * max(n, 1))()
-        sent = (BytesOut * max(n, 1))()
-        rc = self.engine.lib.amh_generate_sync_messages(self.engine.ctx, self.h, arr, n, kinds, msgs, sent)
-        out = []
-        for k in range(n):
-            m = C.string_at(msgs[k].data, msgs[k].len) if msgs[k].data else None
-            sh = C.string_at(sent[k].data, sent[k].len) if sent[k].data else b""
-            self.engine.lib.amh_bytes_free(C.byref(msgs[k]))
-            self.engine.lib.amh_bytes_free(C.byref(sent[k]))
-            if rc == 0 and kinds[k] == 1:
-                st = states[k][1]
-                st.last_sent_heads = SyncMessage.decode(m).heads
-                st.sent_hashes.update(sh[i:i + 32] for i in range(0, len(sh), 32))
-                st.in_flight = True
-            out.append(m)
-        if rc != 0:
+        d_msgs, d_off, d_sent, d_idx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        total, n_sent = C.c_uint64(), C.c_uint64()
+        rc = self.engine.lib.amh_generate_sync_messages_device(self.engine.ctx, self.h, state_array, n, kinds, C.byref(d_msgs), C.byref(d_off),
+                                                               C.byref(total), C.byref(d_sent), C.byref(d_idx), C.byref(n_sent))
+        if rc != 0 and rc != AMH_ERR_DOC_FAILED:
+            raise EngineError(f"amh_generate_sync_messages_device failed: {rc} {self.engine._err()}")
+        return kinds, d_msgs.value, d_off.value, total.value, d_sent.value, d_idx.value, n_sent.value
+
+    def generate_sync_messages_raw(self, state_array, n, want_sent=True, offsets=True):
+        """amh_generate_sync_messages over a prepared SyncStateC array: (kinds, message bytes, offsets, sent hashes, offsets)"""
+        kinds = (C.c_uint32 * max(n, 1))()
+        msgs, sent = BytesOut(), BytesOut()
+        moff, soff = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
+        rc = self.engine.lib.amh_generate_sync_messages(self.engine.ctx, self.h, state_array, n, kinds, C.byref(msgs), C.byref(moff),
+                                                        C.byref(sent) if want_sent else None, C.byref(soff) if want_sent else None)
+        raw = C.string_at(msgs.data, msgs.len) if msgs.data and msgs.len else b""
+        sh = C.string_at(sent.data, sent.len) if want_sent and sent.data and sent.len else b""
+        mo = [moff[i] for i in range(n + 1)] if moff and offsets else None
+        so = [soff[i] for i in range(n + 1)] if want_sent and soff and offsets else None
+        self.engine.lib.amh_bytes_free(C.byref(msgs))
+        self.engine.lib.amh_bytes_free(C.byref(sent))
+        if moff:
+            self.engine.lib.amh_u64_free(moff)
+        if soff:
+            self.engine.lib.amh_u64_free(soff)
+        if rc != 0 and not (rc == AMH_ERR_DOC_FAILED and offsets):   # failed documents: their records say so (kind 3)
             raise EngineError(f"amh_generate_sync_messages failed: {rc} {self.engine._err()}")
-        return out
+        return (list(kinds[:n]) if offsets else kinds), raw, mo, sh, so
 
     def sync_summaries_raw(self):
         """All sync summary records of the batch as one bytes object (amh_sync_summaries)."""

@@ -187,6 +187,8 @@ struct amh_batch {
   mutable std::string msg_buf;
   u32 tot_ht = 0, tot_map = 0, tot_out = 0;
   bool history_only = false;   // amh_batch_release_ops: the per-op arrays are gone, the history (changes, hashes, heads) stays
+  DevAlloc sm_msg, sm_sent, sm_off, sm_job;   // amh_generate_sync_messages_device: the messages of the last call (sm_to_device)
+  u64 sm_total = 0, sm_jobs = 0; u32 sm_n = 0;
   DevAlloc text_out, text_doc; // amh_text_batch_device: the texts of the last call, kept until the next one or until the batch is freed
   u64 text_total = 0;
   mutable HostView hv;
@@ -297,6 +299,44 @@ static bool scan_inplace(amh_batch* b, u32* data, u32 n, u32* total) {
   return true;
 }
 
+// A large result into caller-visible (pageable) host memory: through the context's two pinned buffers, the DMA of one
+// piece running while the host copies the piece before it out (a pageable hipMemcpy runs at a fraction of the link).
+static bool ensure_pins(amh_ctx* ctx) {
+  const size_t PIN = (size_t)32 << 20;
+  for (int k = 0; k < 2; k++)
+    if (!ctx->pin[k]) {
+      ctx->pin[k] = (u8*)rt_host_alloc(PIN);
+      rt_event_create(&ctx->ev_pin[k]);
+      if (!ctx->pin[k]) return false;
+    }
+  return true;
+}
+static bool d2h_large(amh_ctx* ctx, void* dst, const void* d_src, size_t n) {
+  const size_t PIN = (size_t)32 << 20;
+  if (n < ((size_t)4 << 20) || !ensure_pins(ctx)) return rt_d2h(dst, d_src, n, ctx->stream);
+  const size_t pieces = (n + PIN - 1) / PIN;
+  bool ok = true;
+  for (size_t i = 0; i <= pieces && ok; i++) {
+    if (i < pieces) {
+      const size_t o = i * PIN, l = std::min(PIN, n - o);
+      ok = rt_d2h_async(ctx->pin[i & 1], (const u8*)d_src + o, l, ctx->stream);
+      rt_event_record(&ctx->ev_pin[i & 1], ctx->stream);
+    }
+    if (i > 0) {
+      const size_t o = (i - 1) * PIN, l = std::min(PIN, n - o);
+      rt_event_sync(&ctx->ev_pin[(i - 1) & 1]);
+      // fresh pageable memory faults its pages in on first touch: four threads take a quarter of the piece each
+      const u8* src = ctx->pin[(i - 1) & 1];
+      const size_t q = ((l / 4) + 4095) & ~(size_t)4095;
+      std::thread th[3];
+      for (int t = 0; t < 3; t++) th[t] = std::thread([=]() { const size_t a = std::min(l, (size_t)(t + 1) * q), e = std::min(l, (size_t)(t + 2) * q); if (e > a) memcpy((u8*)dst + o + a, src + a, e - a); });
+      memcpy((u8*)dst + o, src, std::min(l, q));
+      for (int t = 0; t < 3; t++) th[t].join();
+    }
+  }
+  return ok && rt_sync(ctx->stream);
+}
+
 // ---------------------------------------------------------------------------------------------
 // stage: host ingest + one H2D copy
 // ---------------------------------------------------------------------------------------------
@@ -348,12 +388,7 @@ extern "C" amh_staged* amh_stage_batch(amh_ctx* ctx, const uint8_t* const* docs,
   // host (actor ids, keys of a hydrate) fetch it on first use, except for batches with documents large enough for
   // host-side SHA-256 (those threads read the mirror while the device pipeline runs).
   const size_t PIN = (size_t)32 << 20;
-  for (int k = 0; k < 2; k++)
-    if (!ctx->pin[k]) {
-      ctx->pin[k] = (u8*)rt_host_alloc(PIN);
-      rt_event_create(&ctx->ev_pin[k]);
-      if (!ctx->pin[k]) { set_error(ctx, "out of pinned host memory while staging"); staged_unref(st); return nullptr; }
-    }
+  if (!ensure_pins(ctx)) { set_error(ctx, "out of pinned host memory while staging"); staged_unref(st); return nullptr; }
   if (any_large) st->h_arena.assign(st->arena_bytes, 0);
   st->host_ok = any_large;
   bool ok = rt_h2d(st->d_doc_off.p, se.data(), se.size() * sizeof(u64), ctx->stream);
@@ -406,6 +441,7 @@ extern "C" void amh_staged_free(amh_staged* s) { staged_unref(s); }
 extern "C" void amh_batch_free(amh_batch* b) {
   if (!b) return;
   for (auto& a : b->allocs) b->ctx->pool.release(a.p, a.cap);
+  for (DevAlloc* a : {&b->sm_msg, &b->sm_sent, &b->sm_off, &b->sm_job}) if (a->p) b->ctx->pool.release(a->p, a->cap);
   if (b->text_out.p) b->ctx->pool.release(b->text_out.p, b->text_out.cap);
   if (b->text_doc.p) b->ctx->pool.release(b->text_doc.p, b->text_doc.cap);
   staged_unref(b->staged);
@@ -577,11 +613,15 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, struct BigSha& big, cons
 // change view, the id tables; succ: entries, preds and the delete table; changes: metadata and column lengths), a
 // little on the high side
 static u64 derived_bytes(u64 rows, u64 succ, u64 chg, u64 deps, u64 map) { return rows * 224 + succ * 72 + chg * 420 + deps * 8 + map * 4; }
+// What a batch may need before its largest documents are failed one by one (AMH_DOC_TOO_LARGE): the caller's limit
+// (amh_ctx_set_limits), else 90 % of the device's TOTAL memory — a figure that does not move with what this or other
+// processes hold at the moment, so the same batch gets the same answer on every run.  A batch under the budget that
+// still does not fit what is free right now fails as a whole with AMH_ERR_OOM, as before.
 static u64 batch_byte_budget(amh_ctx* ctx) {
   if (ctx->max_batch_bytes) return ctx->max_batch_bytes;
   size_t free_b = 0, total_b = 0;
   if (!rt_mem_info(&free_b, &total_b)) return (u64)16 << 30;
-  return ((u64)free_b + ctx->pool.pooled_bytes) / 10 * 9;
+  return (u64)total_b / 10 * 9;
 }
 static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts, bool trailing) {
   if (!ctx || !st_c) { set_error(ctx, "invalid argument"); return nullptr; }
@@ -815,6 +855,7 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
   rt_memset(B.t_pred_fill, 0, ((size_t)T + 2) * 4, ctx->stream);
   launch(ctx, AK_SUCC_LINK, B, B.tot_succ);
   B.a_tab_base = balloc<u32>(b, (size_t)B.tot_actors + 2, &ok); B.a_tab = balloc<u32>(b, (size_t)B.tot_chg + 2, &ok);
+  B.a_tab_bn = balloc<u64>(b, (size_t)B.tot_actors + 2, &ok); B.a_tab_max = balloc<u32>(b, (size_t)B.tot_chg + 2, &ok);
   if (!ok) return fail("device out of memory");
   launch(ctx, AK_ATAB_BASE, B, n);
   launch(ctx, AK_ATAB_FILL, B, B.tot_chg);
@@ -3443,7 +3484,7 @@ extern "C" int amh_sync_summaries_all(amh_ctx* ctx, const amh_batch* bc, amh_byt
 #endif
 }
 // a sync message kernel, timed like the others when the context is profiling
-static const char* const SK_KERNEL_NAMES[SK_NUM] = {"sm_lookup", "sm_plan", "sm_fill"};
+static const char* const SK_KERNEL_NAMES[SK_NUM] = {"sm_lookup", "sm_plan", "sm_fill", "sm_copy"};
 static void launch_sm_timed(amh_ctx* ctx, int k, const SyncDev* G, u32 n) {
   if (n == 0) return;
   if (ctx->profiling) {
@@ -3472,19 +3513,34 @@ static bool sm_parse_bloom(const u8* p, size_t n, u32& entries, u32& probes, siz
   entries = (u32)e; probes = (u32)pr; bits_at = pos; nbytes = (u32)cap;
   return !(entries != 0 && nbytes == 0);
 }
-extern "C" int amh_generate_sync_messages(amh_ctx* ctx, const amh_batch* bc, const amh_sync_state* states, size_t n, uint32_t* kinds,
-                                          amh_bytes_out* msgs, amh_bytes_out* sent) {
-  if (!ctx || !bc || (n && (!states || !kinds || !msgs)) || n >= 0x7FFFFFFFull) { set_error(ctx, "amh_generate_sync_messages: invalid argument"); return AMH_ERR_INVALID_ARG; }
-  amh_batch* b = const_cast<amh_batch*>(bc);
-  for (size_t i = 0; i < n; i++) {
-    kinds[i] = AMH_SYNC_NONE;
-    msgs[i].data = nullptr; msgs[i].len = 0;
-    if (sent) { sent[i].data = nullptr; sent[i].len = 0; }
-  }
+// the messages of one call into device memory owned by the batch (sm_msg: message r at sm_off[r] .. sm_off[r + 1];
+// sm_sent: 32-byte hashes of the changes in message r at 32 * sm_job[r] ..), kinds to the host
+static void sm_release(amh_ctx* ctx, amh_batch* b) {
+  for (DevAlloc* a : {&b->sm_msg, &b->sm_sent, &b->sm_off, &b->sm_job}) if (a->p) { ctx->pool.release(a->p, a->cap); *a = DevAlloc(); }
+  b->sm_total = b->sm_jobs = 0; b->sm_n = 0;
+}
+static int sm_to_device(amh_ctx* ctx, amh_batch* b, const amh_sync_state* states, size_t n, uint32_t* kinds, bool raw = false) {
+  PhaseTimer pt(raw ? "amh_save_after_batch" : "amh_generate_sync_messages");
+  sm_release(ctx, b);
+  for (size_t i = 0; i < n; i++) kinds[i] = AMH_SYNC_NONE;
   if (n == 0) return AMH_SUCCESS;
-  if (!ensure_base(b)) { set_error(ctx, "amh_generate_sync_messages: D2H copy failed"); return AMH_ERR_DEVICE; }
-  const HostView& hv = b->hv;
   const u32 R = (u32)n;
+  bool ok = true;
+  CallScratch scratch(b);
+  // changes and actors of every record's document: all the host needs of the batch to lay out the per-record scratch
+  std::vector<u32> doc_sizes((size_t)R * 2);
+  {
+    std::vector<u32> docs(R);
+    for (u32 r = 0; r < R; r++) {
+      if (states[r].doc >= b->B.n_docs) { set_error(ctx, "amh_generate_sync_messages: invalid sync state"); return AMH_ERR_INVALID_ARG; }
+      docs[r] = states[r].doc;
+    }
+    u32* d_docs = balloc<u32>(b, (size_t)R * 3 + 1, &ok);
+    if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+    if (!rt_h2d(d_docs, docs.data(), (size_t)R * 4, ctx->stream)) { set_error(ctx, "H2D copy failed"); return AMH_ERR_DEVICE; }
+    amh_sm_doc_sizes(b->B, d_docs, d_docs + R, R, (void*)ctx->stream);
+    if (!rt_d2h(doc_sizes.data(), d_docs + R, (size_t)R * 8, ctx->stream)) { set_error(ctx, "D2H copy failed"); return AMH_ERR_DEVICE; }
+  }
   // ---- the States, flattened: one hash pool, per-record list bounds, the Haves and their filters ----
   std::vector<u32> r_doc(R), r_flags(R), r_list((size_t)R * SM_LISTS + 1), r_have(R + 1), pool_rec, h_ls, h_entries, h_probes, h_nbytes;
   std::vector<u64> h_bits, r_flag_base(R), r_clock_base(R), r_word_base(R);
@@ -3551,7 +3607,7 @@ extern "C" int amh_generate_sync_messages(amh_ctx* ctx, const amh_batch* bc, con
       if (nb) blooms.insert(blooms.end(), h.bloom + at, h.bloom + at + nb);
     }
     if (pool_rec.size() >= 0x7FFFFFFFull) { set_error(ctx, "amh_generate_sync_messages: too many hashes in one call"); return AMH_ERR_BATCH_TOO_LARGE; }
-    const u32 nc = b->status[s.doc] ? 0 : hv.cnt[s.doc].n_chg, na = b->status[s.doc] ? 0 : hv.desc[s.doc].n_actors;
+    const u32 nc = doc_sizes[2 * (size_t)r], na = doc_sizes[2 * (size_t)r + 1];
     r_flag_base[r] = n_flag; n_flag += nc;
     r_clock_base[r] = n_clock; n_clock += na;
     r_word_base[r] = n_word;
@@ -3560,6 +3616,7 @@ extern "C" int amh_generate_sync_messages(amh_ctx* ctx, const amh_batch* bc, con
   r_list[(size_t)R * SM_LISTS] = (u32)pool_rec.size();
   r_have[R] = (u32)h_entries.size();
   const u32 n_pool = (u32)pool_rec.size();
+  pt.mark("states flattened (host)");
   // ---- one upload: the tables side by side in one device block ----
   std::vector<u8> blob;
   auto put = [&](const void* p, size_t bytes) { size_t at = (blob.size() + 255) & ~(size_t)255; blob.resize(at + bytes); if (bytes) memcpy(blob.data() + at, p, bytes); return at; };
@@ -3570,21 +3627,21 @@ extern "C" int amh_generate_sync_messages(amh_ctx* ctx, const amh_batch* bc, con
                o_fb = put(r_flag_base.data(), R * 8), o_cb = put(r_clock_base.data(), R * 8), o_wb = put(r_word_base.data(), R * 8);
   const size_t o_G = put(nullptr, 0);
   blob.resize(o_G + sizeof(SyncDev));
-  bool ok = true;
-  CallScratch scratch(b);
   u8* d_blob = balloc<u8>(b, blob.size() + 256, &ok);
   SyncDev G;
   memset(&G, 0, sizeof G);
   G.B = b->B;
-  G.n_rec = R; G.n_pool = n_pool;
+  G.n_rec = R; G.n_pool = n_pool; G.raw = raw ? 1 : 0;
   G.pool_idx = balloc<u32>(b, (size_t)n_pool + 1, &ok);
   G.c_flag = balloc<u8>(b, n_flag + 16, &ok);
   G.clock = balloc<u64>(b, n_clock + 1, &ok);
   G.words = balloc<u32>(b, n_word + 1, &ok);
   G.r_kind = balloc<u32>(b, (size_t)R * 5 + 8, &ok);
-  G.msg_off = balloc<u32>(b, (size_t)R + 2, &ok);
-  G.job_base = balloc<u32>(b, (size_t)R + 2, &ok);
-  if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  b->sm_off.p = ctx->pool.alloc(((size_t)R + 2) * 4, &b->sm_off.cap);
+  b->sm_job.p = ctx->pool.alloc(((size_t)R + 2) * 4, &b->sm_job.cap);
+  if (!ok || !b->sm_off.p || !b->sm_job.p) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
+  G.msg_off = (u32*)b->sm_off.p;
+  G.job_base = (u32*)b->sm_job.p;
   G.r_nheads = G.r_kind + R; G.r_nneed = G.r_kind + 2 * (size_t)R; G.r_nsend = G.r_kind + 3 * (size_t)R; G.r_bloom_n = G.r_kind + 4 * (size_t)R;
   G.r_doc = (const u32*)(d_blob + o_doc); G.r_flags = (const u32*)(d_blob + o_flags); G.pool = d_blob + o_pool;
   G.pool_rec = (const u32*)(d_blob + o_prec); G.r_list = (const u32*)(d_blob + o_list); G.r_have = (const u32*)(d_blob + o_have);
@@ -3599,41 +3656,127 @@ extern "C" int amh_generate_sync_messages(amh_ctx* ctx, const amh_batch* bc, con
   u32 total = 0, jobs = 0;
   if (!scan_inplace(b, G.msg_off, R, &total) || !scan_inplace(b, G.job_base, R, &jobs)) { set_error(ctx, "scan failed"); return AMH_ERR_DEVICE; }
   if (total == 0xFFFFFFFFu || jobs == 0xFFFFFFFFu) { set_error(ctx, "sync messages exceed 4 GiB: generate them in parts"); return AMH_ERR_BATCH_TOO_LARGE; }
-  G.msg_out = balloc<u8>(b, (size_t)total + 64, &ok);
-  G.sent_out = balloc<u8>(b, (size_t)jobs * 32 + 32, &ok);
+  pt.mark("upload + lookup + plan + scans");
+  b->sm_msg.p = ctx->pool.alloc((size_t)total + 64, &b->sm_msg.cap);
+  b->sm_sent.p = ctx->pool.alloc((size_t)jobs * 32 + 32, &b->sm_sent.cap);
+  ok = ok && b->sm_msg.p && b->sm_sent.p;
+  G.msg_out = (u8*)b->sm_msg.p;
+  G.sent_out = (u8*)b->sm_sent.p;
   G.job_src = balloc<u64>(b, (size_t)jobs + 1, &ok);
   G.job_dst = balloc<u64>(b, (size_t)jobs + 1, &ok);
   G.job_len = balloc<u32>(b, (size_t)jobs + 1, &ok);
   if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
   if (!rt_h2d(dG, &G, sizeof G, ctx->stream)) { set_error(ctx, "H2D copy failed"); return AMH_ERR_DEVICE; }
   launch_sm_timed(ctx, SK_FILL, dG, R);
-  if (jobs) amh_copy_bytes64(G.job_src, G.job_len, G.job_dst, G.msg_out, jobs, (void*)ctx->stream);
-  std::vector<u8> h_msg((size_t)total + 1), h_sent((size_t)jobs * 32 + 1);
-  std::vector<u32> h_off(R + 1), h_job(R + 1), h_kind(R);
-  if (!rt_d2h(h_msg.data(), G.msg_out, total, ctx->stream) || !rt_d2h(h_sent.data(), G.sent_out, (size_t)jobs * 32, ctx->stream) ||
-      !rt_d2h(h_off.data(), G.msg_off, ((size_t)R + 1) * 4, ctx->stream) || !rt_d2h(h_job.data(), G.job_base, ((size_t)R + 1) * 4, ctx->stream) ||
-      !rt_d2h(h_kind.data(), G.r_kind, (size_t)R * 4, ctx->stream)) { set_error(ctx, "D2H copy failed"); return AMH_ERR_DEVICE; }
-  collect_profile(ctx);
-  int rc = AMH_SUCCESS;
-  for (u32 r = 0; r < R; r++) {
-    kinds[r] = h_kind[r];
-    if (h_kind[r] == SMK_FAILED) { rc = AMH_ERR_DOC_FAILED; continue; }
-    const size_t len = h_off[r + 1] - h_off[r];
-    if (len) {
-      msgs[r].data = (uint8_t*)malloc(len);
-      if (!msgs[r].data) return AMH_ERR_OOM;
-      memcpy(msgs[r].data, h_msg.data() + h_off[r], len);
-      msgs[r].len = len;
-    }
-    const size_t ns = h_job[r + 1] - h_job[r];
-    if (sent && ns) {
-      sent[r].data = (uint8_t*)malloc(ns * 32);
-      if (!sent[r].data) return AMH_ERR_OOM;
-      memcpy(sent[r].data, h_sent.data() + (size_t)h_job[r] * 32, ns * 32);
-      sent[r].len = ns * 32;
-    }
+  if (jobs) {
+    amh_ctx::Pending p;
+    p.k = AK_NUM + MK_NUM + SK_COPY;
+    if (ctx->profiling) { rt_event_create(&p.a); rt_event_create(&p.b); rt_event_record(&p.a, ctx->stream); }
+    amh_copy_bytes64(G.job_src, G.job_len, G.job_dst, G.msg_out, jobs, (void*)ctx->stream);
+    if (ctx->profiling) { rt_event_record(&p.b, ctx->stream); ctx->pending.push_back(p); }
   }
+  std::vector<u32> h_kind(R);
+  if (!rt_d2h(h_kind.data(), G.r_kind, (size_t)R * 4, ctx->stream)) { set_error(ctx, std::string("device pipeline failed: ") + rt_last_error()); return AMH_ERR_DEVICE; }
+  pt.mark("fill + copy", &ctx->stream);
+  collect_profile(ctx);
+  b->sm_total = total; b->sm_jobs = jobs; b->sm_n = R;
+  int rc = AMH_SUCCESS;
+  for (u32 r = 0; r < R; r++) { kinds[r] = h_kind[r]; if (h_kind[r] == SMK_FAILED) rc = AMH_ERR_DOC_FAILED; }
   if (rc == AMH_ERR_DOC_FAILED) set_error(ctx, "amh_generate_sync_messages: some records name documents that failed to load");
+  return rc;
+}
+extern "C" int amh_generate_sync_messages_device(amh_ctx* ctx, const amh_batch* bc, const amh_sync_state* states, size_t n, uint32_t* kinds,
+                                                 const uint8_t** d_msgs, const uint32_t** d_msg_off, uint64_t* total,
+                                                 const uint8_t** d_sent, const uint32_t** d_sent_idx, uint64_t* n_sent) {
+  if (!ctx || !bc || !d_msgs || !d_msg_off || !total || (n && (!states || !kinds)) || n >= 0x7FFFFFFFull) { set_error(ctx, "amh_generate_sync_messages_device: invalid argument"); return AMH_ERR_INVALID_ARG; }
+  amh_batch* b = const_cast<amh_batch*>(bc);
+  *d_msgs = nullptr; *d_msg_off = nullptr; *total = 0;
+  if (d_sent) *d_sent = nullptr;
+  if (d_sent_idx) *d_sent_idx = nullptr;
+  if (n_sent) *n_sent = 0;
+  int rc = sm_to_device(ctx, b, states, n, kinds);
+  if (rc != AMH_SUCCESS && rc != AMH_ERR_DOC_FAILED) { sm_release(ctx, b); return rc; }
+  *d_msgs = (const uint8_t*)b->sm_msg.p; *d_msg_off = (const uint32_t*)b->sm_off.p; *total = b->sm_total;
+  if (d_sent) *d_sent = (const uint8_t*)b->sm_sent.p;
+  if (d_sent_idx) *d_sent_idx = (const uint32_t*)b->sm_job.p;
+  if (n_sent) *n_sent = b->sm_jobs;
+  return rc;
+}
+extern "C" int amh_generate_sync_messages(amh_ctx* ctx, const amh_batch* bc, const amh_sync_state* states, size_t n, uint32_t* kinds,
+                                          amh_bytes_out* msgs, uint64_t** msg_off, amh_bytes_out* sent, uint64_t** sent_off) {
+  if (!ctx || !bc || !msgs || !msg_off || (sent && !sent_off) || (n && (!states || !kinds)) || n >= 0x7FFFFFFFull) { set_error(ctx, "amh_generate_sync_messages: invalid argument"); return AMH_ERR_INVALID_ARG; }
+  amh_batch* b = const_cast<amh_batch*>(bc);
+  msgs->data = nullptr; msgs->len = 0; *msg_off = nullptr;
+  if (sent) { sent->data = nullptr; sent->len = 0; *sent_off = nullptr; }
+  struct OutGuard {   // a failed call hands nothing out
+    amh_ctx* ctx; amh_batch* b; amh_bytes_out *m, *s; uint64_t **mo, **so; bool keep = false;
+    ~OutGuard() {
+      sm_release(ctx, b);   // the host copy is the result of this entry point: nothing stays on the device
+      if (keep) return;
+      amh_bytes_free(m); free(*mo); *mo = nullptr;
+      if (s) { amh_bytes_free(s); free(*so); *so = nullptr; }
+    }
+  } guard{ctx, b, msgs, sent, msg_off, sent_off};
+  *msg_off = (uint64_t*)calloc(n + 1, sizeof(uint64_t));
+  if (sent) *sent_off = (uint64_t*)calloc(n + 1, sizeof(uint64_t));
+  if (!*msg_off || (sent && !*sent_off)) return AMH_ERR_OOM;
+  int rc = sm_to_device(ctx, b, states, n, kinds);
+  if (rc != AMH_SUCCESS && rc != AMH_ERR_DOC_FAILED) return rc;
+  if (n == 0) { guard.keep = true; return rc; }
+  PhaseTimer pt("amh_generate_sync_messages (host copy)");
+  const u32 R = (u32)n;
+  const size_t total = (size_t)b->sm_total, jobs = (size_t)b->sm_jobs;
+  std::vector<u32> h_off(R + 1), h_job(R + 1);
+  msgs->data = (uint8_t*)malloc(total ? total : 1);
+  if (sent) sent->data = (uint8_t*)malloc(jobs ? jobs * 32 : 1);
+  if (!msgs->data || (sent && !sent->data)) return AMH_ERR_OOM;
+  if (!d2h_large(ctx, msgs->data, b->sm_msg.p, total) || (sent && !d2h_large(ctx, sent->data, b->sm_sent.p, jobs * 32)) ||
+      !rt_d2h(h_off.data(), b->sm_off.p, ((size_t)R + 1) * 4, ctx->stream) || !rt_d2h(h_job.data(), b->sm_job.p, ((size_t)R + 1) * 4, ctx->stream)) {
+    set_error(ctx, "D2H copy failed"); return AMH_ERR_DEVICE;
+  }
+  msgs->len = total;
+  if (sent) sent->len = jobs * 32;
+  for (u32 r = 0; r <= R; r++) {
+    (*msg_off)[r] = h_off[r];
+    if (sent) (*sent_off)[r] = (uint64_t)h_job[r] * 32;
+  }
+  pt.mark("to the host");
+  guard.keep = true;
+  return rc;
+}
+// == Automerge::save_after(heads) (automerge.rs:993-1000) for many (document, heads) pairs in one pass on the device: the
+// clock of the heads' ancestors, the changes above it in history order (get_changes_clock, :1022-1047), their chunks
+// gathered in HBM and copied out once.  The sync message kernels in their raw mode (amh_syncmsg.inl).
+extern "C" int amh_save_after_batch(amh_ctx* ctx, const amh_batch* bc, const uint32_t* doc_idx, const uint8_t* const* heads32, const size_t* n_heads,
+                                    size_t n, amh_bytes_out* out, uint64_t** off) {
+  if (!ctx || !bc || !out || !off || (n && (!doc_idx || !heads32 || !n_heads)) || n >= 0x7FFFFFFFull) { set_error(ctx, "amh_save_after_batch: invalid argument"); return AMH_ERR_INVALID_ARG; }
+  amh_batch* b = const_cast<amh_batch*>(bc);
+  out->data = nullptr; out->len = 0; *off = nullptr;
+  std::vector<amh_sync_state> st(n);
+  std::vector<amh_sync_have> hv(n);
+  std::vector<uint32_t> kinds(n ? n : 1);
+  for (size_t i = 0; i < n; i++) {
+    if (n_heads[i] && !heads32[i]) { set_error(ctx, "amh_save_after_batch: invalid argument"); return AMH_ERR_INVALID_ARG; }
+    memset(&st[i], 0, sizeof st[i]);
+    hv[i] = amh_sync_have{heads32[i], n_heads[i], nullptr, 0};
+    st[i].doc = doc_idx[i];
+    st[i].flags = AMH_SYNC_THEIR_HAVE | AMH_SYNC_THEIR_NEED;
+    st[i].their_have = &hv[i];
+    st[i].n_their_have = 1;
+  }
+  uint64_t* offs = (uint64_t*)calloc(n + 1, sizeof(uint64_t));
+  if (!offs) return AMH_ERR_OOM;
+  int rc = sm_to_device(ctx, b, st.data(), n, kinds.data(), true);
+  if ((rc != AMH_SUCCESS && rc != AMH_ERR_DOC_FAILED) || n == 0) { sm_release(ctx, b); if (rc == AMH_SUCCESS) *off = offs; else free(offs); return rc; }
+  const size_t total = (size_t)b->sm_total;
+  std::vector<u32> h_off(n + 1);
+  out->data = (uint8_t*)malloc(total ? total : 1);
+  bool ok = out->data && d2h_large(ctx, out->data, b->sm_msg.p, total) && rt_d2h(h_off.data(), b->sm_off.p, (n + 1) * 4, ctx->stream);
+  sm_release(ctx, b);
+  if (!ok) { free(out->data); out->data = nullptr; free(offs); set_error(ctx, "amh_save_after_batch: copy to the host failed"); return out->data ? AMH_ERR_DEVICE : AMH_ERR_OOM; }
+  for (size_t i = 0; i <= n; i++) offs[i] = h_off[i];
+  out->len = total;
+  *off = offs;
   return rc;
 }
 extern "C" int amh_comm_unique_id(uint8_t* id128) {
@@ -3739,7 +3882,7 @@ extern "C" int amh_text_batch(amh_ctx* ctx, const amh_batch* bc, amh_bytes_out* 
   out->data = (uint8_t*)malloc(total ? total : 1);
   if (!offs || !out->data) { free(offs); free(out->data); out->data = nullptr; return AMH_ERR_OOM; }
   std::vector<u32> doc32((size_t)n + 1);
-  if (!rt_d2h(doc32.data(), b->text_doc.p, ((size_t)n + 1) * sizeof(u32), ctx->stream) || (total && !rt_d2h(out->data, b->text_out.p, total, ctx->stream)) || !rt_sync(ctx->stream)) {
+  if (!rt_d2h(doc32.data(), b->text_doc.p, ((size_t)n + 1) * sizeof(u32), ctx->stream) || (total && !d2h_large(ctx, out->data, b->text_out.p, total)) || !rt_sync(ctx->stream)) {
     free(out->data); out->data = nullptr; free(offs); set_error(ctx, "D2H copy failed"); return AMH_ERR_DEVICE;
   }
   for (u32 d = 0; d <= n; d++) offs[d] = doc32[d];

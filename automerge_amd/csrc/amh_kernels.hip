@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(64) g_encode_grp(BatchDev B) {
 // Two forms of the change re-encode.  Batches of small changes (the headline: 50 ops per change): lane = change, 64
 // changes per wave in step (g_encode_grp) — a wave per change would spend itself on per-column set-up, and the
 // scalar unit of a CU, shared by its four SIMDs, would be the limit.  Larger changes: one wave per (change, column
-// group), 64 values per step (g_encode_seg), whose cost does not depend on how the ops are spread over the changes.
+// group), 64 values per step (g_encode_one, amh_segenc1.inl), whose cost does not depend on how the ops are spread over the changes.
 static bool encode_lane_form(const BatchDev& B) {
   // AMH_ENCODE_FORM=seg | lane forces one form (tests run every document shape through both)
   const char* form = getenv("AMH_ENCODE_FORM");
@@ -1292,6 +1292,17 @@ void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream) {
     if (i < n) name(*G, i);                                                    \
   }
 AMH_GLOBAL_SM(k_sm_lookup) AMH_GLOBAL_SM(k_sm_plan) AMH_GLOBAL_SM(k_sm_fill)
+__global__ void __launch_bounds__(AMH_BLOCK) g_sm_doc_sizes(BatchDev B, const u32* doc, u32* out, u32 n) {
+  const u32 r = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  if (r >= n) return;
+  const u32 d = doc[r];
+  const bool ok = B.status[d] == 0;
+  out[2 * r] = ok ? B.cnt[d].n_chg : 0;
+  out[2 * r + 1] = ok ? B.desc[d].n_actors : 0;
+}
+void amh_sm_doc_sizes(const BatchDev& B, const u32* doc, u32* out, u32 n, void* stream) {
+  if (n) hipLaunchKernelGGL(g_sm_doc_sizes, dim3((n + AMH_BLOCK - 1) / AMH_BLOCK), dim3(AMH_BLOCK), 0, (hipStream_t)stream, B, doc, out, n);
+}
 void amh_launch_sm(int k, const SyncDev* G, u32 n, void* stream) {
   if (n == 0) return;
   hipStream_t s = (hipStream_t)stream;

@@ -1022,13 +1022,17 @@ AMH_DEV void k_atab_base(const BatchDev& B, u32 d) {
   for (u32 a = 0; a < na; a++) {
     B.a_tab_base[ab + a] = run;
     const u32 last = B.a_last_chg[ab + a];
-    if (last != AMH_EMPTY32) run += (u32)B.c_seq[last];
+    const u32 cnt = last != AMH_EMPTY32 ? (u32)B.c_seq[last] : 0;
+    B.a_tab_bn[ab + a] = (u64)run | ((u64)cnt << 32);
+    run += cnt;
   }
 }
 AMH_DEV void k_atab_fill(const BatchDev& B, u32 c) {
   const u32 d = B.c_doc[c];
   if (d >= B.n_docs || B.status[d]) return;
-  B.a_tab[B.a_tab_base[B.actor_base[d] + B.c_actor[c]] + (u32)B.c_seq[c] - 1] = c;
+  const u32 at = B.a_tab_base[B.actor_base[d] + B.c_actor[c]] + (u32)B.c_seq[c] - 1;
+  B.a_tab[at] = c;
+  B.a_tab_max[at] = B.c_max_op[c] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)B.c_max_op[c];
 }
 AMH_DEV void k_bucket(const BatchDev& B, u32 t) {
   B.t_chg[t] = AMH_EMPTY32;
@@ -1042,17 +1046,17 @@ AMH_DEV void k_bucket(const BatchDev& B, u32 t) {
   }
   u32 ctr, actor;
   op_id(B, t, ctr, actor);
-  const u32 a = B.actor_base[d] + actor;
-  const u32 last = B.a_last_chg[a];
-  if (last == AMH_EMPTY32) { amh_fail(B, d, AMH_E_COLLECT_MISSING_ACTOR); return; }
-  const u32* tab = B.a_tab + B.a_tab_base[a];
-  u32 lo = 0, hi = (u32)B.c_seq[last];   // first change of the actor with max_op >= ctr
+  const u64 bn = B.a_tab_bn[B.actor_base[d] + actor];
+  const u32 n = (u32)(bn >> 32);
+  if (n == 0) { amh_fail(B, d, AMH_E_COLLECT_MISSING_ACTOR); return; }
+  const u32* tmax = B.a_tab_max + (u32)bn;
+  u32 lo = 0, hi = n;   // first change of the actor with max_op >= ctr
   while (lo < hi) {
     const u32 mid = lo + (hi - lo) / 2;
-    if (B.c_max_op[tab[mid]] < ctr) lo = mid + 1; else hi = mid;
+    if (tmax[mid] < ctr) lo = mid + 1; else hi = mid;
   }
-  if (lo == (u32)B.c_seq[last]) { amh_fail(B, d, AMH_E_MISSING_CHANGE); return; }
-  const u32 c = tab[lo];
+  if (lo == n) { amh_fail(B, d, AMH_E_MISSING_CHANGE); return; }
+  const u32 c = B.a_tab[(u32)bn + lo];
   B.t_chg[t] = c;
   amh_atomic_inc_grouped(B.c_nops, c);
 }
@@ -1742,7 +1746,6 @@ AMH_DEV void k_chg_header(const BatchDev& B, u32 c) {
   u32 ab = B.actor_base[d], na = D.n_actors;
   u8* out = B.out_arena + B.c_out_off[c];
   u32 body_len = B.c_body_len[c];
-  u32 hdr = B.c_out_len[c] - body_len;
   u32 nd = B.c_ndeps[c];
   // both runs of header bytes go through the 16-byte register writer: magic, checksum slot (k_chg_hash), type,
   // length, dep count | (dep hashes: k_chg_hash) | actor .. column metadata

@@ -21,6 +21,7 @@ inline void* rt_host_alloc(size_t n) { return malloc(n ? n : 1); }
 inline void rt_host_free(void* p) { free(p); }
 inline bool rt_h2d(void* d, const void* h, size_t n, rt_stream) { if (n) memcpy(d, h, n); return true; }
 inline bool rt_d2h(void* h, const void* d, size_t n, rt_stream) { if (n) memcpy(h, d, n); return true; }
+inline bool rt_d2h_async(void* h, const void* d, size_t n, rt_stream) { if (n) memcpy(h, d, n); return true; }
 inline bool rt_d2d(void* d, const void* s, size_t n, rt_stream) { if (n) memcpy(d, s, n); return true; }
 inline bool rt_memset(void* d, int v, size_t n, rt_stream) { if (n) memset(d, v, n); return true; }
 inline bool rt_sync(rt_stream) { return true; }
@@ -57,6 +58,7 @@ inline bool rt_d2h(void* h, const void* d, size_t n, rt_stream s) {
   if (hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) != hipSuccess) return false;
   return hipStreamSynchronize(s) == hipSuccess;
 }
+inline bool rt_d2h_async(void* h, const void* d, size_t n, rt_stream s) { return n == 0 || hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) == hipSuccess; }   // h pinned
 inline bool rt_d2d(void* d, const void* src, size_t n, rt_stream s) { return n == 0 || hipMemcpyAsync(d, src, n, hipMemcpyDeviceToDevice, s) == hipSuccess; }
 inline bool rt_memset(void* d, int v, size_t n, rt_stream s) { return n == 0 || hipMemsetAsync(d, v, n, s) == hipSuccess; }
 inline bool rt_sync(rt_stream s) { return hipStreamSynchronize(s) == hipSuccess; }

@@ -429,7 +429,7 @@ __device__ __forceinline__ u32 sd_do_group(const BatchDev& B, u32 d, SdWave& W, 
       const u32 c0 = (C::IS_DELTA || COL == OC_VAL_META || COL == OC_SUCC_NUM) ? e2 : 0u;
       for (u32 q = 0; q < reach; q += 65536u) {
         u32 i = atomicAdd(B.fr_n, 1u);
-        if (i >= B.fr_cap) break;
+        if (i >= B.fr_cap) { amh_fail(B, d, AMH_E_TOO_LARGE); break; }   // cannot happen (fr_cap counts every possible piece): never silently
         u32* it = B.fr_items + 8 * (size_t)i;
         it[0] = COL; it[1] = d; it[2] = orow + I.rs + q; it[3] = reach - q < 65536u ? reach - q : 65536u;
         it[4] = (C::IS_DELTA) ? 0u : e0; it[5] = e1; it[6] = c0 + st * q; it[7] = st;

@@ -430,94 +430,10 @@ struct ScMarkSrc {
   }
 };
 
-// blockIdx.y of gridDim.y: the column groups are dealt over gridDim.y waves per change (1 = one wave encodes all the
-// columns of a change: batches of small changes; SC_GROUPS = a wave per group: few, large changes)
+// The change re-encode over these sources (a wave per (change, column group) walking the change view twice, size then
+// store) was round 2's g_encode_seg; round 3 replaced it by the one-pass walk over the op rows (amh_segenc1.inl).  The
+// sources stay: g_en_big (changes cut into ranges) reads the change view through them.
 #define SC_GROUPS 5
-template <bool STORE>
-__global__ void __launch_bounds__(64 * SD_WAVES) g_encode_seg(BatchDev B) {
-  const u32 wave = sd_uniform(threadIdx.x >> 6);
-  const u32 c = blockIdx.x * SD_WAVES + wave;
-  if (c >= B.tot_chg) return;
-  const u32 lane = threadIdx.x & 63;
-  u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
-  const u32 d = B.c_doc[c];
-  const bool big = B.sv_big && B.sv_big[c];   // its columns are cut into ranges (g_en_big); lengths 0 here, set by g_sv_big_total
-  const bool live = B.status[d] == 0 && !big;
-  const u32 n = live ? B.c_nops[c] : 0;
-  const u32 base = B.c_op_base[c];
-  const u8* chunk = B.arena + B.desc[d].chunk_off;
-  if (STORE && !live) return;
-  // store pass: the column lengths of the size pass (as k_chg_layout left them) once, up front; the columns lie back to back
-  u32 clen[AMH_NCOLS], coff[AMH_NCOLS];
-  u8* cols = (u8*)0;
-  if (STORE) {
-    cols = B.out_arena + (u64)B.c_out_off[c] + B.c_cols_off[c];
-    u32 o = 0;
-#pragma unroll
-    for (int k = 0; k < AMH_NCOLS; k++) { clen[k] = cl[k]; coff[k] = o; o += clen[k]; }
-  } else {
-#pragma unroll
-    for (int k = 0; k < AMH_NCOLS; k++) { clen[k] = 0; coff[k] = 0; }
-  }
-  auto out = [&](int k) -> u8* { return cols + coff[k]; };
-  auto put = [&](int k, u32 v) { if (!STORE && lane == 0) cl[k] = v; };
-  const u32 e0 = n ? ((n - 1) & ~63u) + lane : 0;   // this lane's value in the tile the walks start with
-  const bool v0 = n && e0 < n;
-  const bool all = gridDim.y == 1;
-  ScCached<uint2> cobj, cmisc;
-  ScCached<uint4> ckey, cval;
-  const u32 G0 = blockIdx.y;
-  if (all || G0 == 0) cobj.init((const uint2*)B.cv[0] + base, e0, v0);
-  if (all || G0 == 1) ckey.init((const uint4*)B.cv[2] + base, e0, v0);
-  if (all || G0 == 2) cmisc.init((const uint2*)B.cv[6] + base, e0, v0);
-  if (all || G0 == 3) cval.init((const uint4*)B.cv[8] + base, e0, v0);
-  for (u32 G = G0; G < SC_GROUPS; G += gridDim.y) {
-    if (G == 0) {   // object id (columns 0, 1) and mark names (13)
-      ScObjSrc sa{cobj, false}, sc{cobj, true};
-      u32 la = sc_rle_column<false, STORE>(sa, n, STORE ? out(0) : (u8*)0, clen[0], lane);
-      u32 lc = sc_rle_column<false, STORE>(sc, n, STORE ? out(1) : (u8*)0, clen[1], lane);
-      put(0, la); put(1, lc);
-      u32 lm = 0;
-      if (live && B.desc[d].ocol[OC_MARK_NAME].len != 0) {   // only documents with a mark column
-        ScMarkSrc sm{B, B.ops_sorted + base, chunk};
-        lm = sc_str_column<STORE>(sm, n, STORE ? out(13) : (u8*)0, clen[13], lane);
-      }
-      put(13, lm);
-    } else if (G == 1) {   // key (2, 3, 4)
-      ScKeyActorSrc sa{ckey};
-      ScKeyCtrSrc sk{ckey};
-      ScKeyStrSrc ss{ckey, chunk};
-      u32 la = sc_rle_column<false, STORE>(sa, n, STORE ? out(2) : (u8*)0, clen[2], lane);
-      u32 lk = sc_rle_column<true, STORE>(sk, n, STORE ? out(3) : (u8*)0, clen[3], lane);
-      u32 ls = sc_str_column<STORE>(ss, n, STORE ? out(4) : (u8*)0, clen[4], lane);
-      put(2, la); put(3, lk); put(4, ls);
-    } else if (G == 2) {   // insert, action, predNum, expand (5, 6, 9, 12)
-      ScInsertSrc si{cmisc};
-      ScActionSrc sa{cmisc};
-      ScPredNumSrc sp{cmisc};
-      ScExpandSrc se{cmisc};
-      u32 li = sc_bool_column<false, STORE>(si, n, STORE ? out(5) : (u8*)0, clen[5], lane);
-      u32 la = sc_rle_column<false, STORE>(sa, n, STORE ? out(6) : (u8*)0, clen[6], lane);
-      u32 lp = sc_rle_column<false, STORE>(sp, n, STORE ? out(9) : (u8*)0, clen[9], lane);
-      u32 le = sc_bool_column<true, STORE>(se, n, STORE ? out(12) : (u8*)0, clen[12], lane);
-      put(5, li); put(6, la); put(9, lp); put(12, le);
-    } else if (G == 3) {   // value (7, 8)
-      ScValMetaSrc sm{cval};
-      ScValRawSrc sr{cval, chunk};
-      u32 lm = sc_rle_column<false, STORE>(sm, n, STORE ? out(7) : (u8*)0, clen[7], lane);
-      u32 lr = sc_raw_column<STORE>(sr, n, STORE ? out(8) : (u8*)0, clen[8], lane);
-      put(7, lm); put(8, lr);
-    } else {   // pred lists (10, 11)
-      u32 pb = 0, pn = 0;
-      if (n) { pb = B.j_pred_base[base]; pn = B.j_pred_base[base + n] - pb; }
-      ScPredActorSrc sa; sa.ids = B.pred_ids + pb; sa.amap = B.chg_actor_map + B.c_map_base[c];
-      ScPredCtrSrc sc; sc.ids = sa.ids; sc.amap = sa.amap;
-      u32 la = sc_rle_column<false, STORE>(sa, pn, STORE ? out(10) : (u8*)0, clen[10], lane);
-      u32 lc = sc_rle_column<true, STORE>(sc, pn, STORE ? out(11) : (u8*)0, clen[11], lane);
-      put(10, la); put(11, lc);
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // Document save (doc_op_columns.rs:104-311; device form of k_save_size / k_save_store for the op columns 9..24): one

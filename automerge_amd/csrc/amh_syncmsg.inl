@@ -100,6 +100,17 @@ AMH_DEV void k_sm_plan(const SyncDev& G, u32 r) {
   G.msg_off[r] = 0; G.job_base[r] = 0;
   if (B.status[R.d] != 0) { G.r_kind[r] = SMK_FAILED; return; }
   for (u32 c = 0; c < R.nc; c++) R.cf[c] = 0;
+  if (G.raw) {   // save_after (automerge.rs:993-1000) = get_changes(heads): the changes above the heads' clock, history order
+    sm_clock(G, R, R.L[SM_LAST_SYNC], R.L[SM_LAST_SYNC + 1], SMC_ANC_SYNC);
+    u32 ns = 0;
+    u64 len = 0;
+    for (u32 c = 0; c < R.nc; c++) if (sm_since(G, R, c)) { R.send[ns++] = c; len += B.c_out_len[R.cb + c]; }
+    G.r_kind[r] = SMK_MESSAGE;
+    G.r_nsend[r] = ns;
+    G.job_base[r] = ns;
+    G.msg_off[r] = len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)len;
+    return;
+  }
   // our_heads: ascending by hash (get_heads, automerge.rs:1300-1304)
   u32 nh = 0;
   for (u32 c = 0; c < R.nc; c++) {
@@ -214,6 +225,19 @@ AMH_DEV void k_sm_fill(const SyncDev& G, u32 r) {
   const u32 kind = G.r_kind[r];
   if (kind != SMK_MESSAGE && kind != SMK_RESET) return;
   const SmRec R = sm_rec(G, r);
+  if (G.raw) {
+    u32 at = 0;
+    for (u32 k = 0, jb = G.job_base[r]; k < G.r_nsend[r]; k++) {
+      const u32 gc = R.cb + R.send[k], cl = B.c_out_len[gc];
+      G.job_src[jb + k] = (u64)(uintptr_t)(B.out_arena + B.c_out_off[gc]);
+      G.job_len[jb + k] = cl;
+      G.job_dst[jb + k] = (u64)G.msg_off[r] + at;
+      at += cl;
+      const u8* h = B.c_hash + (u64)gc * 32;
+      for (int b = 0; b < 32; b++) G.sent_out[(u64)(jb + k) * 32 + b] = h[b];
+    }
+    return;
+  }
   u8* o = G.msg_out + G.msg_off[r];
   u32 pos = 0;
   o[pos++] = 0x42;

@@ -88,6 +88,8 @@ struct BatchDev {
   // reference checks in — and before anything is sized or decoded.  Null = the kernel fails the document itself
   // (apply's change chunks).
   u32 *a_tab_base, *a_tab;            // [tot_actors + 1] / [tot_chg + 1] an actor's changes by sequence number (k_atab_*)
+  u64* a_tab_bn;                     // [tot_actors + 1] {a_tab_base, number of changes} of an actor in one word (k_bucket's dependent-load chain)
+  u32* a_tab_max;                    // [tot_chg + 1] max_op (saturated to 32 bits) beside a_tab: the key k_bucket searches
   u32 *cd_err, *cd_code, *cd_none;   // [n_docs * 8] change-metadata columns (k_decode_chg_cols): first change / entry that does not read, its error, "column exhausted behind the last change"
   const i32* sha_gate;
   u32 host_chain_min;      // != 0: the changes of a document with more dependency levels than the level-parallel hashing handles and at least this many changes are hashed by the host (a chain of hashes is serial: ~8 us per change on a lone lane, ~0.3 us on a core)
@@ -314,6 +316,7 @@ enum { SMK_NONE = 0, SMK_MESSAGE = 1, SMK_RESET = 2, SMK_FAILED = 3 };
 struct SyncDev {
   BatchDev B;
   u32 n_rec, n_pool;
+  u32 raw;                         // 1 = amh_save_after_batch: per record the changes since the heads in SM_LAST_SYNC, chunks back to back, no framing
   const u32 *r_doc, *r_flags;
   const u8* pool;                  // [n_pool * 32]
   const u32* pool_rec;             // [n_pool] record of the hash

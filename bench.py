@@ -548,8 +548,31 @@ def bench_sync(args, eng, rank, world, dist, torch, red_dev):
     if use_comm:
         amd_dist.init_engine_comm(eng)
 
+    # the sender side of the sync protocol for every document (amh_generate_sync_messages, sync.rs:134-221): one peer per
+    # document that holds nothing of it yet and has said so (their_heads = [], their_need = [], one Have with no
+    # last_sync and a Bloom filter over 8 hashes the document does not contain): every change is probed against the
+    # filter and goes into the message with the dependents of whatever the filter did not claim (sync.rs:276-303)
+    import ctypes as C
+    from automerge_amd.api import SyncHaveC, SyncStateC
+    import hashlib
+    bits = bytearray(10)
+    for k in range(8):   # BloomFilter::add_hash (sync/bloom.rs:69-102) of 8 foreign hashes
+        h = hashlib.sha256(b"peer %d" % k).digest()
+        x, y, z = (int.from_bytes(h[i:i + 4], "little") % 80 for i in (0, 4, 8))
+        for i in range(7):
+            if i:
+                x, y = (x + y) % 80, (y + z) % 80
+            bits[x >> 3] |= 1 << (x & 7)
+    bloom = bytes([8, 10, 7]) + bytes(bits)
+    have = (SyncHaveC * 1)()
+    have[0].last_sync32, have[0].n_last_sync, have[0].bloom, have[0].bloom_len = None, 0, bloom, len(bloom)
+    states = (SyncStateC * args.docs)()
+    for i in range(args.docs):
+        states[i].doc, states[i].flags, states[i].their_have, states[i].n_their_have = i, 7, have, 1
+    msg_bytes = msg_changes = 0
+
     def step():
-        nonlocal gathered_bytes
+        nonlocal gathered_bytes, msg_bytes, msg_changes
         b = eng.load_staged(staged)
         raw = None if use_comm else b.sync_summaries_raw()
         if dist is not None:
@@ -557,6 +580,7 @@ def bench_sync(args, eng, rank, world, dist, torch, red_dev):
             gathered_bytes = sum(len(x) for x in parts)
         else:
             gathered_bytes = len(raw)
+        _, _, _, msg_bytes, _, _, msg_changes = b.generate_sync_messages_device(states, args.docs)   # the messages stay in HBM
         return b
 
     for _ in range(args.warmup):
@@ -575,8 +599,16 @@ def bench_sync(args, eng, rank, world, dist, torch, red_dev):
     eng.reset_profile()
     b2 = eng.load_staged(staged)
     b2.sync_summaries_raw()
+    t1 = time.perf_counter()
+    b2.generate_sync_messages_device(states, args.docs)
+    sm_ms = (time.perf_counter() - t1) * 1e3
     eng.set_profiling(False)
+    t1 = time.perf_counter()
+    b2.generate_sync_messages_raw(states, args.docs, want_sent=False, offsets=False)   # the same with the bytes copied to the host
+    sm_host_ms = (time.perf_counter() - t1) * 1e3
     kt = eng.kernel_times()
+    # a peer that holds nothing is sent every change but the filter's false positives without a sent dependency (1 %)
+    assert 0.97 * st["changes"] <= msg_changes <= st["changes"], (msg_changes, st["changes"])
     tot = torch.tensor([float(elapsed), float(st["ops_loaded"]), float(st["changes"]), float(st["change_bytes"])], dtype=torch.float64, device=red_dev)
     if dist is not None:
         tmax = tot.clone()
@@ -591,12 +623,18 @@ def bench_sync(args, eng, rank, world, dist, torch, red_dev):
         out = {"metric": "ops loaded+merged/sec (node)", "value": ops_all * args.steps / elapsed_max, "unit": "ops/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32/u64", "data": "synthetic",
-               "config": {"workload": "configs[4]: sync sweep — load (re-derive + SHA-256 every change, heads) + heads/Bloom summary per document + all-gather",
+               "config": {"workload": "configs[4]: sync sweep — load (re-derive + SHA-256 every change, heads) + heads/Bloom summary per document + all-gather + one sync message per document to a peer that holds none of it",
                           "docs_per_gpu": args.docs, "docs_per_s": world * args.docs * args.steps / elapsed_max,
                           "changes_hashed_per_s": chg_all * args.steps / elapsed_max, "summary_bytes_gathered": gathered_bytes,
                           "sha256": {"kernel_ms": round(sha_ms, 3), "GB_hashed_per_s": round((chg_bytes_all / max(1, world) + st["encoded_bytes"]) / max(sha_ms, 1e-9) / 1e6, 2),
                                      "note": "VALU-integer bound (64 rounds of 32-bit ALU per 64-byte block), reported as bytes hashed, not against HBM"},
-                          "sync_kernels_ms": {k: round(kt[k][0], 3) for k in ("sync_size", "sync_fill") if k in kt}, "gen_s": round(t_gen, 2)}}
+                          "sync_kernels_ms": {k: round(kt[k][0], 3) for k in ("sync_size", "sync_fill") if k in kt},
+                          "sync_messages": {"records": args.docs, "message_bytes": msg_bytes, "changes_sent": msg_changes, "call_ms": round(sm_ms, 2), "call_with_host_copy_ms": round(sm_host_ms, 2),
+                                            "kernels_ms": {k: round(kt[k][0], 3) for k in ("sm_lookup", "sm_plan", "sm_fill", "sm_copy") if k in kt},
+                                            # the chunk copy moves every change chunk once (read + write); plan reads the change rows of a record a few times
+                                            "sm_copy_GBps": round(2 * st["change_bytes"] / max(kt.get("sm_copy", (1e-9, 0))[0], 1e-9) / 1e6, 1),
+                                            "sm_plan_GBps": round((st["changes"] * 120 + args.docs * 64) / max(kt.get("sm_plan", (1e-9, 0))[0], 1e-9) / 1e6, 1)},
+                          "gen_s": round(t_gen, 2)}}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

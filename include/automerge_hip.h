@@ -135,8 +135,14 @@ int amh_partition_docs(const size_t* lens, size_t n, int world, size_t* first);
 
 /* Limits against hostile inputs (no counterpart in the reference, which loads one document at a time and loses only
  * that document): a document whose op rows, succ entries, changes or deps exceed max_doc_rows (0 = the built-in
- * 2^28), and the largest documents of a batch whose derived device arrays would exceed max_batch_bytes (0 = what the
- * device has free), fail with AMH_DOC_TOO_LARGE; the other documents of the batch load. */
+ * 2^28), and the largest documents of a batch whose derived device arrays would exceed max_batch_bytes, fail with
+ * AMH_DOC_TOO_LARGE; the other documents of the batch load.  The size of the derived arrays is an estimate from the
+ * batch's counts (224 bytes per op row, 72 per succ entry, 420 per change, a little on the high side).
+ * max_batch_bytes = 0: 90 % of the device's total memory, a figure that does not depend on what is allocated at the
+ * moment — the same batch gets the same per-document answers on every run; a batch under it that does not fit what is
+ * free right now fails as a whole (amh_load_batch returns NULL, "device out of memory"), it does not shed documents.
+ * tests: test_byte_budget_sheds_the_largest_document (a batch just under the budget loads whole, one byte less fails
+ * exactly its largest document). */
 int amh_ctx_set_limits(amh_ctx*, uint64_t max_doc_rows, uint64_t max_batch_bytes);
 amh_staged* amh_stage_batch(amh_ctx*, const uint8_t* const* docs, const size_t* lens, size_t n);
 void amh_staged_free(amh_staged*);
@@ -232,6 +238,12 @@ int amh_save_batch(amh_ctx*, const amh_batch*, const amh_save_opts*, amh_bytes_o
  * history order — the counterpart of amh_apply_batch(incremental = 1) on the receiving side.  out is freed
  * with amh_bytes_free. */
 int amh_save_after(const amh_batch*, uint32_t doc, const uint8_t* heads32, size_t n_heads, amh_bytes_out* out);
+/* The same for n (document, heads) pairs in one pass on the device (a server sending every peer what it lacks): the clock
+ * of the heads' ancestors, the changes above it, their chunks gathered in device memory and copied out once.
+ * out = the n results back to back, result i = bytes [off[i], off[i + 1]) (freed with amh_bytes_free / amh_u64_free).
+ * A document that failed to load gives an empty result and the call returns AMH_ERR_DOC_FAILED. */
+int amh_save_after_batch(amh_ctx*, const amh_batch*, const uint32_t* doc_idx, const uint8_t* const* heads32, const size_t* n_heads,
+                         size_t n, amh_bytes_out* out, uint64_t** off);
 
 /* ---- sync summaries ---------------------------------------------------------------------------
  * per document: sorted heads (get_heads) + Bloom filter over all change hashes
@@ -262,11 +274,14 @@ int amh_sync_summaries_noalloc(amh_ctx*, const amh_batch*, uint8_t* d_out, size_
  * amh_sync_state is sync::State (sync/state.rs:31-53) as the reference reads it; hashes are 32 bytes each, lists in the
  * order the State holds them (shared_heads goes into the message as it is).  flags: which of the Option fields are Some,
  * and in_flight.  A Bloom filter is its wire form (BloomFilter::to_bytes; empty = the default filter).
- * Results per record: kinds[i] = AMH_SYNC_NONE (generate_sync_message returned None: msgs[i] is empty),
- * AMH_SYNC_MESSAGE (msgs[i] = the encoded message; the caller then does what sync.rs:207-219 does to the State:
- * last_sent_heads = the document's heads, sent_hashes += the 32-byte hashes in sent[i], in_flight = true),
- * AMH_SYNC_RESET (msgs[i] = the reset message; the State stays as it is) or AMH_SYNC_FAILED (the document failed to
- * load).  msgs and sent are arrays of n amh_bytes_out, each freed with amh_bytes_free; sent may be NULL.
+ * Results: kinds[i] = AMH_SYNC_NONE (generate_sync_message returned None: no bytes), AMH_SYNC_MESSAGE (the encoded
+ * message; the caller then does what sync.rs:207-219 does to the State: last_sent_heads = the document's heads,
+ * sent_hashes += the hashes in `sent`, in_flight = true), AMH_SYNC_RESET (the reset message; the State stays as it is)
+ * or AMH_SYNC_FAILED (the document failed to load; the call returns AMH_ERR_DOC_FAILED, the other records are served).
+ * msgs = the messages of all records back to back, message i = bytes [msg_off[i], msg_off[i + 1]); sent (may be NULL,
+ * then sent_off is ignored) = the 32-byte hashes of the changes in the messages, those of record i at
+ * [sent_off[i], sent_off[i + 1]).  msgs / sent are freed with amh_bytes_free, the offset arrays (n + 1 entries) with
+ * amh_u64_free.
  * A filter with entries but no bits (the reference divides by zero on it) is AMH_ERR_INVALID_ARG.
  * The receiving side (receive_sync_message, sync.rs:323-383) is not part of the library yet: a caller applies a
  * message's changes with amh_apply_changes and keeps the State itself (tests/sync_cases.py shows the loop). */
@@ -287,7 +302,16 @@ typedef struct amh_sync_state {
   const uint8_t* sent_hashes32; size_t n_sent_hashes;
 } amh_sync_state;
 int amh_generate_sync_messages(amh_ctx*, const amh_batch*, const amh_sync_state* states, size_t n, uint32_t* kinds,
-                               amh_bytes_out* msgs, amh_bytes_out* sent);
+                               amh_bytes_out* msgs, uint64_t** msg_off, amh_bytes_out* sent, uint64_t** sent_off);
+/* The same call with the results left in device memory (a sender that hands the bytes to a GPU-aware transport, or
+ * batches further device work): d_msgs = the messages back to back, message i = bytes [d_msg_off[i], d_msg_off[i + 1])
+ * (n + 1 u32 in device memory), total = their size; d_sent (may be NULL) = the 32-byte hashes of the changes in the
+ * messages, those of record i being entries [d_sent_idx[i], d_sent_idx[i + 1]) of it, n_sent in all.  kinds comes to
+ * the host as above.  The buffers belong to the batch and live until the next amh_generate_sync_messages* call on it or
+ * amh_batch_free. */
+int amh_generate_sync_messages_device(amh_ctx*, const amh_batch*, const amh_sync_state* states, size_t n, uint32_t* kinds,
+                                      const uint8_t** d_msgs, const uint32_t** d_msg_off, uint64_t* total,
+                                      const uint8_t** d_sent, const uint32_t** d_sent_idx, uint64_t* n_sent);
 
 /* ---- measurement ------------------------------------------------------------------------------
  * HIP-event timing of every kernel launch of the context's stream (for bench.py's roofline leg). */

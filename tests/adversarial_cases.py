@@ -212,3 +212,37 @@ def check_hostile_documents(engine, good_docs, rows_hostile, max_doc_rows):
         b.close()
     finally:
         engine.set_limits(0, 0)
+
+
+def check_byte_budget(engine, docs):
+    """amh_ctx_set_limits(max_batch_bytes): the smallest budget under which the whole batch loads is found by bisection;
+    at that budget every document loads, one byte below it exactly the largest document fails (TooLarge = 90) and the
+    others are what they were.  `docs` must have one document clearly larger than the others."""
+    def load(budget):
+        engine.set_limits(0, budget)
+        try:
+            b = engine.load_batch(docs)
+            st = [b.status(i)[0] for i in range(len(docs))]
+            heads = [b.get_heads(i) if st[i] == 0 else None for i in range(len(docs))]
+            b.close()
+            return st, heads
+        finally:
+            engine.set_limits(0, 0)
+    ref_st, ref_heads = load(1 << 40)
+    assert all(s == 0 for s in ref_st)
+    lo, hi = 1, 1 << 40          # lo: some document fails; hi: all load
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        st, _ = load(mid)
+        if all(s == 0 for s in st):
+            hi = mid
+        else:
+            lo = mid
+    st, heads = load(hi)
+    assert st == ref_st and heads == ref_heads
+    st, heads = load(hi - 1)
+    largest = max(range(len(docs)), key=lambda i: len(docs[i]))
+    assert st[largest] == 90, st
+    for i in range(len(docs)):
+        if i != largest:
+            assert st[i] == 0 and heads[i] == ref_heads[i], (i, st)

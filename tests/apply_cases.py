@@ -222,8 +222,14 @@ def check_save_after_roundtrip(engine, replicas):
     b = engine.load_batch([bytes(replicas[0]), bytes(replicas[1])])
     r0, r1 = o.Doc.load(bytes(replicas[0])), o.Doc.load(bytes(replicas[1]))
     h0 = r0.get_heads()
-    for heads in (h0, [], h0 + [b"\x07" * 32], r1.get_heads()):
+    cases = (h0, [], h0 + [b"\x07" * 32], r1.get_heads())
+    for heads in cases:
         assert b.save_after(1, heads) == r1.save_after(heads)
+    # the batched form (one device pass over many (document, heads) pairs) gives the same bytes
+    items = [(1, h) for h in cases] + [(0, h) for h in cases] + [(1, r1.get_heads()[:1]), (0, [c["hash"] for c in r0.changes()][:2])]
+    want = [(r1 if d == 1 else r0).save_after(h) for d, h in items]
+    assert b.save_after_many(items) == want
+    assert b.save_after_many([]) == []
     delta = b.save_after(1, h0)
     assert b.apply_batch([(0, delta)], incremental=True) == [0]
     r0.load_incremental(r1.save_after(h0))

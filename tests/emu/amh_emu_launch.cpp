@@ -54,6 +54,14 @@ void amh_launch_mg(int k, const MergeDev* G, u32 n, void*) {
   }
 #undef M
 }
+void amh_sm_doc_sizes(const BatchDev& B, const u32* doc, u32* out, u32 n, void*) {
+  for (u32 r = 0; r < n; r++) {
+    const u32 d = doc[r];
+    const bool ok = B.status[d] == 0;
+    out[2 * r] = ok ? B.cnt[d].n_chg : 0;
+    out[2 * r + 1] = ok ? B.desc[d].n_actors : 0;
+  }
+}
 void amh_launch_sm(int k, const SyncDev* G, u32 n, void*) {
   for (u32 i = 0; i < n; i++) {
     if (k == SK_LOOKUP) k_sm_lookup(*G, i);

@@ -406,6 +406,15 @@ def check_random_states(engine, seed):
     blobs = [to_blob(st) for _, st in records]
     eng_states = [from_blob(b) for b in blobs]
     msgs = batch.generate_sync_messages([(d, s) for (d, _), s in zip(records, eng_states)])
+    # the same call with the results left in device memory: sizes must agree (the emulation's "device" is host memory,
+    # so there the bytes are compared as well)
+    arr, _keep = batch.sync_state_array([(d, from_blob(b)) for (d, _), b in zip(records, blobs)])
+    dk, d_msgs, d_off, total, d_sent, d_idx, n_sent = batch.generate_sync_messages_device(arr, len(records))
+    assert total == sum(len(m) for m in msgs if m is not None)
+    assert n_sent == sum(len(SyncMessage.decode(m).changes) for m in msgs if m is not None)
+    if getattr(engine, "is_emulation", False) and total:
+        import ctypes
+        assert ctypes.string_at(d_msgs, total) == b"".join(m for m in msgs if m is not None)
     kinds = {"none": 0, "message": 0, "with_changes": 0, "reset": 0}
     for (d, _), blob, es, m in zip(records, blobs, eng_states, msgs):
         want, new_blob = docs[d].generate_sync_message(blob)
@@ -420,3 +429,47 @@ def check_random_states(engine, seed):
             kinds["with_changes"] += 1 if SyncMessage.decode(want).changes else 0
     batch.close()
     return kinds
+
+
+def check_golden_documents(engine, golden_dir, seed=0x601D):
+    """every golden document (the reference-written ones included) and a failed one, each with random States: the records
+    of good documents agree with the oracle, the record of the failed document reports its load error"""
+    import glob
+    import os
+    from automerge_amd import AutomergeError
+    rng = random.Random(seed)
+    files = sorted(glob.glob(os.path.join(golden_dir, "docs", "*.automerge")))
+    datas = [open(f, "rb").read() for f in files]
+    bad = bytearray(datas[0]); bad[len(bad) // 2] ^= 0x55
+    datas.insert(1, bytes(bad))
+    docs = [None if i == 1 else o.Doc.load(d) for i, d in enumerate(datas)]
+    batch = engine.load_batch(datas)
+    records = []
+    for d, doc in enumerate(docs):
+        if doc is None:
+            records.append((d, SyncState()))
+            continue
+        known = [c["hash"] for c in doc.changes()]
+        unknown = [bytes(rng.getrandbits(8) for _ in range(32)) for _ in range(2)]
+        for _ in range(3):
+            st = SyncState()
+            st.shared_heads = sorted(set(rng.sample(known, min(len(known), rng.randint(0, 2)))))
+            st.their_heads = sorted(set(rng.sample(known, min(len(known), rng.randint(0, 2))) + rng.sample(unknown, rng.randint(0, 1))))
+            st.their_need = rng.sample(known, min(len(known), rng.randint(0, 2)))
+            st.their_have = [SyncHave(sorted(rng.sample(known, min(len(known), rng.randint(0, 1)))),
+                                      o.bloom_from_hashes([h for h in known if rng.random() < 0.6]))]
+            records.append((d, st))
+    blobs = [to_blob(st) for _, st in records]
+    eng_states = [from_blob(b) for b in blobs]
+    msgs = batch.generate_sync_messages([(d, s) for (d, _), s in zip(records, eng_states)])
+    n_with_changes = 0
+    for (d, _), blob, es, m in zip(records, blobs, eng_states, msgs):
+        if docs[d] is None:
+            assert isinstance(m, AutomergeError) and to_blob(es) == blob
+            continue
+        want, new_blob = docs[d].generate_sync_message(blob)
+        assert m == want, (files[d - 1 if d > 1 else d], None if m is None else m.hex(), None if want is None else want.hex())
+        assert to_blob(es) == new_blob
+        n_with_changes += 1 if want is not None and SyncMessage.decode(want).changes else 0
+    assert n_with_changes > 0
+    batch.close()

@@ -388,9 +388,23 @@ def test_sync_conversations(emu):
     sc.check_reset_and_queue(emu)
 
 
+def test_sync_messages_for_golden_documents(emu, golden_dir):
+    import sync_cases as sc
+    sc.check_golden_documents(emu, golden_dir)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_sync_messages_random_states(emu, seed):
     """random States over random change graphs: every branch of generate_sync_message against the oracle, byte for byte"""
     import sync_cases as sc
     kinds = sc.check_random_states(emu, 0x5C00 + seed)
     assert sum(kinds.values()) > 0
+
+
+def test_byte_budget_sheds_the_largest_document(emu):
+    import adversarial_cases as adv
+    blob, offs = emu.gen_map_docs(91, 4, 3, 3, 20, 16, 1)
+    docs = [bytes(blob[offs[i]:offs[i + 1]]) for i in range(4)]
+    blob, offs = emu.gen_text_docs(92, 1, 1, 50, 3000, 100, 1)
+    docs.insert(2, bytes(blob[offs[0]:offs[1]]))
+    adv.check_byte_budget(emu, docs)

@@ -538,9 +538,23 @@ def test_sync_conversations(engine):
     sc.check_reset_and_queue(engine)
 
 
+def test_sync_messages_for_golden_documents(engine, golden_dir):
+    import sync_cases as sc
+    sc.check_golden_documents(engine, golden_dir)
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_sync_messages_random_states(engine, seed):
     """random States over random change graphs: every branch of generate_sync_message against the oracle, byte for byte"""
     import sync_cases as sc
     kinds = sc.check_random_states(engine, 0x5C00 + seed)
     assert sum(kinds.values()) > 0
+
+
+def test_byte_budget_sheds_the_largest_document(engine):
+    import adversarial_cases as adv
+    blob, offs = engine.gen_map_docs(91, 4, 3, 3, 20, 16, 1)
+    docs = [bytes(blob[offs[i]:offs[i + 1]]) for i in range(4)]
+    blob, offs = engine.gen_text_docs(92, 1, 1, 50, 3000, 100, 1)
+    docs.insert(2, bytes(blob[offs[0]:offs[1]]))
+    adv.check_byte_budget(engine, docs)
