@@ -209,10 +209,8 @@ static void save_big_launch(amh_ctx* ctx, const BatchDev& B, int phase);
 // ---------------------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------------------
-static int g_dbg_stop_after = -1;  // AMH_DEBUG_STOP_AFTER=<kernel id>: skip every kernel with a larger id (diagnostics)
 static void launch_on(amh_ctx* ctx, rt_stream st, int k, const BatchDev& B, u32 n) {
   if (n == 0) return;
-  if (g_dbg_stop_after >= 0 && k > g_dbg_stop_after) return;
   if (ctx->profiling) {
     amh_ctx::Pending p;
     p.k = k;
@@ -626,7 +624,6 @@ static u64 batch_byte_budget(amh_ctx* ctx) {
 static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts, bool trailing) {
   if (!ctx || !st_c) { set_error(ctx, "invalid argument"); return nullptr; }
   amh_staged* st = const_cast<amh_staged*>(st_c);
-  if (const char* e = getenv("AMH_DEBUG_STOP_AFTER")) g_dbg_stop_after = atoi(e);
   auto* b = new amh_batch();
   b->ctx = ctx;
   b->staged = st;

@@ -566,8 +566,10 @@ union SdBlockShared {
   SdWave w[SD_WAVES];
   DsShared s;
 };
-__global__ void __launch_bounds__(64 * SD_WAVES) g_decode_seg(BatchDev B) {
+template <bool ALL>
+__global__ void __launch_bounds__(64 * SD_WAVES) g_decode_seg(BatchDev B, u32 cmask) {
   __shared__ SdBlockShared L;
+  if (!((cmask >> blockIdx.y) & 1)) return;   // (development: AMH_DEC_CMASK times the columns one by one, tools/dev/decode_cols_time.py)
   if (blockIdx.y < 2) {
     if (threadIdx.x >= 64 || blockIdx.x * 64 >= B.n_docs) return;
     if (blockIdx.y == 0) decode_str_body<OC_KEY_STR>(B, L.s);
@@ -578,13 +580,22 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_decode_seg(BatchDev B) {
   const u32 d = blockIdx.x * SD_WAVES + wave;
   if (d >= B.n_docs || B.status[d] != 0) return;
   SdWave& w = L.w[wave];
-  switch (blockIdx.y - 2) {
+  // ALL (gridDim.y == 3): batches of many small documents (change chunks of a few hundred ops): one wave takes all the
+  // columns of its document one after the other, so that 13 waves of a handful of steps each do not pay a start each
 #define DC(i, col) case i: sd_decode_column<col>(B, d, w); break;
-    DC(0, OC_OBJ_ACTOR) DC(1, OC_OBJ_CTR) DC(2, OC_KEY_ACTOR) DC(3, OC_KEY_CTR) DC(4, OC_ID_ACTOR) DC(5, OC_ID_CTR) DC(6, OC_INSERT)
-    DC(7, OC_ACTION) DC(8, OC_VAL_META) DC(9, OC_SUCC_NUM) DC(10, OC_SUCC_ACTOR) DC(11, OC_SUCC_CTR) DC(12, OC_EXPAND)
-#undef DC
-    default: break;
+#define DC_ALL DC(0, OC_OBJ_ACTOR) DC(1, OC_OBJ_CTR) DC(2, OC_KEY_ACTOR) DC(3, OC_KEY_CTR) DC(4, OC_ID_ACTOR) DC(5, OC_ID_CTR) DC(6, OC_INSERT) \
+               DC(7, OC_ACTION) DC(8, OC_VAL_META) DC(9, OC_SUCC_NUM) DC(10, OC_SUCC_ACTOR) DC(11, OC_SUCC_CTR) DC(12, OC_EXPAND)
+  if (!ALL) {
+    switch (blockIdx.y - 2) { DC_ALL default: break; }
+  } else {
+    for (u32 y = 0; y < SD_NCOLS; y++) {
+      if (!((cmask >> (y + 2)) & 1)) continue;
+      switch (y) { DC_ALL default: break; }
+      if (B.status[d] != 0) return;
+    }
   }
+#undef DC_ALL
+#undef DC
 }
 
 // the deferred runs: a block per piece of at most 64 Ki rows
