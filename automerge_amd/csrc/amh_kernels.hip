@@ -878,13 +878,7 @@ void amh_launch(int k, const BatchDev& B, u32 n, void* stream) {
     return;
   }
   if (k == AK_DECODE_OPS) {
-    const char* cm = getenv("AMH_DEC_CMASK");
-    const char* ac = getenv("AMH_DEC_ALLCOLS");   // 1 / 0 forces the form (development)
-    const u32 small_rows = ac && ac[0] == 'a' ? (u32)atoi(ac + 1) : 0;   // "a<rows>": documents that average fewer rows than that
-    const bool all = ac ? (small_rows ? B.n_docs >= 32768 && (u64)B.tot_rows < (u64)B.n_docs * small_rows : atoi(ac) != 0) : false;
-    const dim3 gd((B.n_docs + SD_WAVES - 1) / SD_WAVES, all ? 3 : SD_NCOLS + 2), bd(64 * SD_WAVES);
-    if (all) hipLaunchKernelGGL(g_decode_seg<true>, gd, bd, 0, s, B, cm ? (u32)atoi(cm) : 0x7FFFu);
-    else hipLaunchKernelGGL(g_decode_seg<false>, gd, bd, 0, s, B, cm ? (u32)atoi(cm) : 0x7FFFu);
+    hipLaunchKernelGGL(g_decode_seg, dim3((B.n_docs + SD_WAVES - 1) / SD_WAVES, SD_NCOLS + 2), dim3(64 * SD_WAVES), 0, s, B);
     if (B.bc_n) hipLaunchKernelGGL(g_bc_decode, dim3((B.bc_cap_segs + SD_WAVES - 1) / SD_WAVES), dim3(64 * SD_WAVES), 0, s, B);
     if (B.fr_n) hipLaunchKernelGGL(g_fill_runs, dim3(2048), dim3(AMH_BLOCK), 0, s, B);
     return;

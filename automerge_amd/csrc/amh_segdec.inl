@@ -566,10 +566,8 @@ union SdBlockShared {
   SdWave w[SD_WAVES];
   DsShared s;
 };
-template <bool ALL>
-__global__ void __launch_bounds__(64 * SD_WAVES) g_decode_seg(BatchDev B, u32 cmask) {
+__global__ void __launch_bounds__(64 * SD_WAVES) g_decode_seg(BatchDev B) {
   __shared__ SdBlockShared L;
-  if (!((cmask >> blockIdx.y) & 1)) return;   // (development: AMH_DEC_CMASK times the columns one by one, tools/dev/decode_cols_time.py)
   if (blockIdx.y < 2) {
     if (threadIdx.x >= 64 || blockIdx.x * 64 >= B.n_docs) return;
     if (blockIdx.y == 0) decode_str_body<OC_KEY_STR>(B, L.s);
@@ -580,22 +578,15 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_decode_seg(BatchDev B, u32 cm
   const u32 d = blockIdx.x * SD_WAVES + wave;
   if (d >= B.n_docs || B.status[d] != 0) return;
   SdWave& w = L.w[wave];
-  // ALL (gridDim.y == 3): batches of many small documents (change chunks of a few hundred ops): one wave takes all the
-  // columns of its document one after the other, so that 13 waves of a handful of steps each do not pay a start each
+  // (measured and dropped, round 3: one wave taking all 13 columns of a small document one after the other — 90 VGPRs,
+  // 5 waves / SIMD; the 700,000 change chunks of the headline merge 11.7 -> 11.0 ms, configs[1] 5.0 -> 5.7 ms)
+  switch (blockIdx.y - 2) {
 #define DC(i, col) case i: sd_decode_column<col>(B, d, w); break;
-#define DC_ALL DC(0, OC_OBJ_ACTOR) DC(1, OC_OBJ_CTR) DC(2, OC_KEY_ACTOR) DC(3, OC_KEY_CTR) DC(4, OC_ID_ACTOR) DC(5, OC_ID_CTR) DC(6, OC_INSERT) \
-               DC(7, OC_ACTION) DC(8, OC_VAL_META) DC(9, OC_SUCC_NUM) DC(10, OC_SUCC_ACTOR) DC(11, OC_SUCC_CTR) DC(12, OC_EXPAND)
-  if (!ALL) {
-    switch (blockIdx.y - 2) { DC_ALL default: break; }
-  } else {
-    for (u32 y = 0; y < SD_NCOLS; y++) {
-      if (!((cmask >> (y + 2)) & 1)) continue;
-      switch (y) { DC_ALL default: break; }
-      if (B.status[d] != 0) return;
-    }
-  }
-#undef DC_ALL
+    DC(0, OC_OBJ_ACTOR) DC(1, OC_OBJ_CTR) DC(2, OC_KEY_ACTOR) DC(3, OC_KEY_CTR) DC(4, OC_ID_ACTOR) DC(5, OC_ID_CTR) DC(6, OC_INSERT)
+    DC(7, OC_ACTION) DC(8, OC_VAL_META) DC(9, OC_SUCC_NUM) DC(10, OC_SUCC_ACTOR) DC(11, OC_SUCC_CTR) DC(12, OC_EXPAND)
 #undef DC
+    default: break;
+  }
 }
 
 // the deferred runs: a block per piece of at most 64 Ki rows

@@ -148,7 +148,7 @@ def pmc_traffic(workload, dom):
         tj = json.load(open(os.path.join(ROOT, "profiles", f"traffic_{workload}.json")))
         if tj.get("workload") != workload:
             return None
-        forms = {"decode_ops": ["void g_decode_seg<false>(BatchDev, unsigned int)", "void g_decode_seg<true>(BatchDev, unsigned int)", "g_decode_seg(BatchDev)"], "count": ["g_count_seg(BatchDev)"],
+        forms = {"decode_ops": ["g_decode_seg(BatchDev)", "void g_decode_seg<false>(BatchDev, unsigned int)"], "count": ["g_count_seg(BatchDev)"],
                  "encode_size": ["void g_encode_one<0>(BatchDev, unsigned int, unsigned int)"] + [f"void g_encode_grp<false, {g}>(BatchDev)" for g in range(1, 7)],
                  "encode_store": ["g_encode_place(BatchDev)"] + [f"void g_encode_grp<true, {g}>(BatchDev)" for g in range(1, 7)],
                  "visible": ["g_visible_seg(BatchDev, unsigned int)"],
