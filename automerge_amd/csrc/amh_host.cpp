@@ -3770,7 +3770,12 @@ extern "C" int amh_save_after_batch(amh_ctx* ctx, const amh_batch* bc, const uin
   out->data = (uint8_t*)malloc(total ? total : 1);
   bool ok = out->data && d2h_large(ctx, out->data, b->sm_msg.p, total) && rt_d2h(h_off.data(), b->sm_off.p, (n + 1) * 4, ctx->stream);
   sm_release(ctx, b);
-  if (!ok) { free(out->data); out->data = nullptr; free(offs); set_error(ctx, "amh_save_after_batch: copy to the host failed"); return out->data ? AMH_ERR_DEVICE : AMH_ERR_OOM; }
+  if (!ok) {
+    const int e = out->data ? AMH_ERR_DEVICE : AMH_ERR_OOM;
+    free(out->data); out->data = nullptr; free(offs);
+    set_error(ctx, "amh_save_after_batch: copy to the host failed");
+    return e;
+  }
   for (size_t i = 0; i <= n; i++) offs[i] = h_off[i];
   out->len = total;
   *off = offs;

@@ -16,6 +16,7 @@ import json
 import os
 import sys
 import time
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -201,6 +202,8 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
         stats = []
         for k, (lo, hi) in enumerate(bounds):
             ids = list(range(hi - lo))
+            ids_np = np.arange(hi - lo, dtype=np.uint32)
+            src_np = np.tile(ids_np, (R - 1, 1))
             batches = []
             for r, s in enumerate(staged[k]):
                 batches.append(eng.load_staged(s))   # every replica is loaded and verified in full
@@ -214,7 +217,7 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
                     rc = batches[0].merge(batches[r], [(i, i) for i in ids])
                     assert rc == 0, rc
             else:   # the same result (history order included) with one pass over the rows
-                rc = batches[0].merge_many(batches[1:], ids, [ids] * (R - 1))
+                rc = batches[0].merge_many(batches[1:], ids_np, src_np)
                 assert rc == 0, rc
             # ... + materialize text: ReadDoc::text of every merged document, left in HBM like the inputs
             # (amh_text_batch_device); the copy to the host is timed once, outside the steps (config.text_to_host_ms)

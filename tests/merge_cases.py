@@ -163,3 +163,29 @@ def check_merge_many_duplicate_seq(engine):
     for b in srcs:
         b.close()
     bd.close()
+
+
+def check_merge_many_numpy(engine, reps):
+    """the index arguments of merge_many as numpy arrays (handed to the C ABI as they are) give what the lists give"""
+    import numpy as np
+    n_rep, n_docs = len(reps), len(reps[0])
+    out = []
+    for form in ("lists", "numpy"):
+        bd = engine.load_batch(reps[0])
+        others = [engine.load_batch(reps[r]) for r in range(1, n_rep)]
+        ids = list(range(n_docs))
+        if form == "lists":
+            rc = bd.merge_many(others, ids, [ids] * (n_rep - 1))
+        else:
+            a = np.arange(n_docs, dtype=np.uint32)
+            rc = bd.merge_many(others, a, np.tile(a, (n_rep - 1, 1)))
+        assert rc == 0
+        out.append(bd.save_all(deflate=False))
+        for b in others:
+            b.close()
+        bd.close()
+    assert out[0] == out[1]
+    ref = o.Doc.load(bytes(reps[0][0]))
+    for r in range(1, n_rep):
+        ref.merge(o.Doc.load(bytes(reps[r][0])))
+    assert out[1][0] == ref.save(deflate=False)

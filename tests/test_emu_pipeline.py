@@ -408,3 +408,10 @@ def test_byte_budget_sheds_the_largest_document(emu):
     blob, offs = emu.gen_text_docs(92, 1, 1, 50, 3000, 100, 1)
     docs.insert(2, bytes(blob[offs[0]:offs[1]]))
     adv.check_byte_budget(emu, docs)
+
+
+def test_merge_many_with_numpy_indices(emu):
+    from merge_cases import check_merge_many_numpy
+    n_docs, n_rep = 3, 4
+    blob, offs = emu.gen_text_docs(0xE172, n_docs, n_rep, 40, 160, 30, 2)
+    check_merge_many_numpy(emu, [[bytes(blob[offs[i * n_rep + r]:offs[i * n_rep + r + 1]]) for i in range(n_docs)] for r in range(n_rep)])
