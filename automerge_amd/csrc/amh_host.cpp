@@ -160,15 +160,25 @@ static void staged_unref(amh_staged* s) {
   delete s;
 }
 
+// std::vector without the zero fill of resize(): the mirrors below are overwritten in full by the copy that follows
+// (a 70,000-document batch's history is 60 MB: zeroing it first costs as much as fetching it)
+template <class T> struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  template <class U> void construct(U* p) { ::new ((void*)p) U; }
+  template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+template <class T> using HVec = std::vector<T, NoInitAlloc<T>>;
 struct HostView {  // lazily fetched mirrors for the accessors
   bool base_ok = false, chg_ok = false, out_ok = false;
-  std::vector<DocCounts> cnt;
-  std::vector<DocDesc> desc;
-  std::vector<u32> row_base, succ_base, chg_base, dep_base, actor_base, doc_max_op;
-  std::vector<u32> c_actor, c_nops, c_ndeps, c_dep_base, c_out_off, c_out_len, dep_idx, actor_off, actor_len, c_doc;
-  std::vector<u64> c_seq, c_start_op;
-  std::vector<i64> c_time;
-  std::vector<u8> c_hash, out_arena;
+  HVec<DocCounts> cnt;
+  HVec<DocDesc> desc;
+  HVec<u32> row_base, succ_base, chg_base, dep_base, actor_base, doc_max_op;
+  HVec<u32> c_actor, c_nops, c_ndeps, c_dep_base, c_out_off, c_out_len, dep_idx, actor_off, actor_len, c_doc;
+  HVec<u64> c_seq, c_start_op;
+  HVec<i64> c_time;
+  HVec<u8> c_hash, out_arena;
   std::map<u32, std::vector<u8>> heads_cache;
   // the actor tables of the documents, packed (ensure_actor_pack): what an apply reads of the documents it changes when
   // their bytes are not on the host
@@ -453,12 +463,14 @@ static bool ensure_chg(const amh_batch* b);
 extern "C" int amh_batch_release_ops(amh_ctx* ctx, amh_batch* b) {
   if (!ctx || !b) return AMH_ERR_INVALID_ARG;
   if (b->history_only) return AMH_SUCCESS;
+  PhaseTimer pt("amh_batch_release_ops");
   if (!ensure_chg(b) || !rt_sync(ctx->stream) || !rt_sync(ctx->side)) return AMH_ERR_DEVICE;   // the host's view of the history, while its sources exist
+  pt.mark("host view of the history");
   const BatchDev& B = b->B;
   const void* keep[] = {B.status, B.fail_line, B.desc, B.cnt, B.row_base, B.succ_base, B.chg_base, B.dep_base, B.actor_base, B.doc_hash, B.doc_max_op,
                         B.heads_ok, B.actor_off, B.actor_len, B.actor_rank, B.actor_by_rank, B.c_actor, B.c_seq, B.c_max_op, B.c_time, B.c_msg_off,
                         B.c_msg_len, B.c_ndeps, B.c_dep_base, B.c_extra_off, B.c_extra_len, B.c_doc, B.dep_idx, B.c_nops, B.c_start_op, B.c_is_dep,
-                        B.c_hash, B.c_out_off, B.c_out_len, B.out_arena};
+                        B.c_hash, B.c_out_off, B.c_out_len, B.out_arena, B.c_npred};
   std::vector<DevAlloc> kept;
   for (auto& a : b->allocs) {
     bool k = false;
@@ -757,6 +769,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   B.c_extra_off = balloc<u32>(b, NC, &ok); B.c_extra_len = balloc<u32>(b, NC, &ok); B.c_doc = balloc<u32>(b, NC, &ok);
   B.dep_idx = balloc<u32>(b, B.tot_deps + 1, &ok);
   B.c_nops = balloc<u32>(b, NC, &ok); B.c_start_op = balloc<u64>(b, NC, &ok); B.c_op_base = balloc<u32>(b, NC, &ok);
+  B.c_npred = balloc<u32>(b, NC, &ok);
   B.c_next_same_actor = balloc<u32>(b, NC, &ok); B.c_level = balloc<u32>(b, NC, &ok); B.c_is_dep = balloc<u8>(b, NC, &ok); B.c_hash = balloc<u8>(b, NC * 32, &ok);
   B.c_out_off = balloc<u32>(b, NC, &ok); B.c_out_len = balloc<u32>(b, NC, &ok); B.c_body_len = balloc<u32>(b, NC, &ok);
   B.c_cols_off = balloc<u32>(b, NC, &ok); B.c_col_len = balloc<u32>(b, NC * AMH_NCOLS, &ok); B.c_wide = balloc<u32>(b, NC, &ok);
@@ -1055,8 +1068,8 @@ extern "C" amh_batch* amh_load_batch(amh_ctx* ctx, const uint8_t* const* docs, c
 // ---------------------------------------------------------------------------------------------
 // host views for the accessors
 // ---------------------------------------------------------------------------------------------
-template <class T>
-static bool fetch(const amh_batch* b, std::vector<T>& v, const T* dev, size_t n) {
+template <class V, class T>
+static bool fetch(const amh_batch* b, V& v, const T* dev, size_t n) {
   v.resize(n);
   return rt_d2h(v.data(), dev, n * sizeof(T), b->ctx->stream);
 }
@@ -1788,6 +1801,7 @@ static amh_batch* rows_to_batch(amh_ctx* ctx, amh_batch* mb, const amh_batch* ds
   B.heads_ok = balloc<u32>(nb, P + 1, &ok); B.doc_level = balloc<u32>(nb, P + 1, &ok); B.max_level = balloc<u32>(nb, 4, &ok);
   B.a_first_chg = balloc<u32>(nb, NA, &ok); B.a_last_chg = balloc<u32>(nb, NA, &ok);
   B.c_nops = balloc<u32>(nb, NC, &ok); B.c_start_op = balloc<u64>(nb, NC, &ok); B.c_op_base = balloc<u32>(nb, NC, &ok);
+  B.c_npred = nullptr;   // a merged batch's changes are adopted or verified, not counted again: as a later merge source it is counted by k_ap_count
   B.c_next_same_actor = balloc<u32>(nb, NC, &ok); B.c_level = balloc<u32>(nb, NC, &ok);
   // merged from loaded batches: the documents adopt their sources' change chunks and hashes
   const bool adopt = ap && ap->all_dev && getenv("AMH_VERIFY_MERGE") == nullptr && dst->hv.chg_ok;
@@ -2358,8 +2372,17 @@ struct ApplyItem {
   // change chunks that are already in device memory (merge: the re-derived chunks of the source batches): each entry is
   // one whole uncompressed change chunk; entries with the same `buf` form one apply_changes call.  They are gathered
   // into the staged arena by a device copy and never cross to the host as a batch's change bytes.
-  struct DevChunk { const u8* d; u32 len; u32 buf; };
+  struct DevChunk { const u8* d; u32 len; u32 buf; const BatchDev* sb; u32 chg; };   // sb / chg: the loaded batch and the change (global index) the chunk is: its hash and op / pred counts are there   // hash: the chunk's SHA-256 (= change hash) where the source batch keeps it, device memory
   std::vector<DevChunk> dev;
+};
+// a table filled in full by its owner: sized without the zero fill (and the page faults on one thread) of std::vector::resize
+template <class T> struct RawVec {
+  std::unique_ptr<T[]> p; size_t n = 0;
+  void resize(size_t k) { p.reset(k ? new T[k] : nullptr); n = k; }
+  T* data() const { return p.get(); }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T& operator[](size_t i) const { return p[i]; }
 };
 template <class T> struct PinSpan { T* p = nullptr; T& operator[](size_t i) const { return p[i]; } T* data() const { return p; } };
 struct HostChunk {
@@ -2372,6 +2395,8 @@ struct HostChunk {
   bool is_doc = false;         // a document chunk: replaced by the changes it holds before staging
   u32 buf = 0;                 // which of the item's buffers it came from (one buffer = one apply_changes call)
   const u8* dev = nullptr;     // the chunk lies in device memory (p is set once the staged arena is back on the host)
+  const BatchDev* dev_sb = nullptr;   // ... as change dev_chg of that loaded batch, which holds its hash and its op / pred counts
+  u32 dev_chg = 0;
   u32 staged = AMH_NULL32;     // index in U
 };
 static bool host_uleb(const u8* p, size_t& pos, size_t end, u64& out) {
@@ -2446,7 +2471,20 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   // ---- chunks of every pair: the new ones, then the document's queue -------------------------------
   std::vector<HostChunk> chunks;
   std::vector<u32> pc_base(P + 1, 0);
-  {
+  bool dev_only = dst->queue.empty();   // every item names device-resident chunks only (amh_merge_many of loaded batches): no stream to split
+  for (u32 p = 0; p < P && dev_only; p++) dev_only = items[p].bufs.empty();
+  if (dev_only) {
+    size_t total = 0;
+    for (u32 p = 0; p < P; p++) { pc_base[p] = (u32)total; total += items[p].dev.size(); }
+    chunks.resize(total);
+    host_parallel_for(P, [&](u32 p) {
+      HostChunk* to = chunks.data() + pc_base[p];
+      for (auto& dc : items[p].dev) {
+        HostChunk& hc = *to++;
+        hc.pair = p; hc.dev = dc.d; hc.dev_sb = dc.sb; hc.dev_chg = dc.chg; hc.len = dc.len; hc.buf = dc.buf;
+      }
+    });
+  } else {
     std::vector<std::vector<HostChunk>> per_pair(P);
     host_parallel_for(P, [&](u32 p) {
       std::vector<HostChunk>& out = per_pair[p];
@@ -2462,7 +2500,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       }
       for (auto& dc : items[p].dev) {
         HostChunk hc;
-        hc.pair = p; hc.dev = dc.d; hc.len = dc.len; hc.buf = bi + dc.buf;
+        hc.pair = p; hc.dev = dc.d; hc.dev_sb = dc.sb; hc.dev_chg = dc.chg; hc.len = dc.len; hc.buf = bi + dc.buf;
         out.push_back(std::move(hc));
       }
       if (qit != dst->queue.end())
@@ -2546,8 +2584,9 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   struct StageView { u8* p = nullptr; size_t n = 0; u8* data() const { return p; } size_t size() const { return n; } } h_arena;
   ap.s_desc.resize(P); ap.s_cnt.resize(P); ap.s_row_base.assign(P + 1, 0);
   std::vector<u32> staged_of;   // U index -> chunks index
-  std::vector<u64> seg_src, seg_dst;
-  std::vector<u32> seg_len;
+  RawVec<u64> seg_nops, seg_npred;   // where the op / pred counts of a device-resident chunk lie (0 = not known)
+  RawVec<u64> seg_src, seg_dst, seg_hash, seg_hdst;   // seg_hash / seg_hdst: where the hash of a device-resident chunk lies / goes in U.doc_hash
+  RawVec<u32> seg_len;
   size_t n_host_staged = 0;
   std::vector<u32> p_n(P + 1, 0);   // per pair: its staged chunks, then (prefix sums) the U index of its first one
   {
@@ -2578,7 +2617,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     p_n[P] = nu; p_dev[P] = ndev;
     n_host_staged = nu - ndev;
     staged_of.resize(nu); ap.c_pair.resize(nu); ap.c_rel.resize(nu); doc_off.resize(2 * (size_t)nu);
-    seg_src.resize(ndev); seg_len.resize(ndev); seg_dst.resize(ndev);
+    seg_src.resize(ndev); seg_len.resize(ndev); seg_dst.resize(ndev); seg_hash.resize(ndev); seg_hdst.resize(ndev); seg_nops.resize(ndev); seg_npred.resize(ndev);
     pt.mark("apply: stage layout");
     if ((size_t)off + 256 > ctx->stage_cap) {
       rt_sync(ctx->stream);   // nothing may still be copying out of the old area
@@ -2602,7 +2641,14 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
         const u64 next = (o + hc.len + 15) & ~(u64)15;
         if (hc.dev) {   // gathered on the device; the host's picture of the arena receives its head only
           hc.p = h_arena.data() + o;
-          seg_src[sd] = (u64)(uintptr_t)hc.dev; seg_len[sd] = (u32)hc.len; seg_dst[sd] = o; sd++;
+          seg_src[sd] = (u64)(uintptr_t)hc.dev; seg_len[sd] = (u32)hc.len; seg_dst[sd] = o;
+          seg_hdst[sd] = (u64)u * 32;
+          if (hc.dev_sb) {
+            seg_hash[sd] = (u64)(uintptr_t)(hc.dev_sb->c_hash + (size_t)hc.dev_chg * 32);
+            seg_nops[sd] = (u64)(uintptr_t)(hc.dev_sb->c_nops + hc.dev_chg);
+            seg_npred[sd] = hc.dev_sb->c_npred ? (u64)(uintptr_t)(hc.dev_sb->c_npred + hc.dev_chg) : 0;
+          } else { seg_hash[sd] = 0; seg_nops[sd] = 0; seg_npred[sd] = 0; }
+          sd++;
         } else {        // chunk bytes + the alignment gap behind them
           memcpy(h_arena.data() + o, hc.p, hc.len);
           memset(h_arena.data() + o + hc.len, 0, (size_t)(next - (o + hc.len)));
@@ -2696,7 +2742,23 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       return true;
     };
     mg0(MK_AP_PARSE, NCH);
-    launch(ctx, AK_SHA_DOC, U, NCH);
+    // chunk hashes (= change hashes).  When every chunk comes out of a loaded batch (amh_merge_many) the hashes were
+    // computed, and the checksums written, when those batches were loaded: they are copied, not taken again (1.3 GB of
+    // SHA-256 per headline step)
+    bool hashes_given = !seg_src.empty() && n_host_staged == 0 && seg_src.size() == NCH;
+    for (size_t k = 0; hashes_given && k < seg_hash.size(); k++) hashes_given = seg_hash[k] != 0;
+    if (hashes_given) {
+      const u32 ns = (u32)seg_hash.size();
+      u64* d_hs = balloc<u64>(hb, ns + 1, &ok); u64* d_hd = balloc<u64>(hb, ns + 1, &ok); u32* d_hn = balloc<u32>(hb, ns + 1, &ok);
+      if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+      std::vector<u32> len32(ns, 32);
+      if (!rt_h2d(d_hs, seg_hash.data(), ns * sizeof(u64), ctx->stream) || !rt_h2d(d_hd, seg_hdst.data(), ns * sizeof(u64), ctx->stream) ||
+          !rt_h2d(d_hn, len32.data(), ns * sizeof(u32), ctx->stream) || !rt_sync(ctx->stream))
+        return faild("H2D copy failed");
+      amh_copy_bytes64(d_hs, d_hn, d_hd, U.doc_hash, ns, (void*)ctx->stream);
+    } else {
+      launch(ctx, AK_SHA_DOC, U, NCH);
+    }
     u32 *d_hl = nullptr, *d_ho = nullptr;
     u8* d_heads = nullptr;
     u32 heads_total = 0;
@@ -2720,7 +2782,20 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       }
       amh_ap_head_copy(d_arena, d_off, d_hl, d_ho, d_heads, NCH, (void*)ctx->stream);
     }
-    mg0(MK_AP_COUNT, NCH);
+    // op and pred counts per chunk: known where the chunks come out of loaded batches that counted them (k_chg_layout)
+    bool counts_given = hashes_given;
+    for (size_t k = 0; counts_given && k < seg_nops.size(); k++) counts_given = seg_nops[k] != 0 && seg_npred[k] != 0;
+    if (counts_given) {
+      const u32 ns = (u32)seg_nops.size();
+      u64* d_a = balloc<u64>(hb, 3 * (size_t)ns + 3, &ok);
+      if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
+      if (!rt_h2d(d_a, seg_nops.data(), ns * sizeof(u64), ctx->stream) || !rt_h2d(d_a + ns, seg_npred.data(), ns * sizeof(u64), ctx->stream) ||
+          !rt_h2d(d_a + 2 * (size_t)ns, seg_hdst.data(), ns * sizeof(u64), ctx->stream) || !rt_sync(ctx->stream))
+        return faild("H2D copy failed");
+      amh_ap_counts_given(U, d_a, d_a + ns, d_a + 2 * (size_t)ns, ns, (void*)ctx->stream);
+    } else {
+      mg0(MK_AP_COUNT, NCH);
+    }
     u32 tot_rows = 0, tot_preds = 0;
     for (int attempt = 0;; attempt++) {
       if (!scan_inplace(hb, U.row_base, NCH, &tot_rows) || !scan_inplace(hb, U.succ_base, NCH, &tot_preds)) return faild("scan failed");
@@ -3231,9 +3306,11 @@ extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* con
       const HostView& hb = sb->hv;
       u32 ncb = hb.cnt[b].n_chg, cbb = hb.chg_base[b];
       auto bhash = [&](u32 j) { return hb.c_hash.data() + (size_t)(cbb + j) * 32; };
-      std::vector<u8> is_dep(ncb, 0), seen(ncb, 0);
+      static thread_local std::vector<u8> is_dep, seen;   // reused across the pairs a host thread serves: no allocation per (pair, source)
+      static thread_local std::vector<u32> stack, added, deps;
+      is_dep.assign(ncb, 0); seen.assign(ncb, 0);
+      stack.clear(); added.clear(); deps.clear();
       for (u32 j = 0; j < ncb; j++) for (u32 k = 0; k < hb.c_ndeps[cbb + j]; k++) is_dep[hb.dep_idx[hb.c_dep_base[cbb + j] + k]] = 1;
-      std::vector<u32> stack, added, deps;
       for (u32 j = 0; j < ncb; j++) if (!is_dep[j]) stack.push_back(j);
       std::sort(stack.begin(), stack.end(), [&](u32 x, u32 y) { return memcmp(bhash(x), bhash(y), 32) < 0; });
       while (!stack.empty()) {
@@ -3252,7 +3329,7 @@ extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* con
       // the added changes of one source = one apply_changes call; their re-derived chunks stay where they are, in the
       // source batch's device memory
       for (u32 j : added) {
-        items[p].dev.push_back({sb->B.out_arena + hb.c_out_off[cbb + j], hb.c_out_len[cbb + j], n_calls});
+        items[p].dev.push_back({sb->B.out_arena + hb.c_out_off[cbb + j], hb.c_out_len[cbb + j], n_calls, &sb->B, cbb + j});
         Hash32 h; memcpy(h.b, bhash(j), 32);
         known.emplace(h, 0);   // every added change applies (the source's history is causally closed)
       }

@@ -1292,6 +1292,17 @@ void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream) {
     if (i < n) name(*G, i);                                                    \
   }
 AMH_GLOBAL_SM(k_sm_lookup) AMH_GLOBAL_SM(k_sm_plan) AMH_GLOBAL_SM(k_sm_fill)
+__global__ void __launch_bounds__(AMH_BLOCK) g_ap_counts_given(BatchDev U, const u64* nops, const u64* npred, const u64* place, u32 n) {
+  const u32 k = blockIdx.x * AMH_BLOCK + threadIdx.x;
+  if (k >= n) return;
+  const u32 c = (u32)(place[k] / 32), rows = *(const u32*)(uintptr_t)nops[k], preds = *(const u32*)(uintptr_t)npred[k];
+  const bool ok = U.status[c] == 0;
+  U.cnt[c].n_rows = ok ? rows : 0; U.cnt[c].n_succ = ok ? preds : 0;
+  U.row_base[c] = ok ? rows : 0; U.succ_base[c] = ok ? preds : 0;
+}
+void amh_ap_counts_given(const BatchDev& U, const u64* nops, const u64* npred, const u64* place, u32 n, void* stream) {
+  if (n) hipLaunchKernelGGL(g_ap_counts_given, dim3((n + AMH_BLOCK - 1) / AMH_BLOCK), dim3(AMH_BLOCK), 0, (hipStream_t)stream, U, nops, npred, place, n);
+}
 __global__ void __launch_bounds__(AMH_BLOCK) g_sm_doc_sizes(BatchDev B, const u32* doc, u32* out, u32 n) {
   const u32 r = blockIdx.x * AMH_BLOCK + threadIdx.x;
   if (r >= n) return;

@@ -1683,7 +1683,9 @@ AMH_DEV void k_chg_layout(const BatchDev& B, u32 c) {
   B.c_out_len[c] = 0;
   B.c_body_len[c] = 0;
   B.c_cols_off[c] = 0;
+  if (B.c_npred) B.c_npred[c] = 0;
   if (B.status[d]) return;
+  if (B.c_npred && B.c_nops[c]) B.c_npred[c] = B.j_pred_base[B.c_op_base[c] + B.c_nops[c]] - B.j_pred_base[B.c_op_base[c]];
   u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
   if (cl[0] == 0) cl[1] = 0;     // ObjIdRange::encode -> None (obj_id.rs:79-81)
   if (cl[10] == 0) cl[11] = 0;   // pred actor/ctr only when there are entries (change_op_columns.rs:304-315)

@@ -59,6 +59,9 @@ u64 amh_encode_tmp_bytes(const BatchDev& B);
 // end of its last one; the copy puts them at off[d] (exclusive sums of len) of dst
 void amh_actor_pack_len(const BatchDev& B, u32* len, void* stream);
 void amh_actor_pack_copy(const BatchDev& B, const u32* len, const u32* off, u8* dst, void* stream);
+// op / pred counts of chunks whose source batches know them: chunk u = place[k] / 32 of U gets *nops[k] rows and *npred[k]
+// pred entries (U.cnt, and U.row_base / U.succ_base as k_ap_count leaves them for the scans)
+void amh_ap_counts_given(const BatchDev& U, const u64* nops, const u64* npred, const u64* place, u32 n, void* stream);
 void amh_ap_head_len(const ChgHdr* hdr, const i32* status, u32* len16, u32 n, void* stream);
 void amh_ap_head_copy(const u8* arena, const u64* doc_off, const u32* len16, const u32* off, u8* dst, u32 n, void* stream);
 

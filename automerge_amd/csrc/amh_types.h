@@ -126,6 +126,7 @@ struct BatchDev {
   u32* dep_idx;                  // [tot_deps] document-local change index
   // derived per change
   u32* c_nops;
+  u32* c_npred;                  // [tot_chg] pred entries of the change's ops (k_chg_layout; nullptr where the batch's changes were not re-encoded)
   u64* c_start_op;
   u32* c_op_base;                // [tot_chg + 1] slot base in ops_sorted
   u32* c_next_same_actor;

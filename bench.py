@@ -178,6 +178,8 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
     GPU's HBM while the step still covers all `--docs` documents."""
     import ctypes as C
     R = args.replicas
+    if args.sequential_merges or R < 3:
+        args.source_batches = 0   # pairwise merges take one batch per replica
     threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), 32))
     n_slices = max(1, (args.docs + args.slice - 1) // args.slice)
     bounds = [(k * args.docs // n_slices, (k + 1) * args.docs // n_slices) for k in range(n_slices)]
@@ -187,7 +189,10 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
         blob, offs = eng.gen_text_docs(0xB070 + rank * args.docs + lo, hi - lo, R, 1000, 5000, 500, threads)
         reps = [[blob[offs[i * R + r]:offs[i * R + r + 1]] for i in range(hi - lo)] for r in range(R)]
         ts = time.perf_counter()
-        staged.append([eng.stage(reps[r]) for r in range(R)])
+        if args.source_batches == 1:   # replica 0 of every document, then the R-1 source replicas of all of them as one batch (replica-major)
+            staged.append([eng.stage(reps[0]), eng.stage([d for r in range(1, R) for d in reps[r]])])
+        else:
+            staged.append([eng.stage(reps[r]) for r in range(R)])
         t_stage += time.perf_counter() - ts
         enc_bytes += len(blob)
         if k == 0:
@@ -204,12 +209,14 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
             ids = list(range(hi - lo))
             ids_np = np.arange(hi - lo, dtype=np.uint32)
             src_np = np.tile(ids_np, (R - 1, 1))
+            if args.source_batches == 1:   # source s of document p = document s * n + p of the one wide batch
+                src_np = (src_np + (np.arange(R - 1, dtype=np.uint32) * np.uint32(hi - lo))[:, None]).astype(np.uint32)
             batches = []
             for r, s in enumerate(staged[k]):
                 batches.append(eng.load_staged(s))   # every replica is loaded and verified in full
                 if keep_stats:   # per-batch counts of the source loads for the byte model (before the merge replaces batch 0)
                     stats.append([]) if r == 0 else None
-                    stats[-1].append((batches[-1].stats(), column_bytes(eng, batches[-1], hi - lo)))
+                    stats[-1].append((batches[-1].stats(), column_bytes(eng, batches[-1], batches[-1].n)))
                 if r and not args.sequential_merges:
                     batches[-1].release_ops()       # a merge source is read for its history only: its op rows go back to the pool
             if args.sequential_merges:
@@ -217,7 +224,7 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
                     rc = batches[0].merge(batches[r], [(i, i) for i in ids])
                     assert rc == 0, rc
             else:   # the same result (history order included) with one pass over the rows
-                rc = batches[0].merge_many(batches[1:], ids_np, src_np)
+                rc = batches[0].merge_many(batches[1:] if args.source_batches != 1 else [batches[1]] * (R - 1), ids_np, src_np)
                 assert rc == 0, rc
             # ... + materialize text: ReadDoc::text of every merged document, left in HBM like the inputs
             # (amh_text_batch_device); the copy to the host is timed once, outside the steps (config.text_to_host_ms)
@@ -330,7 +337,10 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
                           "text_ms_per_step": round(text_ms, 2), "text_bytes_per_step": text_total[0], "text_to_host_ms": round(text_host_ms[0], 1),
                           "docs_per_gpu": args.docs, "replicas": R, "ops_per_merged_doc": ops / args.docs, "encoded_bytes_per_gpu": enc_bytes,
                           "slices_per_step": n_slices, "docs_per_slice": args.slice, "sharding": f"documents x{world} (replicas of a document co-located)",
-                          "merge_call": "sequential amh_merge_batch" if args.sequential_merges else "amh_merge_many", "gen_s": round(t_gen, 2),
+                          "merge_call": "sequential amh_merge_batch" if args.sequential_merges else "amh_merge_many",
+                          "source_loads": (f"the {R - 1} source replicas of all documents as ONE batch of {(R - 1) * args.slice} documents (one amh_load_staged call), replica 0 as another"
+                                           if args.source_batches == 1 else f"one batch per replica ({R} amh_load_staged calls)"),
+                          "gen_s": round(t_gen, 2),
                           "stage_s": round(t_stage, 3),   # host bytes -> HBM through the pinned double buffer (amh_stage_batch), outside the timed region
                           "pcie_inclusive_ops_per_s": ops_all / (elapsed_max / args.steps + t_stage),
                           "note": "ops counted once per merged document; every replica is loaded in full (every change re-derived from the ops, SHA-256 hashed, heads checked); the merged document keeps those verified change chunks, as the reference's merge keeps stored changes (AMH_VERIFY_MERGE=1 re-derives them from the merged rows as well)"},
@@ -730,6 +740,8 @@ def main():
     ap.add_argument("--ops", type=int, default=10000000, help="bigdoc workload: ops of the document")
     ap.add_argument("--replicas", type=int, default=8)
     ap.add_argument("--sequential-merges", action="store_true", help="merge workload: R-1 amh_merge_batch calls instead of one amh_merge_many")
+    ap.add_argument("--source-batches", type=int, default=1, help="merge workload: 1 = the R-1 source replicas of all documents are loaded as ONE "
+                    "batch of (R-1) x docs documents (default: one load call, one set of dependency levels to hash); 0 = one batch per replica")
     args = ap.parse_args()
     if args.docs is None:
         args.docs = {"load": 100000, "merge": 10000, "sync": 125000, "apply": 100000, "bigdoc": 1, "trace": 1}[args.workload]

@@ -62,6 +62,14 @@ void amh_sm_doc_sizes(const BatchDev& B, const u32* doc, u32* out, u32 n, void*)
     out[2 * r + 1] = ok ? B.desc[d].n_actors : 0;
   }
 }
+void amh_ap_counts_given(const BatchDev& U, const u64* nops, const u64* npred, const u64* place, u32 n, void*) {
+  for (u32 k = 0; k < n; k++) {
+    const u32 c = (u32)(place[k] / 32), rows = *(const u32*)(uintptr_t)nops[k], preds = *(const u32*)(uintptr_t)npred[k];
+    const bool ok = U.status[c] == 0;
+    U.cnt[c].n_rows = ok ? rows : 0; U.cnt[c].n_succ = ok ? preds : 0;
+    U.row_base[c] = ok ? rows : 0; U.succ_base[c] = ok ? preds : 0;
+  }
+}
 void amh_launch_sm(int k, const SyncDev* G, u32 n, void*) {
   for (u32 i = 0; i < n; i++) {
     if (k == SK_LOOKUP) k_sm_lookup(*G, i);

@@ -184,7 +184,16 @@ def check_merge_many_numpy(engine, reps):
         for b in others:
             b.close()
         bd.close()
-    assert out[0] == out[1]
+    # all source replicas of all documents as ONE batch, named once per source with shifted indices
+    bd = engine.load_batch(reps[0])
+    wide = engine.load_batch([d for r in range(1, n_rep) for d in reps[r]])
+    wide.release_ops()
+    a = np.arange(n_docs, dtype=np.uint32)
+    src = (np.tile(a, (n_rep - 1, 1)) + (np.arange(n_rep - 1, dtype=np.uint32) * np.uint32(n_docs))[:, None]).astype(np.uint32)
+    assert bd.merge_many([wide] * (n_rep - 1), a, src) == 0
+    out.append(bd.save_all(deflate=False))
+    wide.close(); bd.close()
+    assert out[0] == out[1] == out[2]
     ref = o.Doc.load(bytes(reps[0][0]))
     for r in range(1, n_rep):
         ref.merge(o.Doc.load(bytes(reps[r][0])))
