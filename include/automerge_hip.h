@@ -199,7 +199,9 @@ int amh_merge_batch(amh_ctx*, amh_batch* dst, const amh_batch* src, const uint32
  * and the call returns AMH_ERR_DOC_FAILED (tests/merge_cases.py check_merge_many_duplicate_seq, against the oracle).
  * History: when every source is a loaded batch, the merged document ADOPTS the sources' change chunks and hashes (each
  * was re-derived from its ops and hashed when its source was loaded), as the reference's merge keeps the stored
- * changes; they are not derived again from the merged rows unless AMH_VERIFY_MERGE=1 is set (the test suites run both). */
+ * changes; they are not derived again from the merged rows unless AMH_VERIFY_MERGE=1 is set (the test suites run both).
+ * The same batch may be named as several sources (srcs[s] equal, src_idx shifted): all source replicas of all
+ * documents can be loaded as one batch. */
 int amh_merge_many(amh_ctx*, amh_batch* dst, const amh_batch* const* srcs, size_t n_srcs, const uint32_t* dst_idx,
                    const uint32_t* src_idx, size_t n_pairs);
 /* == Automerge::apply_changes (automerge.rs:785-858; AMapplyChanges, automerge-c/src/doc.rs:84) on one document:

@@ -198,3 +198,24 @@ def check_merge_many_numpy(engine, reps):
     for r in range(1, n_rep):
         ref.merge(o.Doc.load(bytes(reps[r][0])))
     assert out[1][0] == ref.save(deflate=False)
+
+
+def check_merge_of_a_merged_batch(engine, reps):
+    """a source that is itself the result of a merge (it adopted its changes: no per-change counts of its own) merged into
+    a third replica: the same as the oracle's ref0.merge(ref1.merge(ref2))"""
+    n_docs = len(reps[0])
+    ids = list(range(n_docs))
+    mid = engine.load_batch(reps[1])
+    last = engine.load_batch(reps[2])
+    assert mid.merge_many([last], ids, [ids]) == 0
+    dst = engine.load_batch(reps[0])
+    assert dst.merge_many([mid], ids, [ids]) == 0
+    saved = dst.save_all(deflate=False)
+    for i in range(n_docs):
+        r1 = o.Doc.load(bytes(reps[1][i])); r1.merge(o.Doc.load(bytes(reps[2][i])))
+        r0 = o.Doc.load(bytes(reps[0][i])); r0.merge(r1)
+        assert dst.get_heads(i) == r0.get_heads(), i
+        assert [c["hash"] for c in dst.get_changes(i)] == [c["hash"] for c in r0.changes()], i
+        assert saved[i] == r0.save(deflate=False), i
+    for b in (mid, last, dst):
+        b.close()

@@ -564,4 +564,7 @@ def test_merge_many_with_numpy_indices(engine):
     from merge_cases import check_merge_many_numpy
     n_docs, n_rep = 3, 4
     blob, offs = engine.gen_text_docs(0xE172, n_docs, n_rep, 40, 160, 30, 2)
-    check_merge_many_numpy(engine, [[bytes(blob[offs[i * n_rep + r]:offs[i * n_rep + r + 1]]) for i in range(n_docs)] for r in range(n_rep)])
+    reps = [[bytes(blob[offs[i * n_rep + r]:offs[i * n_rep + r + 1]]) for i in range(n_docs)] for r in range(n_rep)]
+    check_merge_many_numpy(engine, reps)
+    from merge_cases import check_merge_of_a_merged_batch
+    check_merge_of_a_merged_batch(engine, reps)
