@@ -3,8 +3,9 @@
 // (rust/automerge/tests/test.rs:1405-1415) restated for the load and apply paths.  Built with
 // -fsanitize=address,undefined by tests/emu/Makefile (target fuzz_apply) and run by tests/test_emu_fuzz.py.
 // Documents and changes are generated, mutated (bit flips, byte writes, truncations, splices) and pushed through
-// amh_load_batch / amh_apply_batch (both modes) / amh_save_batch / amh_hydrate_json; the run passes when the
-// sanitizers stay silent and every call returns.
+// amh_load_batch / amh_apply_batch (both modes) / amh_save_batch / amh_hydrate_json / amh_text_batch, and whatever state
+// results through amh_generate_sync_messages and amh_save_after_batch with States made of known hashes, random hashes,
+// random flags and damaged Bloom filters; the run passes when the sanitizers stay silent and every call returns.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -106,6 +107,53 @@ int main(int argc, char** argv) {
     for (uint32_t i = 0; i < ND; i++) { amh_bytes_out j; if (amh_hydrate_json(b, i, &j) == 0) amh_bytes_free(&j); }
     amh_bytes_out sy;
     if (amh_sync_summaries(ctx, b, &sy) == 0) amh_bytes_free(&sy);
+    // 4. the text of every document, and the sender side of the sync protocol over States put together from the hashes the
+    //    batch knows, random ones, random flags and (sometimes damaged) Bloom filters: calls may fail as calls on a malformed
+    //    filter (INVALID_ARG), nothing may read or write out of bounds
+    { amh_bytes_out tx; uint64_t* to = nullptr; if (amh_text_batch(ctx, b, &tx, &to) == 0) { amh_bytes_free(&tx); amh_u64_free(to); } }
+    {
+      std::vector<Bytes> pools(ND), blooms(ND);
+      std::vector<amh_sync_state> st(ND);
+      std::vector<amh_sync_have> hv(ND);
+      for (uint32_t i = 0; i < ND; i++) {
+        const uint8_t* hs = nullptr; size_t nh = 0;
+        Bytes& pool = pools[i];
+        if (amh_heads(b, i, &hs, &nh) == 0) pool.insert(pool.end(), hs, hs + 32 * nh);
+        size_t nc = 0;
+        if (amh_changes(b, i, nullptr, &nc) == 0 && nc) {
+          std::vector<amh_change_view> v(nc); size_t cap = nc;
+          if (amh_changes(b, i, v.data(), &cap) == 0) for (size_t k = 0; k < nc; k++) if (rnd() % 2) pool.insert(pool.end(), v[k].hash, v[k].hash + 32);
+        }
+        for (int k = 0; k < 3; k++) { for (int j = 0; j < 32; j++) pool.push_back((uint8_t)rnd()); }
+        const size_t np = pool.size() / 32;
+        auto pick = [&](const uint8_t*& ptr, size_t& n) { size_t a = rnd() % np, c = rnd() % 4; if (a + c > np) c = np - a; ptr = pool.data() + 32 * a; n = c; };
+        memset(&st[i], 0, sizeof st[i]);
+        st[i].doc = i; st[i].flags = (uint32_t)(rnd() & 15);
+        pick(st[i].shared_heads32, st[i].n_shared_heads); pick(st[i].last_sent_heads32, st[i].n_last_sent_heads);
+        pick(st[i].their_heads32, st[i].n_their_heads); pick(st[i].their_need32, st[i].n_their_need);
+        pick(st[i].sent_hashes32, st[i].n_sent_hashes);
+        Bytes& bl = blooms[i];
+        const uint32_t ne = (uint32_t)(rnd() % 5);
+        if (ne) { bl.push_back((uint8_t)ne); bl.push_back(10); bl.push_back((uint8_t)(rnd() % 9)); for (uint32_t k = 0; k < (ne * 10 + 7) / 8; k++) bl.push_back((uint8_t)rnd()); }
+        if (rnd() % 5 == 0) mutate(bl);
+        pick(hv[i].last_sync32, hv[i].n_last_sync);
+        hv[i].bloom = bl.data(); hv[i].bloom_len = bl.size();
+        st[i].their_have = &hv[i]; st[i].n_their_have = rnd() % 2;
+      }
+      std::vector<uint32_t> kinds(ND);
+      amh_bytes_out msgs, sent; uint64_t *mo = nullptr, *so = nullptr;
+      int rc2 = amh_generate_sync_messages(ctx, b, st.data(), ND, kinds.data(), &msgs, &mo, &sent, &so);
+      if (rc2 == AMH_SUCCESS || rc2 == AMH_ERR_DOC_FAILED) {
+        for (uint32_t i = 0; i < ND; i++) if (mo[i + 1] < mo[i] || mo[i + 1] > msgs.len) { fprintf(stderr, "sync message offsets out of order\n"); return 3; }
+        amh_bytes_free(&msgs); amh_bytes_free(&sent); amh_u64_free(mo); amh_u64_free(so);
+      } else if (rc2 != AMH_ERR_INVALID_ARG) { fprintf(stderr, "sync messages failed as a call: %d %s\n", rc2, amh_last_error(ctx)); return 3; }
+      std::vector<uint32_t> di(ND); std::vector<const uint8_t*> hp(ND); std::vector<size_t> hn(ND);
+      for (uint32_t i = 0; i < ND; i++) { di[i] = i; hp[i] = st[i].their_heads32; hn[i] = st[i].n_their_heads; }
+      amh_bytes_out sa; uint64_t* sao = nullptr;
+      int rc3 = amh_save_after_batch(ctx, b, di.data(), hp.data(), hn.data(), ND, &sa, &sao);
+      if (rc3 == AMH_SUCCESS || rc3 == AMH_ERR_DOC_FAILED) { amh_bytes_free(&sa); amh_u64_free(sao); }
+      else { fprintf(stderr, "save_after_batch failed as a call: %d %s\n", rc3, amh_last_error(ctx)); return 3; }
+    }
     amh_batch_free(b);
   }
   printf("fuzz ok: %d iterations, documents ok/bad %ld/%ld, apply outcomes ok/refused %ld/%ld\n", iters, ok_docs, bad_docs, applied, refused);
