@@ -196,7 +196,8 @@ AMH_DEV void k_ap_map(const MergeDev& G, u32 r) {
   G.A.gap[r] = AMH_NULL32; G.A.anchor[r] = AMH_NULL32; G.A.parent[r] = AMH_NULL32;
   G.A.o_next[r] = AMH_NULL32; G.A.o_head_upd[r] = AMH_NULL32; G.A.o_head_ins[r] = AMH_NULL32;
   G.S.r_succ_cnt[r] = 0;
-  if (!ap_row_live(G, r, c, p)) { U.r_doc[r] = G.A.c_pair[G.A.u_chg[r]]; return; }
+  if (!ap_row_live(G, r, c, p)) { U.r_doc[r] = G.A.c_pair[G.A.u_chg[r]]; G.new_idx[r] = 0; return; }
+  G.new_idx[r] = U.r_action[r] != 3 ? 1 : 0;   // k_ap_new_flag's verdict, while the row is at hand (one pass less over U)
   const u32* amap = G.A.amap + G.A.amap_base[c];
   u32 rel = G.A.c_rel[c];
   U.r_id_actor[r] = amap[0];

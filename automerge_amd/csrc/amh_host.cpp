@@ -1951,9 +1951,8 @@ static int mg_execute(amh_ctx* ctx, amh_batch* dst, const BatchDev& SB, MgPlan& 
     A.p_tgt = balloc<u32>(mb, (size_t)U.tot_succ + 2, &ok);
     if (!ok) { set_error(ctx, std::string(who) + ": device out of memory"); return AMH_ERR_OOM; }
     rt_memset(A.p_tgt, 0xFF, ((size_t)U.tot_succ + 2) * 4, ctx->stream);
-    mg(MK_AP_MAP, U.tot_rows);
+    mg(MK_AP_MAP, U.tot_rows);   // also flags the new rows (k_ap_new_flag's rule) into G.new_idx
     mg(MK_AP_CHG_META, ap->n_chunks);
-    mg(MK_AP_NEW_FLAG, U.tot_rows);
   } else
   mg(MK_NEW_FLAG, SB.tot_rows);
   u32 tot_new = 0;
