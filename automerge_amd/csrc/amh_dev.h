@@ -19,6 +19,7 @@ static inline u32 amh_atomic_min(u32* p, u32 v) { u32 o = *p; if (v < o) *p = v;
 static inline u32 amh_atomic_max(u32* p, u32 v) { u32 o = *p; if (v > o) *p = v; return o; }
 static inline u32 amh_atomic_cas(u32* p, u32 cmp, u32 val) { u32 o = *p; if (o == cmp) *p = val; return o; }
 static inline u32 amh_atomic_exch(u32* p, u32 val) { u32 o = *p; *p = val; return o; }
+static inline void amh_atomic_or(u32* p, u32 v) { *p |= v; }
 static inline void amh_atomic_inc_grouped(u32* base, u32 idx) { base[idx]++; }
 static inline u64 amh_atomic_cas64(u64* p, u64 cmp, u64 val) { u64 o = *p; if (o == cmp) *p = val; return o; }
 static inline i32 amh_atomic_cas_i32(i32* p, i32 cmp, i32 val) { i32 o = *p; if (o == cmp) *p = val; return o; }
@@ -36,6 +37,7 @@ AMH_DEV u32 amh_atomic_min(u32* p, u32 v) { return atomicMin(p, v); }
 AMH_DEV u32 amh_atomic_max(u32* p, u32 v) { return atomicMax(p, v); }
 AMH_DEV u32 amh_atomic_cas(u32* p, u32 cmp, u32 val) { return atomicCAS(p, cmp, val); }
 AMH_DEV u32 amh_atomic_exch(u32* p, u32 val) { return atomicExch(p, val); }
+AMH_DEV void amh_atomic_or(u32* p, u32 v) { atomicOr(p, v); }
 // base[idx] += 1 where many lanes of a wave name the same few words (ops of one document counting into its changes):
 // the lanes that share an index send one atomic with their number instead of one each
 AMH_DEV void amh_atomic_inc_grouped(u32* base, u32 idx) {

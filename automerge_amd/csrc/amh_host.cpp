@@ -3557,7 +3557,7 @@ extern "C" int amh_sync_summaries_all(amh_ctx* ctx, const amh_batch* bc, amh_byt
 #endif
 }
 // a sync message kernel, timed like the others when the context is profiling
-static const char* const SK_KERNEL_NAMES[SK_NUM] = {"sm_lookup", "sm_plan", "sm_fill", "sm_copy"};
+static const char* const SK_KERNEL_NAMES[SK_NUM] = {"sm_lookup", "sm_plan", "sm_fill", "sm_copy", "sm_bloom", "sm_jobs"};
 static void launch_sm_timed(amh_ctx* ctx, int k, const SyncDev* G, u32 n) {
   if (n == 0) return;
   if (ctx->profiling) {
@@ -3684,7 +3684,7 @@ static int sm_to_device(amh_ctx* ctx, amh_batch* b, const amh_sync_state* states
     r_flag_base[r] = n_flag; n_flag += nc;
     r_clock_base[r] = n_clock; n_clock += na;
     r_word_base[r] = n_word;
-    n_word += (u64)nc * 2 + (L[SM_QHASH] - L[SM_QDEPS]) + (L[SM_THEIR_NEED] - L[SM_THEIR_HEADS]) + (L[SM_SENT] - L[SM_THEIR_NEED]);
+    n_word += (u64)nc * 3 + (L[SM_QHASH] - L[SM_QDEPS]) + (L[SM_THEIR_NEED] - L[SM_THEIR_HEADS]) + 2 * (u64)(L[SM_SENT] - L[SM_THEIR_NEED]);
   }
   r_list[(size_t)R * SM_LISTS] = (u32)pool_rec.size();
   r_have[R] = (u32)h_entries.size();
@@ -3709,13 +3709,13 @@ static int sm_to_device(amh_ctx* ctx, amh_batch* b, const amh_sync_state* states
   G.c_flag = balloc<u8>(b, n_flag + 16, &ok);
   G.clock = balloc<u64>(b, n_clock + 1, &ok);
   G.words = balloc<u32>(b, n_word + 1, &ok);
-  G.r_kind = balloc<u32>(b, (size_t)R * 5 + 8, &ok);
+  G.r_kind = balloc<u32>(b, (size_t)R * 6 + 8, &ok);
   b->sm_off.p = ctx->pool.alloc(((size_t)R + 2) * 4, &b->sm_off.cap);
   b->sm_job.p = ctx->pool.alloc(((size_t)R + 2) * 4, &b->sm_job.cap);
   if (!ok || !b->sm_off.p || !b->sm_job.p) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
   G.msg_off = (u32*)b->sm_off.p;
   G.job_base = (u32*)b->sm_job.p;
-  G.r_nheads = G.r_kind + R; G.r_nneed = G.r_kind + 2 * (size_t)R; G.r_nsend = G.r_kind + 3 * (size_t)R; G.r_bloom_n = G.r_kind + 4 * (size_t)R;
+  G.r_nheads = G.r_kind + R; G.r_nneed = G.r_kind + 2 * (size_t)R; G.r_nsend = G.r_kind + 3 * (size_t)R; G.r_bloom_n = G.r_kind + 4 * (size_t)R; G.r_bits_at = G.r_kind + 5 * (size_t)R;
   G.r_doc = (const u32*)(d_blob + o_doc); G.r_flags = (const u32*)(d_blob + o_flags); G.pool = d_blob + o_pool;
   G.pool_rec = (const u32*)(d_blob + o_prec); G.r_list = (const u32*)(d_blob + o_list); G.r_have = (const u32*)(d_blob + o_have);
   G.h_ls = (const u32*)(d_blob + o_ls); G.h_entries = (const u32*)(d_blob + o_ent); G.h_probes = (const u32*)(d_blob + o_pr);
@@ -3740,7 +3740,11 @@ static int sm_to_device(amh_ctx* ctx, amh_batch* b, const amh_sync_state* states
   G.job_len = balloc<u32>(b, (size_t)jobs + 1, &ok);
   if (!ok) { set_error(ctx, "device out of memory"); return AMH_ERR_OOM; }
   if (!rt_h2d(dG, &G, sizeof G, ctx->stream)) { set_error(ctx, "H2D copy failed"); return AMH_ERR_DEVICE; }
+  if (n_flag >= 0xFFFFFFFFull) { set_error(ctx, "amh_generate_sync_messages: too many (record, change) pairs in one call"); return AMH_ERR_BATCH_TOO_LARGE; }
+  rt_memset(G.msg_out, 0, (size_t)total + 64, ctx->stream);   // the Bloom filters' bits are ORed in
   launch_sm_timed(ctx, SK_FILL, dG, R);
+  if (!raw) launch_sm_timed(ctx, SK_BLOOM, dG, (u32)n_flag);
+  launch_sm_timed(ctx, SK_JOBS, dG, jobs);
   if (jobs) {
     amh_ctx::Pending p;
     p.k = AK_NUM + MK_NUM + SK_COPY;

@@ -33,7 +33,7 @@ enum MgKernel {
 };
 void amh_launch_mg(int k, const MergeDev* G, u32 n, void* stream);
 // sync message kernels (amh_syncmsg.inl): G is the SyncDev in device memory (host memory in the emulation)
-enum SmKernel { SK_LOOKUP = 0, SK_PLAN, SK_FILL, SK_COPY, SK_NUM };   // SK_COPY: the change chunks into the messages (amh_copy_bytes64), timed under this id
+enum SmKernel { SK_LOOKUP = 0, SK_PLAN, SK_FILL, SK_COPY, SK_BLOOM, SK_JOBS, SK_NUM };   // SK_COPY: the change chunks into the messages (amh_copy_bytes64), timed under this id
 void amh_launch_sm(int k, const SyncDev* G, u32 n, void* stream);
 // out[2 r] = changes, out[2 r + 1] = actors of the document of record r (0, 0 for a failed document); doc[] and out[] in device memory
 void amh_sm_doc_sizes(const BatchDev& B, const u32* doc, u32* out, u32 n, void* stream);

@@ -205,7 +205,10 @@ struct Sc1Pred { u32 pa; u64 delta; };
 template <int MODE>
 __global__ void __launch_bounds__(64 * SD_WAVES) g_encode_one(BatchDev B, u32 gmask, u32 parts) {
   const u32 wave = sd_uniform(threadIdx.x >> 6);
-  const u32 c = (blockIdx.x / parts) * SD_WAVES + wave;
+  // XCD x takes the x-th eighth of the changes (the grid is a multiple of 8): the changes of one document gather the same
+  // rows — each touches most sectors of every field it reads — so they sit behind ONE L2 instead of three
+  const u32 blk = sd_uniform(amh_xcd_block());
+  const u32 c = (blk / parts) * SD_WAVES + wave;
   if (c >= B.tot_chg) return;
   const u32 lane = threadIdx.x & 63;
   u32* cl = B.c_col_len + (u64)c * AMH_NCOLS;
@@ -240,7 +243,7 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_encode_one(BatchDev B, u32 gm
     cl[k] = len;
     if (len > o.cap) atomicOr(&B.c_wide[c], 1u << k);
   };
-  for (u32 G = blockIdx.x % parts; G < SC_GROUPS; G += parts) {
+  for (u32 G = blk % parts; G < SC_GROUPS; G += parts) {
     if (!((gmask >> G) & 1)) continue;   // (development: AMH_ENC_GMASK times the column groups one by one)
     if (MODE == 1) {   // groups without a flagged column
       const u32 gm = G == 0 ? 0x2003u : G == 1 ? 0x001Cu : G == 2 ? 0x1260u : G == 3 ? 0x0180u : 0x0C00u;

@@ -13,7 +13,9 @@
 //                                    (sync.rs:276-303: the dependents map only holds changes since last_sync)
 //   k_sm_lookup  thread per pool hash    where the hash sits in its document's history
 //   k_sm_plan    thread per record       need, have, changes to send, None / reset decision, message size
-//   k_sm_fill    thread per record       the message but for its change chunks, which become copy jobs
+//   k_sm_fill    thread per record       type, heads, need, the Have's last_sync and Bloom header, change count
+//   k_sm_bloom   thread per (record, change)  the Bloom filter's bits (atomic OR into the zeroed message buffer)
+//   k_sm_jobs    thread per change sent  its length prefix, its copy job (the chunk stays in HBM), its hash for sent_hashes
 #pragma once
 #include "amh_kernels.inl"
 
@@ -41,7 +43,7 @@ struct SmRec {
   const u32* L;      // the record's row of r_list
   u8* cf;            // [nc] SMC_* bits
   u64* clock;        // [na]
-  u32 *heads, *need, *send;
+  u32 *heads, *need, *send, *spos;   // spos[k]: where the k-th change sent starts (its length prefix) inside the message
 };
 AMH_DEV SmRec sm_rec(const SyncDev& G, u32 r) {
   const BatchDev& B = G.B;
@@ -57,6 +59,7 @@ AMH_DEV SmRec sm_rec(const SyncDev& G, u32 r) {
   R.heads = G.words + G.r_word_base[r];
   R.need = R.heads + R.nc;
   R.send = R.need + (R.L[SM_QDEPS + 1] - R.L[SM_QDEPS]) + (R.L[SM_THEIR_HEADS + 1] - R.L[SM_THEIR_HEADS]);
+  R.spos = R.send + (R.L[SM_THEIR_NEED + 1] - R.L[SM_THEIR_NEED]) + R.nc;
   return R;
 }
 AMH_DEV const u8* sm_chg_hash(const SyncDev& G, const SmRec& R, u32 c) { return G.B.c_hash + (u64)(R.cb + c) * 32; }
@@ -104,7 +107,7 @@ AMH_DEV void k_sm_plan(const SyncDev& G, u32 r) {
     sm_clock(G, R, R.L[SM_LAST_SYNC], R.L[SM_LAST_SYNC + 1], SMC_ANC_SYNC);
     u32 ns = 0;
     u64 len = 0;
-    for (u32 c = 0; c < R.nc; c++) if (sm_since(G, R, c)) { R.send[ns++] = c; len += B.c_out_len[R.cb + c]; }
+    for (u32 c = 0; c < R.nc; c++) if (sm_since(G, R, c)) { R.spos[ns] = (u32)len; R.send[ns++] = c; len += B.c_out_len[R.cb + c]; }
     G.r_kind[r] = SMK_MESSAGE;
     G.r_nsend[r] = ns;
     G.job_base[r] = ns;
@@ -216,29 +219,16 @@ AMH_DEV void k_sm_plan(const SyncDev& G, u32 r) {
   G.r_nsend[r] = ns;
   G.job_base[r] = ns;
   u64 len = 1 + sm_hashes_len(nh) + sm_hashes_len(nn) + have_len + uleb_size(ns);
-  for (u32 k = 0; k < ns; k++) { const u32 cl = B.c_out_len[R.cb + R.send[k]]; len += uleb_size(cl) + cl; }
+  for (u32 k = 0; k < ns; k++) { const u32 cl = B.c_out_len[R.cb + R.send[k]]; R.spos[k] = len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)len; len += uleb_size(cl) + cl; }
   G.msg_off[r] = len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)len;
 }
 
 AMH_DEV void k_sm_fill(const SyncDev& G, u32 r) {
-  const BatchDev& B = G.B;
   const u32 kind = G.r_kind[r];
-  if (kind != SMK_MESSAGE && kind != SMK_RESET) return;
+  G.r_bits_at[r] = 0;
+  if (G.raw || (kind != SMK_MESSAGE && kind != SMK_RESET)) return;
   const SmRec R = sm_rec(G, r);
-  if (G.raw) {
-    u32 at = 0;
-    for (u32 k = 0, jb = G.job_base[r]; k < G.r_nsend[r]; k++) {
-      const u32 gc = R.cb + R.send[k], cl = B.c_out_len[gc];
-      G.job_src[jb + k] = (u64)(uintptr_t)(B.out_arena + B.c_out_off[gc]);
-      G.job_len[jb + k] = cl;
-      G.job_dst[jb + k] = (u64)G.msg_off[r] + at;
-      at += cl;
-      const u8* h = B.c_hash + (u64)gc * 32;
-      for (int b = 0; b < 32; b++) G.sent_out[(u64)(jb + k) * 32 + b] = h[b];
-    }
-    return;
-  }
-  u8* o = G.msg_out + G.msg_off[r];
+  u8* o = G.msg_out + G.msg_off[r];   // the buffer was zeroed: the Bloom filter's bits are ORed into it by k_sm_bloom
   u32 pos = 0;
   o[pos++] = 0x42;
   const u32 nh = G.r_nheads[r];
@@ -262,35 +252,50 @@ AMH_DEV void k_sm_fill(const SyncDev& G, u32 r) {
       const u32 head = wr_uleb(o + pos, nb);
       o[pos + head] = 10;
       o[pos + head + 1] = 7;
-      u8* bits = o + pos + head + 2;
-      const u32 nbytes = bl - head - 2, modulo = 8 * nbytes;
-      for (u32 i = 0; i < nbytes; i++) bits[i] = 0;
-      for (u32 c = 0; c < R.nc; c++) {
-        if (!(R.cf[c] & SMC_BLOOM)) continue;
-        const u8* h = sm_chg_hash(G, R, c);
-        u32 x = ((u32)h[0] | ((u32)h[1] << 8) | ((u32)h[2] << 16) | ((u32)h[3] << 24)) % modulo;
-        u32 y = ((u32)h[4] | ((u32)h[5] << 8) | ((u32)h[6] << 16) | ((u32)h[7] << 24)) % modulo;
-        const u32 z = ((u32)h[8] | ((u32)h[9] << 8) | ((u32)h[10] << 16) | ((u32)h[11] << 24)) % modulo;
-        bits[x >> 3] |= (u8)(1u << (x & 7));
-        for (u32 k = 1; k < 7; k++) {
-          x = (u32)(((u64)x + y) % modulo);
-          y = (u32)(((u64)y + z) % modulo);
-          bits[x >> 3] |= (u8)(1u << (x & 7));
-        }
-      }
+      G.r_bits_at[r] = G.msg_off[r] + pos + head + 2;
       pos += bl;
     }
   }
-  const u32 ns = G.r_nsend[r], jb = G.job_base[r];
-  pos += wr_uleb(o + pos, ns);
-  for (u32 k = 0; k < ns; k++) {
-    const u32 gc = R.cb + R.send[k], cl = B.c_out_len[gc];
-    pos += wr_uleb(o + pos, cl);
-    G.job_src[jb + k] = (u64)(uintptr_t)(B.out_arena + B.c_out_off[gc]);
-    G.job_len[jb + k] = cl;
-    G.job_dst[jb + k] = (u64)G.msg_off[r] + pos;
-    pos += cl;
-    const u8* h = B.c_hash + (u64)gc * 32;
-    for (int b = 0; b < 32; b++) G.sent_out[(u64)(jb + k) * 32 + b] = h[b];
+  pos += wr_uleb(o + pos, G.r_nsend[r]);
+}
+// the record an index of a per-record region belongs to: the last r with base[r] <= i (bases ascend; empty regions repeat)
+template <class T>
+AMH_DEV u32 sm_find_rec(const T* base, u32 n, u64 i) {
+  u32 lo = 0, hi = n;
+  while (hi - lo > 1) { const u32 mid = lo + (hi - lo) / 2; if ((u64)base[mid] <= i) lo = mid; else hi = mid; }
+  return lo;
+}
+// one change of one record: if the message's Have holds it (SMC_BLOOM), its 7 probes (bloom.rs:69-102) into the bits
+AMH_DEV void k_sm_bloom(const SyncDev& G, u32 i) {
+  const u32 r = sm_find_rec(G.r_flag_base, G.n_rec, i);
+  const u32 at = G.r_bits_at[r];
+  if (at == 0) return;
+  const u32 c = (u32)(i - G.r_flag_base[r]);
+  if (!(G.c_flag[i] & SMC_BLOOM)) return;
+  const u32 nb = G.r_bloom_n[r];
+  const u32 nbytes = (u32)(((u64)nb * 10 + 7) / 8), modulo = 8 * nbytes;
+  const u8* h = G.B.c_hash + (u64)(G.B.chg_base[G.r_doc[r]] + c) * 32;
+  u32 x = ((u32)h[0] | ((u32)h[1] << 8) | ((u32)h[2] << 16) | ((u32)h[3] << 24)) % modulo;
+  u32 y = ((u32)h[4] | ((u32)h[5] << 8) | ((u32)h[6] << 16) | ((u32)h[7] << 24)) % modulo;
+  const u32 z = ((u32)h[8] | ((u32)h[9] << 8) | ((u32)h[10] << 16) | ((u32)h[11] << 24)) % modulo;
+  for (u32 k = 0; k < 7; k++) {
+    if (k) { x = (u32)(((u64)x + y) % modulo); y = (u32)(((u64)y + z) % modulo); }
+    const u64 byte = (u64)at + (x >> 3);   // a byte of msg_out: set through the aligned word that holds it
+    amh_atomic_or((u32*)(G.msg_out + (byte & ~(u64)3)), (1u << (x & 7)) << (8 * (u32)(byte & 3)));
   }
+}
+// one change sent by one record: length prefix, copy job, hash
+AMH_DEV void k_sm_jobs(const SyncDev& G, u32 j) {
+  const BatchDev& B = G.B;
+  const u32 r = sm_find_rec(G.job_base, G.n_rec, j);
+  const SmRec R = sm_rec(G, r);
+  const u32 k = j - G.job_base[r];
+  const u32 gc = R.cb + R.send[k], cl = B.c_out_len[gc];
+  u64 at = (u64)G.msg_off[r] + R.spos[k];
+  if (!G.raw) at += wr_uleb(G.msg_out + at, cl);
+  G.job_src[j] = (u64)(uintptr_t)(B.out_arena + B.c_out_off[gc]);
+  G.job_len[j] = cl;
+  G.job_dst[j] = at;
+  const u8* h = B.c_hash + (u64)gc * 32;
+  for (int b = 0; b < 32; b++) G.sent_out[(u64)j * 32 + b] = h[b];
 }

@@ -333,9 +333,10 @@ struct SyncDev {
   const u64 *r_flag_base, *r_clock_base, *r_word_base;   // [n_rec]
   u8* c_flag;                      // [sum n_chg] SMC_* bits per (record, change)
   u64* clock;                      // [sum n_actors]
-  u32* words;                      // per record: heads[n_chg] | need[n_qdeps + n_their_heads] | send[n_their_need + n_chg]
+  u32* words;                      // per record: heads[n_chg] | need[n_qdeps + n_their_heads] | send[n_their_need + n_chg] | spos[same]
   // results
   u32 *r_kind, *r_nheads, *r_nneed, *r_nsend, *r_bloom_n;   // [n_rec]; r_bloom_n = AMH_NULL32: no Have in the message
+  u32* r_bits_at;                  // [n_rec] where the Bloom filter's bits start in msg_out (0 = none)
   u32* msg_off;                    // [n_rec + 1] message sizes, then their exclusive scan
   u32* job_base;                   // [n_rec + 1] r_nsend, scanned: places in the copy job tables and in sent_out
   u8* msg_out;

@@ -643,7 +643,7 @@ def bench_sync(args, eng, rank, world, dist, torch, red_dev):
                                      "note": "VALU-integer bound (64 rounds of 32-bit ALU per 64-byte block), reported as bytes hashed, not against HBM"},
                           "sync_kernels_ms": {k: round(kt[k][0], 3) for k in ("sync_size", "sync_fill") if k in kt},
                           "sync_messages": {"records": args.docs, "message_bytes": msg_bytes, "changes_sent": msg_changes, "call_ms": round(sm_ms, 2), "call_with_host_copy_ms": round(sm_host_ms, 2),
-                                            "kernels_ms": {k: round(kt[k][0], 3) for k in ("sm_lookup", "sm_plan", "sm_fill", "sm_copy") if k in kt},
+                                            "kernels_ms": {k: round(kt[k][0], 3) for k in ("sm_lookup", "sm_plan", "sm_fill", "sm_bloom", "sm_jobs", "sm_copy") if k in kt},
                                             # the chunk copy moves every change chunk once (read + write); plan reads the change rows of a record a few times
                                             "sm_copy_GBps": round(2 * st["change_bytes"] / max(kt.get("sm_copy", (1e-9, 0))[0], 1e-9) / 1e6, 1),
                                             "sm_plan_GBps": round((st["changes"] * 120 + args.docs * 64) / max(kt.get("sm_plan", (1e-9, 0))[0], 1e-9) / 1e6, 1)},

@@ -75,6 +75,8 @@ void amh_launch_sm(int k, const SyncDev* G, u32 n, void*) {
     if (k == SK_LOOKUP) k_sm_lookup(*G, i);
     else if (k == SK_PLAN) k_sm_plan(*G, i);
     else if (k == SK_FILL) k_sm_fill(*G, i);
+    else if (k == SK_BLOOM) k_sm_bloom(*G, i);
+    else if (k == SK_JOBS) k_sm_jobs(*G, i);
   }
 }
 void amh_copy_bytes(const u64* src, const u32* len, const u32* dst_off, u8* dst, u32 n, void*) {
