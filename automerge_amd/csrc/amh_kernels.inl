@@ -1975,8 +1975,8 @@ AMH_DEV void k_text_len(const BatchDev& B, u32 r) {
 AMH_DEV void k_text_fill(const BatchDev& B, u32 r) {
   const u32 n = B.tx_off[r + 1] - B.tx_off[r];
   if (n == 0) return;
-  bool is_str;
-  text_row_len(B, r, is_str);
+  // a row with bytes is a winner inside a text object (k_text_len looked the object up): only its kind is left to tell
+  const bool is_str = B.r_action[r] == 1 && (B.r_vmeta[r] & 15) == 6;
   u8* o = B.tx_out + B.tx_off[r];
   if (is_str) {
     const DocDesc& D = B.desc[B.r_doc[r]];
