@@ -433,6 +433,36 @@ def check_random_states(engine, seed):
     return kinds
 
 
+def check_long_history(engine, n=3000):
+    """records over a long history (a text typed one character per change) beside records over short ones in the same
+    call: the per-change kernels (Bloom bits, length prefixes, copy jobs) find their record across very different sizes"""
+    import adversarial_cases as adv
+    import oracle_lib as o
+    long_doc = o.Doc(); long_doc.apply_changes(adv.keystrokes(n))
+    hashes = [c["hash"] for c in long_doc.changes()]
+    small_docs, _ = random_states_case(0x10F6)
+    docs = [small_docs[0], long_doc] + list(small_docs[1:3])
+    batch = engine.load_batch([d.save(deflate=False) for d in docs])
+    records = []
+    for d, dd in enumerate(docs):
+        hs = hashes if dd is long_doc else [c["hash"] for c in dd.changes()]
+        for ls in ([], [hs[len(hs) // 2]], [hs[-1]]):
+            st = SyncState(); st.their_heads, st.their_need, st.their_have = list(ls), [], [SyncHave(list(ls), b"")]
+            records.append((d, st))
+        st = SyncState(); st.shared_heads = [hs[len(hs) // 3]]   # a Have with a Bloom filter over the later two thirds
+        records.append((d, st))
+    blobs = [to_blob(st) for _, st in records]
+    msgs = batch.generate_sync_messages([(d, from_blob(b)) for (d, _), b in zip(records, blobs)])
+    n_changes = 0
+    for (d, _), blob, m in zip(records, blobs, msgs):
+        want, _new = docs[d].generate_sync_message(blob)
+        assert m == want, (d, None if m is None else len(m), None if want is None else len(want))
+        n_changes += len(SyncMessage.decode(m).changes) if m is not None else 0
+    batch.close()
+    assert n_changes >= n + n // 2
+    return n_changes
+
+
 def check_golden_documents(engine, golden_dir, seed=0x601D):
     """every golden document (the reference-written ones included) and a failed one, each with random States: the records
     of good documents agree with the oracle, the record of the failed document reports its load error"""

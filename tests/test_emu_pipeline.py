@@ -388,6 +388,11 @@ def test_sync_conversations(emu):
     sc.check_reset_and_queue(emu)
 
 
+def test_sync_messages_over_a_long_history(emu):
+    import sync_cases as sc
+    sc.check_long_history(emu, 1500)
+
+
 def test_sync_messages_for_golden_documents(emu, golden_dir):
     import sync_cases as sc
     sc.check_golden_documents(emu, golden_dir)

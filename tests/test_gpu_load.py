@@ -538,6 +538,11 @@ def test_sync_conversations(engine):
     sc.check_reset_and_queue(engine)
 
 
+def test_sync_messages_over_a_long_history(engine):
+    import sync_cases as sc
+    sc.check_long_history(engine, 20000)
+
+
 def test_sync_messages_for_golden_documents(engine, golden_dir):
     import sync_cases as sc
     sc.check_golden_documents(engine, golden_dir)
