@@ -13,6 +13,7 @@
 #include <set>
 #include <cmath>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -107,6 +108,7 @@ struct amh_ctx {
   u8* bigc = nullptr;             // pinned: the re-derived change chunks of a large document on their way to the host's SHA-256
   size_t bigc_cap = 0;
   u8* pin[2] = {nullptr, nullptr};   // pinned staging buffers of amh_stage_batch (double-buffered H2D), kept for the context's life
+  std::mutex pin_mu;                 // ... also the way out for large results (d2h_large): one copy at a time
   rt_event ev_pin[2]{};
   bool profiling = false;
   // limits (amh_ctx_set_limits): a document over the per-document limit, or the largest documents of a batch whose
@@ -319,9 +321,11 @@ static bool ensure_pins(amh_ctx* ctx) {
     }
   return true;
 }
-static bool d2h_large(amh_ctx* ctx, void* dst, const void* d_src, size_t n) {
+static bool d2h_large(amh_ctx* ctx, void* dst, const void* d_src, size_t n, size_t min_bytes = (size_t)4 << 20) {
   const size_t PIN = (size_t)32 << 20;
-  if (n < ((size_t)4 << 20) || !ensure_pins(ctx)) return rt_d2h(dst, d_src, n, ctx->stream);
+  if (n < min_bytes) return rt_d2h(dst, d_src, n, ctx->stream);
+  std::lock_guard<std::mutex> pin_lock(ctx->pin_mu);   // the two pinned buffers serve one copy at a time (a helper thread may be fetching a host view)
+  if (!ensure_pins(ctx)) return rt_d2h(dst, d_src, n, ctx->stream);
   const size_t pieces = (n + PIN - 1) / PIN;
   bool ok = true;
   for (size_t i = 0; i <= pieces && ok; i++) {
@@ -1071,7 +1075,7 @@ extern "C" amh_batch* amh_load_batch(amh_ctx* ctx, const uint8_t* const* docs, c
 template <class V, class T>
 static bool fetch(const amh_batch* b, V& v, const T* dev, size_t n) {
   v.resize(n);
-  return rt_d2h(v.data(), dev, n * sizeof(T), b->ctx->stream);
+  return d2h_large(b->ctx, v.data(), dev, n * sizeof(T), (size_t)1 << 20);   // the history of a wide batch is tens of MB
 }
 static bool ensure_base(const amh_batch* b) {
   HostView& hv = b->hv;
@@ -2459,6 +2463,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   // the host already)
   const bool use_pack = !dst->staged->host_ok;
   if (use_pack && !ensure_actor_pack(dst)) { set_error(ctx, std::string(who) + ": D2H copy failed"); return AMH_ERR_DEVICE; }
+  pt.mark("apply: actor tables of dst (device pack)");
   bool view_ok = true;
   std::thread view_thread([&]() {
     rt_set_device(ctx->device);
@@ -2468,22 +2473,45 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   const HostView& ha = dst->hv;
   const BatchDev& DB = dst->B;
   // ---- chunks of every pair: the new ones, then the document's queue -------------------------------
-  std::vector<HostChunk> chunks;
+  // The chunk list of a wide merge is 700,000 entries = 60 MB: a fresh block of that size is an mmap whose pages fault in
+  // one by one while the entries are constructed, and is unmapped again at the end.  The calling thread keeps the storage
+  // between calls (up to 256 MB; a nested call takes a list of its own).
+  static thread_local std::vector<HostChunk> t_chunks;
+  static thread_local bool t_chunks_busy = false;
+  std::vector<HostChunk> own_chunks;
+  const bool cached = !t_chunks_busy;
+  std::vector<HostChunk>& chunks = cached ? t_chunks : own_chunks;
+  // A list of device-resident chunks owns no memory: its entries are left in place for the next call, which then
+  // constructs nothing and overwrites every field (in parallel); any other list is cleared.
+  struct ChunkListGuard {
+    std::vector<HostChunk>& v; bool cached; bool keep = false;
+    ~ChunkListGuard() {
+      if (!cached) return;
+      if (!keep) v.clear();
+      if (v.capacity() * sizeof(HostChunk) > ((size_t)256 << 20)) std::vector<HostChunk>().swap(v);
+      t_chunks_busy = false;
+    }
+  } chunk_guard{chunks, cached};
+  if (cached) t_chunks_busy = true;
   std::vector<u32> pc_base(P + 1, 0);
   bool dev_only = dst->queue.empty();   // every item names device-resident chunks only (amh_merge_many of loaded batches): no stream to split
   for (u32 p = 0; p < P && dev_only; p++) dev_only = items[p].bufs.empty();
   if (dev_only) {
     size_t total = 0;
     for (u32 p = 0; p < P; p++) { pc_base[p] = (u32)total; total += items[p].dev.size(); }
-    chunks.resize(total);
+    chunks.resize(total);   // entries left by the last such call stay as they are
+    chunk_guard.keep = true;
+    pt.mark("apply: chunk list sized");
     host_parallel_for(P, [&](u32 p) {
       HostChunk* to = chunks.data() + pc_base[p];
       for (auto& dc : items[p].dev) {
         HostChunk& hc = *to++;
-        hc.pair = p; hc.dev = dc.d; hc.dev_sb = dc.sb; hc.dev_chg = dc.chg; hc.len = dc.len; hc.buf = dc.buf;
+        hc.pair = p; hc.p = nullptr; hc.len = dc.len; hc.bad = 0; hc.from_queue = false; hc.is_doc = false; hc.buf = dc.buf;
+        hc.dev = dc.d; hc.dev_sb = dc.sb; hc.dev_chg = dc.chg; hc.staged = AMH_NULL32;   // (`owned` is never used on this path)
       }
     });
   } else {
+    chunks.clear();
     std::vector<std::vector<HostChunk>> per_pair(P);
     host_parallel_for(P, [&](u32 p) {
       std::vector<HostChunk>& out = per_pair[p];
@@ -2579,10 +2607,10 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   amh_batch* hb = holder.get();
   hb->ctx = ctx;
   ApplyRun ap;
-  std::vector<u64> doc_off;
+  HVec<u64> doc_off;
   struct StageView { u8* p = nullptr; size_t n = 0; u8* data() const { return p; } size_t size() const { return n; } } h_arena;
   ap.s_desc.resize(P); ap.s_cnt.resize(P); ap.s_row_base.assign(P + 1, 0);
-  std::vector<u32> staged_of;   // U index -> chunks index
+  HVec<u32> staged_of;   // U index -> chunks index (every entry written by the parallel fill below: no zero fill)
   RawVec<u64> seg_nops, seg_npred;   // where the op / pred counts of a device-resident chunk lie (0 = not known)
   RawVec<u64> seg_src, seg_dst, seg_hash, seg_hdst;   // seg_hash / seg_hdst: where the hash of a device-resident chunk lies / goes in U.doc_hash
   RawVec<u32> seg_len;
