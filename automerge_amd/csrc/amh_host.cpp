@@ -13,7 +13,10 @@
 #include <set>
 #include <cmath>
 #include <string>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <unistd.h>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -1640,23 +1643,77 @@ struct RawBuf {
   size_t size() const { return n; }
 };
 
-// per-document host bookkeeping of a batch call on a few threads (documents are independent)
+// per-document host bookkeeping of a batch call on a few threads (documents are independent).
+// The threads are a process-wide pool: a wide merge runs a dozen such loops per call, and starting and joining 16
+// threads for each cost about as much as the loops themselves.  One region at a time (a second caller, or a loop
+// started from inside a region, runs the way it did before the pool: on threads of its own / inline); a forked child
+// gets a pool of its own (the parent's threads do not exist there); the pool is never torn down (its threads sleep on a
+// condition variable until the process ends).
+struct HostPool {
+  std::mutex m, region;
+  std::condition_variable cv_start, cv_done;
+  const std::function<void()>* body = nullptr;
+  u64 gen = 0;
+  unsigned running = 0, n_workers = 0;
+  long pid = 0;
+  explicit HostPool(unsigned workers) : n_workers(workers), pid((long)getpid()) {
+    for (unsigned t = 0; t < workers; t++)
+      std::thread([this]() {
+        in_worker() = true;
+        u64 seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+          cv_start.wait(lk, [&] { return gen != seen; });
+          seen = gen;
+          const std::function<void()>* f = body;
+          lk.unlock();
+          (*f)();
+          lk.lock();
+          if (--running == 0) cv_done.notify_all();
+        }
+      }).detach();
+  }
+  static bool& in_worker() { static thread_local bool w = false; return w; }
+  void run(const std::function<void()>& f) {   // f on every worker and on the caller; returns when all are back
+    {
+      std::lock_guard<std::mutex> lk(m);
+      body = &f; running = n_workers; gen++;
+    }
+    cv_start.notify_all();
+    f();
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return running == 0; });
+  }
+  static HostPool* get(unsigned nt) {
+    static std::mutex gm;
+    static HostPool* pool = nullptr;
+    std::lock_guard<std::mutex> lk(gm);
+    if (!pool || pool->pid != (long)getpid()) pool = new HostPool(nt - 1);   // (after a fork: the old one is left alone)
+    return pool;
+  }
+};
 template <class F>
 static void host_parallel_for(u32 n, F f, u32 min_items, u32 grain) {
-  unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
-  if (const char* e = getenv("OMP_NUM_THREADS")) { int v = atoi(e); if (v > 0) nt = std::min<unsigned>(nt, (unsigned)v); }
-  if (n < min_items || nt < 2) { for (u32 i = 0; i < n; i++) f(i); return; }
+  static const unsigned nt = [] {
+    unsigned v = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
+    if (const char* e = getenv("OMP_NUM_THREADS")) { int o = atoi(e); if (o > 0) v = std::min<unsigned>(v, (unsigned)o); }
+    return v;
+  }();
+  if (n < min_items || nt < 2 || HostPool::in_worker()) { for (u32 i = 0; i < n; i++) f(i); return; }
   std::atomic<u32> next{0};
-  std::vector<std::thread> ts;
-  for (unsigned t = 0; t < nt; t++)
-    ts.emplace_back([&]() {
-      for (;;) {
-        u32 lo = next.fetch_add(grain);
-        if (lo >= n) break;
-        u32 hi = std::min(n, lo + grain);
-        for (u32 i = lo; i < hi; i++) f(i);
-      }
-    });
+  const std::function<void()> body = [&]() {
+    for (;;) {
+      u32 lo = next.fetch_add(grain);
+      if (lo >= n) break;
+      u32 hi = std::min(n, lo + grain);
+      for (u32 i = lo; i < hi; i++) f(i);
+    }
+  };
+  HostPool* pool = HostPool::get(nt);
+  std::unique_lock<std::mutex> one(pool->region, std::try_to_lock);
+  if (one.owns_lock()) { pool->run(body); return; }
+  std::vector<std::thread> ts;   // the pool is serving another caller
+  for (unsigned t = 0; t < nt; t++) ts.emplace_back(body);
   for (auto& th : ts) th.join();
 }
 
@@ -2549,7 +2606,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   pt.mark("apply: split");
   // document chunks inside the streams (load_incremental of a whole saved document): loaded as a batch of their own
   // without the heads check (load.rs:90-93), each then stands for its re-derived changes
-  {
+  if (!dev_only) {   // (a list of device-resident chunks holds no document chunk: 700,000 entries are not walked to find that out)
     std::vector<u32> docs_at;
     for (u32 k = 0; k < chunks.size(); k++) if (chunks[k].is_doc) docs_at.push_back(k);
     if (!docs_at.empty()) {
@@ -2601,7 +2658,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     }
   }
   pc_base[P] = (u32)chunks.size();
-  for (auto& hc : chunks) if (!hc.p && !hc.bad && !hc.dev) hc.p = hc.owned.data();
+  if (!dev_only) for (auto& hc : chunks) if (!hc.p && !hc.bad && !hc.dev) hc.p = hc.owned.data();
   // ---- stage the good ones -----------------------------------------------------------------------
   std::unique_ptr<amh_batch, void (*)(amh_batch*)> holder(new amh_batch(), amh_batch_free);
   amh_batch* hb = holder.get();
