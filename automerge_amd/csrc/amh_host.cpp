@@ -100,6 +100,7 @@ struct amh_ctx {
   rt_stream side{};          // second stream: kernels that are independent of the main chain run beside it (fork / join by events)
   rt_event ev_fork{}, ev_fork2{}, ev_join{};
   DevPool pool;
+  size_t total_mem = 0;      // device memory of this GPU (batch_byte_budget)
   // pinned staging area of apply / merge_many calls, kept between calls (grow only): no page faults on fresh memory
   // every call, and the H2D copy of the change chunks runs at the pinned rate
   u8* stage = nullptr;
@@ -636,9 +637,12 @@ static u64 derived_bytes(u64 rows, u64 succ, u64 chg, u64 deps, u64 map) { retur
 // still does not fit what is free right now fails as a whole with AMH_ERR_OOM, as before.
 static u64 batch_byte_budget(amh_ctx* ctx) {
   if (ctx->max_batch_bytes) return ctx->max_batch_bytes;
-  size_t free_b = 0, total_b = 0;
-  if (!rt_mem_info(&free_b, &total_b)) return (u64)16 << 30;
-  return (u64)total_b / 10 * 9;
+  if (!ctx->total_mem) {   // asked once: the total does not change, and the query is a driver call
+    size_t free_b = 0, total_b = 0;
+    if (!rt_mem_info(&free_b, &total_b)) return (u64)16 << 30;
+    ctx->total_mem = total_b;
+  }
+  return (u64)ctx->total_mem / 10 * 9;
 }
 static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const amh_load_opts* opts, bool trailing) {
   if (!ctx || !st_c) { set_error(ctx, "invalid argument"); return nullptr; }
@@ -764,6 +768,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
       return fail("H2D copy failed");
     launch(ctx, AK_EXTRACT, B, n);
   }
+  pt.mark("load: parse, count, scans");
   B.tot_rows = totals[0]; B.tot_succ = totals[1]; B.tot_chg = totals[2]; B.tot_deps = totals[3];
   B.tot_actors = totals[4]; b->tot_ht = totals[5]; B.tot_dt = totals[6]; b->tot_map = totals[7];
   size_t NA = B.tot_actors + 1, NC = B.tot_chg + 2, NR = B.tot_rows + 1, NS = B.tot_succ + 1;
@@ -791,6 +796,7 @@ static amh_batch* load_staged_impl(amh_ctx* ctx, const amh_staged* st_c, const a
   B.s_actor = balloc<u32>(b, NS, &ok); B.s_ctr = balloc<u32>(b, NS, &ok); B.s_row = balloc<u32>(b, NS, &ok);
   B.s_target = balloc<u32>(b, NS, &ok); B.pred_ids = balloc<u64>(b, NS, &ok);
   if (!ok) return fail("device out of memory");
+  pt.mark("load: arrays allocated");
   rt_memset(B.s_row, 0xFF, NS * 4, ctx->stream);
   rt_memset(B.r_doc, 0xFF, NR * 4, ctx->stream);
   // "absent column" defaults of the two string columns (their staged decoder skips columns no document of a wave has);
@@ -3378,9 +3384,18 @@ extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* con
     items[p].mode = APM_STRICT;
     if (dst->status[a]) return;   // apply_core reports it
     u32 nca = ha.cnt[a].n_chg, cba = ha.chg_base[a];
-    std::unordered_map<Hash32, u32, Hash32Hasher> known;
-    known.reserve((size_t)nca * 2 + 16);
-    for (u32 i = 0; i < nca; i++) { Hash32 h; memcpy(h.b, ha.c_hash.data() + (size_t)(cba + i) * 32, 32); known.emplace(h, i); }
+    // the hashes the document holds so far: an open-addressing set of pointers into the host views, reused by the thread
+    // from pair to pair (a node-based map cost one allocation per hash: 800,000 per call of the headline step)
+    static thread_local std::vector<const u8*> known;
+    size_t kcap = 16, kneed = nca;
+    for (size_t s = 0; s < n_srcs; s++) { u32 b = src_idx[s * n_pairs + p]; if (b != AMH_NULL32 && !srcs[s]->status[b]) kneed += srcs[s]->hv.cnt[b].n_chg; }
+    while (kcap < 2 * kneed) kcap <<= 1;
+    known.assign(kcap, nullptr);
+    const size_t kmask = kcap - 1;
+    auto kslot = [&](const u8* h) { u64 k; memcpy(&k, h, 8); size_t i = (size_t)(k ^ (k >> 29)) & kmask; while (known[i] && memcmp(known[i], h, 32) != 0) i = (i + 1) & kmask; return i; };
+    auto known_has = [&](const u8* h) { return known[kslot(h)] != nullptr; };
+    auto known_add = [&](const u8* h) { known[kslot(h)] = h; };
+    for (u32 i = 0; i < nca; i++) known_add(ha.c_hash.data() + (size_t)(cba + i) * 32);
     u32 n_calls = 0;
     for (size_t s = 0; s < n_srcs; s++) {
       u32 b = src_idx[s * n_pairs + p];
@@ -3400,8 +3415,7 @@ extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* con
       while (!stack.empty()) {
         u32 j = stack.back(); stack.pop_back();
         if (seen[j]) continue;
-        Hash32 h; memcpy(h.b, bhash(j), 32);
-        if (known.count(h)) continue;
+        if (known_has(bhash(j))) continue;
         seen[j] = 1; added.push_back(j);
         deps.clear();
         for (u32 k = 0; k < hb.c_ndeps[cbb + j]; k++) deps.push_back(hb.dep_idx[hb.c_dep_base[cbb + j] + k]);
@@ -3414,8 +3428,7 @@ extern "C" int amh_merge_many(amh_ctx* ctx, amh_batch* dst, const amh_batch* con
       // source batch's device memory
       for (u32 j : added) {
         items[p].dev.push_back({sb->B.out_arena + hb.c_out_off[cbb + j], hb.c_out_len[cbb + j], n_calls, &sb->B, cbb + j});
-        Hash32 h; memcpy(h.b, bhash(j), 32);
-        known.emplace(h, 0);   // every added change applies (the source's history is causally closed)
+        known_add(bhash(j));   // every added change applies (the source's history is causally closed)
       }
       n_calls++;
     }

@@ -37,8 +37,26 @@ inline void rt_stream_wait(rt_stream, rt_event*) {}
 inline const char* rt_last_error() { return "emu"; }
 #else
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <map>
+#include <mutex>
 typedef hipStream_t rt_stream;
 struct rt_event { hipEvent_t e; };
+// AMH_COPY_TRACE=1 (development): transfers and fills counted per calling line of amh_host.cpp, printed at exit
+struct RtCopyTrace {
+  std::mutex m;
+  std::map<std::pair<char, int>, std::pair<size_t, size_t>> sites;   // (kind, line) -> (calls, bytes)
+  bool on = getenv("AMH_COPY_TRACE") != nullptr;
+  void note(char kind, int line, size_t n) { std::lock_guard<std::mutex> lk(m); auto& s = sites[{kind, line}]; s.first++; s.second += n; }
+  ~RtCopyTrace() {
+    if (!on) return;
+    for (auto& kv : sites) fprintf(stderr, "[amh copies] %c line %5d: %7zu calls %14zu bytes\n", kv.first.first, kv.first.second, kv.second.first, kv.second.second);
+  }
+};
+inline RtCopyTrace& rt_copy_trace() { static RtCopyTrace t; return t; }
+#define RT_NOTE(kind) do { RtCopyTrace& t_ = rt_copy_trace(); if (t_.on) t_.note(kind, line, n); } while (0)
 inline bool rt_init(int device, rt_stream* s, std::string& err) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { err = "no HIP device available (the HIP path is required; there is no CPU fallback)"; return false; }
@@ -52,15 +70,16 @@ inline void* rt_malloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, n ? n : 
 inline void rt_free(void* p) { (void)hipFree(p); }
 inline void* rt_host_alloc(size_t n) { void* p = nullptr; if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) return nullptr; return p; }
 inline void rt_host_free(void* p) { (void)hipHostFree(p); }
-inline bool rt_h2d(void* d, const void* h, size_t n, rt_stream s) { return n == 0 || hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) == hipSuccess; }
-inline bool rt_d2h(void* h, const void* d, size_t n, rt_stream s) {
+inline bool rt_h2d(void* d, const void* h, size_t n, rt_stream s, int line = __builtin_LINE()) { RT_NOTE('u'); return n == 0 || hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) == hipSuccess; }
+inline bool rt_d2h(void* h, const void* d, size_t n, rt_stream s, int line = __builtin_LINE()) {
+  RT_NOTE('d');
   if (n == 0) return true;
   if (hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) != hipSuccess) return false;
   return hipStreamSynchronize(s) == hipSuccess;
 }
-inline bool rt_d2h_async(void* h, const void* d, size_t n, rt_stream s) { return n == 0 || hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) == hipSuccess; }   // h pinned
-inline bool rt_d2d(void* d, const void* src, size_t n, rt_stream s) { return n == 0 || hipMemcpyAsync(d, src, n, hipMemcpyDeviceToDevice, s) == hipSuccess; }
-inline bool rt_memset(void* d, int v, size_t n, rt_stream s) { return n == 0 || hipMemsetAsync(d, v, n, s) == hipSuccess; }
+inline bool rt_d2h_async(void* h, const void* d, size_t n, rt_stream s, int line = __builtin_LINE()) { RT_NOTE('a'); return n == 0 || hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s) == hipSuccess; }   // h pinned
+inline bool rt_d2d(void* d, const void* src, size_t n, rt_stream s, int line = __builtin_LINE()) { RT_NOTE('c'); return n == 0 || hipMemcpyAsync(d, src, n, hipMemcpyDeviceToDevice, s) == hipSuccess; }
+inline bool rt_memset(void* d, int v, size_t n, rt_stream s, int line = __builtin_LINE()) { RT_NOTE('f'); return n == 0 || hipMemsetAsync(d, v, n, s) == hipSuccess; }
 inline bool rt_sync(rt_stream s) { return hipStreamSynchronize(s) == hipSuccess; }
 inline bool rt_mem_info(size_t* free_b, size_t* total_b) { return hipMemGetInfo(free_b, total_b) == hipSuccess; }
 inline void rt_event_create(rt_event* e) { (void)hipEventCreate(&e->e); }
