@@ -1700,9 +1700,21 @@ struct HostPool {
 };
 template <class F>
 static void host_parallel_for(u32 n, F f, u32 min_items, u32 grain) {
+  // Threads of the host loops: AMH_HOST_THREADS if set; else at most 16 and at most OMP_NUM_THREADS (on shared machines
+  // that is the process's CPU share).  torch.distributed.run sets OMP_NUM_THREADS=1 for every rank when the caller left
+  // it unset: under it (LOCAL_WORLD_SIZE > 1) a value of 1 is read as "unset" and the machine's threads are divided
+  // among the local ranks, or a rank's host passes would run 16 times slower beside its GPU.
   static const unsigned nt = [] {
-    unsigned v = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16);
-    if (const char* e = getenv("OMP_NUM_THREADS")) { int o = atoi(e); if (o > 0) v = std::min<unsigned>(v, (unsigned)o); }
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    unsigned v = std::min<unsigned>(hw, 16);
+    if (const char* e = getenv("AMH_HOST_THREADS")) { int o = atoi(e); if (o > 0) return std::min<unsigned>((unsigned)o, 64); }
+    if (const char* e = getenv("OMP_NUM_THREADS")) {
+      int o = atoi(e);
+      const char* lw = getenv("LOCAL_WORLD_SIZE");
+      const int ranks = lw ? atoi(lw) : 1;
+      if (o == 1 && ranks > 1) v = std::min<unsigned>(v, std::max(1u, hw / (unsigned)ranks));
+      else if (o > 0) v = std::min<unsigned>(v, (unsigned)o);
+    }
     return v;
   }();
   if (n < min_items || nt < 2 || HostPool::in_worker()) { for (u32 i = 0; i < n; i++) f(i); return; }

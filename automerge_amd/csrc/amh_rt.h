@@ -66,8 +66,8 @@ inline bool rt_init(int device, rt_stream* s, std::string& err) {
   return true;
 }
 inline void rt_shutdown(rt_stream s) { (void)hipStreamDestroy(s); }
-inline void* rt_malloc(size_t n) { void* p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr; return p; }
-inline void rt_free(void* p) { (void)hipFree(p); }
+inline void* rt_malloc(size_t n, int line = __builtin_LINE()) { RT_NOTE('m'); void* p = nullptr; if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr; return p; }
+inline void rt_free(void* p, size_t n = 0, int line = __builtin_LINE()) { RT_NOTE('r'); (void)hipFree(p); }
 inline void* rt_host_alloc(size_t n) { void* p = nullptr; if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) return nullptr; return p; }
 inline void rt_host_free(void* p) { (void)hipHostFree(p); }
 inline bool rt_h2d(void* d, const void* h, size_t n, rt_stream s, int line = __builtin_LINE()) { RT_NOTE('u'); return n == 0 || hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) == hipSuccess; }
