@@ -3800,17 +3800,25 @@ static int sm_to_device(amh_ctx* ctx, amh_batch* b, const amh_sync_state* states
   r_have[R] = (u32)h_entries.size();
   const u32 n_pool = (u32)pool_rec.size();
   pt.mark("states flattened (host)");
-  // ---- one upload: the tables side by side in one device block ----
-  std::vector<u8> blob;
-  auto put = [&](const void* p, size_t bytes) { size_t at = (blob.size() + 255) & ~(size_t)255; blob.resize(at + bytes); if (bytes) memcpy(blob.data() + at, p, bytes); return at; };
-  const size_t o_doc = put(r_doc.data(), R * 4), o_flags = put(r_flags.data(), R * 4), o_pool = put(pool.data(), pool.size()),
-               o_prec = put(pool_rec.data(), (size_t)n_pool * 4), o_list = put(r_list.data(), r_list.size() * 4), o_have = put(r_have.data(), r_have.size() * 4),
-               o_ls = put(h_ls.data(), h_ls.size() * 4), o_ent = put(h_entries.data(), h_entries.size() * 4), o_pr = put(h_probes.data(), h_probes.size() * 4),
-               o_bits = put(h_bits.data(), h_bits.size() * 8), o_nb = put(h_nbytes.data(), h_nbytes.size() * 4), o_bl = put(blooms.data(), blooms.size()),
-               o_fb = put(r_flag_base.data(), R * 8), o_cb = put(r_clock_base.data(), R * 8), o_wb = put(r_word_base.data(), R * 8);
-  const size_t o_G = put(nullptr, 0);
-  blob.resize(o_G + sizeof(SyncDev));
-  u8* d_blob = balloc<u8>(b, blob.size() + 256, &ok);
+  // ---- one upload: the tables side by side in one device block, put together in pinned memory when they fit it ----
+  struct Part { const void* p; size_t bytes; size_t at; };
+  Part parts[] = {{r_doc.data(), (size_t)R * 4, 0}, {r_flags.data(), (size_t)R * 4, 0}, {pool.data(), pool.size(), 0}, {pool_rec.data(), (size_t)n_pool * 4, 0},
+                  {r_list.data(), r_list.size() * 4, 0}, {r_have.data(), r_have.size() * 4, 0}, {h_ls.data(), h_ls.size() * 4, 0}, {h_entries.data(), h_entries.size() * 4, 0},
+                  {h_probes.data(), h_probes.size() * 4, 0}, {h_bits.data(), h_bits.size() * 8, 0}, {h_nbytes.data(), h_nbytes.size() * 4, 0}, {blooms.data(), blooms.size(), 0},
+                  {r_flag_base.data(), (size_t)R * 8, 0}, {r_clock_base.data(), (size_t)R * 8, 0}, {r_word_base.data(), (size_t)R * 8, 0}};
+  size_t blob_len = 0;
+  for (Part& q : parts) { q.at = (blob_len + 255) & ~(size_t)255; blob_len = q.at + q.bytes; }
+  const size_t o_doc = parts[0].at, o_flags = parts[1].at, o_pool = parts[2].at, o_prec = parts[3].at, o_list = parts[4].at, o_have = parts[5].at, o_ls = parts[6].at,
+               o_ent = parts[7].at, o_pr = parts[8].at, o_bits = parts[9].at, o_nb = parts[10].at, o_bl = parts[11].at, o_fb = parts[12].at, o_cb = parts[13].at, o_wb = parts[14].at;
+  const size_t o_G = (blob_len + 255) & ~(size_t)255;
+  blob_len = o_G + sizeof(SyncDev);
+  std::vector<u8> blob_mem;
+  std::unique_lock<std::mutex> pin_lock(ctx->pin_mu, std::defer_lock);
+  u8* blob = nullptr;
+  if (blob_len <= ((size_t)32 << 20)) { pin_lock.lock(); if (ensure_pins(ctx)) blob = ctx->pin[0]; else pin_lock.unlock(); }
+  if (!blob) { blob_mem.resize(blob_len); blob = blob_mem.data(); }
+  for (const Part& q : parts) if (q.bytes) memcpy(blob + q.at, q.p, q.bytes);
+  u8* d_blob = balloc<u8>(b, blob_len + 256, &ok);
   SyncDev G;
   memset(&G, 0, sizeof G);
   G.B = b->B;
@@ -3831,9 +3839,10 @@ static int sm_to_device(amh_ctx* ctx, amh_batch* b, const amh_sync_state* states
   G.h_ls = (const u32*)(d_blob + o_ls); G.h_entries = (const u32*)(d_blob + o_ent); G.h_probes = (const u32*)(d_blob + o_pr);
   G.h_bits = (const u64*)(d_blob + o_bits); G.h_nbytes = (const u32*)(d_blob + o_nb); G.blooms = d_blob + o_bl;
   G.r_flag_base = (const u64*)(d_blob + o_fb); G.r_clock_base = (const u64*)(d_blob + o_cb); G.r_word_base = (const u64*)(d_blob + o_wb);
-  memcpy(blob.data() + o_G, &G, sizeof G);
+  memcpy(blob + o_G, &G, sizeof G);
   SyncDev* dG = (SyncDev*)(d_blob + o_G);
-  if (!rt_h2d(d_blob, blob.data(), blob.size(), ctx->stream)) { set_error(ctx, "H2D copy failed"); return AMH_ERR_DEVICE; }
+  if (!rt_h2d(d_blob, blob, blob_len, ctx->stream)) { set_error(ctx, "H2D copy failed"); return AMH_ERR_DEVICE; }
+  if (pin_lock.owns_lock()) { if (!rt_sync(ctx->stream)) { set_error(ctx, "H2D copy failed"); return AMH_ERR_DEVICE; } pin_lock.unlock(); }   // the pinned buffer is free again
   launch_sm_timed(ctx, SK_LOOKUP, dG, n_pool);
   launch_sm_timed(ctx, SK_PLAN, dG, R);
   u32 total = 0, jobs = 0;
