@@ -105,6 +105,8 @@ struct amh_ctx {
   // every call, and the H2D copy of the change chunks runs at the pinned rate
   u8* stage = nullptr;
   size_t stage_cap = 0;
+  u8* tabs = nullptr;             // pinned: the per-chunk tables of a wide merge (sources, places, hashes, counts) on their way to the device
+  size_t tabs_cap = 0;
   u8* heads = nullptr;            // pinned: the packed heads of device-resident change chunks on their way to the host
   size_t heads_cap = 0;
   u8* res = nullptr;              // pinned: per-chunk results of an apply's decode pass (headers, counts, hashes)
@@ -2455,12 +2457,13 @@ struct ApplyItem {
 };
 // a table filled in full by its owner: sized without the zero fill (and the page faults on one thread) of std::vector::resize
 template <class T> struct RawVec {
-  std::unique_ptr<T[]> p; size_t n = 0;
-  void resize(size_t k) { p.reset(k ? new T[k] : nullptr); n = k; }
-  T* data() const { return p.get(); }
+  std::unique_ptr<T[]> p; T* q = nullptr; size_t n = 0;
+  void resize(size_t k) { p.reset(k ? new T[k] : nullptr); q = p.get(); n = k; }
+  void attach(T* ext, size_t k) { p.reset(); q = ext; n = k; }   // storage owned by someone else (the context's pinned table area)
+  T* data() const { return q; }
   size_t size() const { return n; }
   bool empty() const { return n == 0; }
-  T& operator[](size_t i) const { return p[i]; }
+  T& operator[](size_t i) const { return q[i]; }
 };
 template <class T> struct PinSpan { T* p = nullptr; T& operator[](size_t i) const { return p[i]; } T* data() const { return p; } };
 struct HostChunk {
@@ -2719,7 +2722,25 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     p_n[P] = nu; p_dev[P] = ndev;
     n_host_staged = nu - ndev;
     staged_of.resize(nu); ap.c_pair.resize(nu); ap.c_rel.resize(nu); doc_off.resize(2 * (size_t)nu);
-    seg_src.resize(ndev); seg_len.resize(ndev); seg_dst.resize(ndev); seg_hash.resize(ndev); seg_hdst.resize(ndev); seg_nops.resize(ndev); seg_npred.resize(ndev);
+    // 52 bytes per device-resident chunk, 36 MB for the 700,000 chunks of the headline step: written straight into pinned
+    // memory (kept by the context, grow only), so that their uploads run at the link's rate and do not hold the host
+    {
+      const size_t per = ((size_t)ndev * 8 + 255) & ~(size_t)255, need = 7 * per + 256;
+      if (ndev >= 4096 && need > ctx->tabs_cap) {
+        rt_sync(ctx->stream);
+        if (ctx->tabs) rt_host_free(ctx->tabs);
+        ctx->tabs_cap = need + need / 4;
+        ctx->tabs = (u8*)rt_host_alloc(ctx->tabs_cap);
+        if (!ctx->tabs) ctx->tabs_cap = 0;
+      }
+      if (ndev >= 4096 && ctx->tabs) {
+        u8* t = ctx->tabs;
+        seg_src.attach((u64*)t, ndev); seg_dst.attach((u64*)(t + per), ndev); seg_hash.attach((u64*)(t + 2 * per), ndev); seg_hdst.attach((u64*)(t + 3 * per), ndev);
+        seg_nops.attach((u64*)(t + 4 * per), ndev); seg_npred.attach((u64*)(t + 5 * per), ndev); seg_len.attach((u32*)(t + 6 * per), ndev);
+      } else {
+        seg_src.resize(ndev); seg_len.resize(ndev); seg_dst.resize(ndev); seg_hash.resize(ndev); seg_hdst.resize(ndev); seg_nops.resize(ndev); seg_npred.resize(ndev);
+      }
+    }
     pt.mark("apply: stage layout");
     if ((size_t)off + 256 > ctx->stage_cap) {
       rt_sync(ctx->stream);   // nothing may still be copying out of the old area
@@ -4144,6 +4165,7 @@ extern "C" void amh_ctx_destroy(amh_ctx* ctx) {
   ctx->pool.trim();
   if (ctx->stage) rt_host_free(ctx->stage);
   if (ctx->heads) rt_host_free(ctx->heads);
+  if (ctx->tabs) rt_host_free(ctx->tabs);
   if (ctx->res) rt_host_free(ctx->res);
   if (ctx->bigc) rt_host_free(ctx->bigc);
 #ifndef AMH_EMU
