@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_encode_one(BatchDev B, u32 gm
     for (int k = 0; k < AMH_NCOLS; k++) { clen[k] = cl[k]; coff[k] = o; o += clen[k]; }
   }
   auto open = [&](Sc1Col& o, u32 k) {
-    if (MODE == 0) { u32 cap; u8* s = sc1_slot(B, c, k, base, n, pb, pn, cap); sc1_init(o, s, cap); }
+    if (MODE == 0) { u32 cap; u8* s = sc1_slot(B, c, k, base, n, pb, pn, cap); if (gmask & 0x100u) { s += cap; cap = 0; } sc1_init(o, s, cap); }   // (development, bit 8 of AMH_ENC_GMASK: no column fits its slot, every one is written by the second walk — what the first walk costs without its stores)
     else if (((flags >> k) & 1) && clen[k]) sc1_init(o, cols + coff[k], clen[k]);
     else sc1_init(o, (u8*)0, 0);
   };
@@ -244,11 +244,12 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_encode_one(BatchDev B, u32 gm
     if (len > o.cap) atomicOr(&B.c_wide[c], 1u << k);
   };
   for (u32 G = blk % parts; G < SC_GROUPS; G += parts) {
-    if (!((gmask >> G) & 1)) continue;   // (development: AMH_ENC_GMASK times the column groups one by one)
-    if (MODE == 1) {   // groups without a flagged column
-      const u32 gm = G == 0 ? 0x2003u : G == 1 ? 0x001Cu : G == 2 ? 0x1260u : G == 3 ? 0x0180u : 0x0C00u;
-      if (!(flags & gm)) continue;
+    const u32 gm = G == 0 ? 0x2003u : G == 1 ? 0x001Cu : G == 2 ? 0x1260u : G == 3 ? 0x0180u : 0x0C00u;   // the group's columns
+    if (!((gmask >> G) & 1)) {   // (development: AMH_ENC_GMASK times the column groups one by one; a group left out has empty columns)
+      if (MODE == 0 && lane == 0) for (u32 k = 0; k < AMH_NCOLS; k++) if ((gm >> k) & 1) cl[k] = 0;
+      continue;
     }
+    if (MODE == 1 && !(flags & gm)) continue;   // groups without a flagged column
     if (G == 0) {   // object id (columns 0, 1) and mark names (13)
       Sc1Col ca, cc;
       open(ca, 0); open(cc, 1);
@@ -259,6 +260,7 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_encode_one(BatchDev B, u32 gm
           return v;
         },
         [&](const Sc1Obj& v, const Sc1Obj& f, u32 tb, u32 cnt) {
+          if (gmask & 0x200u) { ca.total += (u32)__popcll(__ballot(((v.oa ^ v.oc) & 1) != 0)); return; }   // (development, bit 9: gathers only)
           const bool pn0 = sc1_last(f.oc) == 0;
           sc1_num<false, u32>(ca, v.oa, v.oc == 0, sc1_last(f.oa), pn0, tb, cnt, lane);
           sc1_num<false, u32>(cc, v.oc, v.oc == 0, sc1_last(f.oc), pn0, tb, cnt, lane);
@@ -307,6 +309,7 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_encode_one(BatchDev B, u32 gm
           return v;
         },
         [&](const Sc1Key& v, const Sc1Key& f, u32 tb, u32 cnt) {
+          if (gmask & 0x200u) { ca.total += (u32)__popcll(__ballot(((v.ka ^ v.kind ^ (u32)v.delta ^ v.s.len) & 1) != 0)); return; }
           const u32 fk = sc1_last(f.kind);
           sc1_num<false, u32>(ca, v.ka, v.kind != 2, sc1_last(f.ka), fk != 2, tb, cnt, lane);
           sc1_num<true, u64>(ck, v.delta, v.kind == 0 || v.kind == 3, sc1_last(f.delta), fk == 0, tb, cnt, lane);
@@ -331,6 +334,7 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_encode_one(BatchDev B, u32 gm
           return v;
         },
         [&](const Sc1Misc& v, const Sc1Misc& f, u32 tb, u32 cnt) {
+          if (gmask & 0x200u) { ci.total += (u32)__popcll(__ballot(((v.f ^ v.np) & 1) != 0)); return; }
           const u32 ff = sc1_last(f.f);
           sc1_bool(ci, (v.f & 1) != 0, (ff & 1) != 0, tb, cnt, lane);
           sc1_num<false, u32>(ca, v.f >> 8, false, ff >> 8, false, tb, cnt, lane);
@@ -357,6 +361,7 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_encode_one(BatchDev B, u32 gm
           return v;
         },
         [&](const Sc1Val& v, const Sc1Val& f, u32 tb, u32 cnt) {
+          if (gmask & 0x200u) { cm.total += (u32)__popcll(__ballot((((u32)v.meta ^ (u32)v.raw.x ^ v.raw.len) & 1) != 0)); return; }
           sc1_num<false, u64>(cm, v.meta, false, sc1_last(f.meta), false, tb, cnt, lane);
           sc1_raw(cr, v.raw, cnt, lane);
         });
@@ -376,6 +381,7 @@ __global__ void __launch_bounds__(64 * SD_WAVES) g_encode_one(BatchDev B, u32 gm
           return v;
         },
         [&](const Sc1Pred& v, const Sc1Pred& f, u32 tb, u32 cnt) {
+          if (gmask & 0x200u) { ca.total += (u32)__popcll(__ballot(((v.pa ^ (u32)v.delta) & 1) != 0)); return; }
           sc1_num<false, u32>(ca, v.pa, false, sc1_last(f.pa), false, tb, cnt, lane);
           sc1_num<true, u64>(cc, v.delta, false, sc1_last(f.delta), false, tb, cnt, lane);
         });
