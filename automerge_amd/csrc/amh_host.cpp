@@ -329,16 +329,17 @@ static bool ensure_pins(amh_ctx* ctx) {
 }
 static bool d2h_large(amh_ctx* ctx, void* dst, const void* d_src, size_t n, size_t min_bytes = (size_t)4 << 20) {
   const size_t PIN = (size_t)32 << 20;
-  if (n < min_bytes) return rt_d2h(dst, d_src, n, ctx->stream);
+  const rt_stream stream = ctx->stream;
+  if (n < min_bytes) return rt_d2h(dst, d_src, n, stream);
   std::lock_guard<std::mutex> pin_lock(ctx->pin_mu);   // the two pinned buffers serve one copy at a time (a helper thread may be fetching a host view)
-  if (!ensure_pins(ctx)) return rt_d2h(dst, d_src, n, ctx->stream);
+  if (!ensure_pins(ctx)) return rt_d2h(dst, d_src, n, stream);
   const size_t pieces = (n + PIN - 1) / PIN;
   bool ok = true;
   for (size_t i = 0; i <= pieces && ok; i++) {
     if (i < pieces) {
       const size_t o = i * PIN, l = std::min(PIN, n - o);
-      ok = rt_d2h_async(ctx->pin[i & 1], (const u8*)d_src + o, l, ctx->stream);
-      rt_event_record(&ctx->ev_pin[i & 1], ctx->stream);
+      ok = rt_d2h_async(ctx->pin[i & 1], (const u8*)d_src + o, l, stream);
+      rt_event_record(&ctx->ev_pin[i & 1], stream);
     }
     if (i > 0) {
       const size_t o = (i - 1) * PIN, l = std::min(PIN, n - o);
@@ -352,7 +353,7 @@ static bool d2h_large(amh_ctx* ctx, void* dst, const void* d_src, size_t n, size
       for (int t = 0; t < 3; t++) th[t].join();
     }
   }
-  return ok && rt_sync(ctx->stream);
+  return ok && rt_sync(stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2495,7 +2496,9 @@ static i32 change_err_kind(i32 dev_status) {   // storage/load.rs:15-30 as seen 
   return AMH_E_INVALID_CHANGE_COLUMNS;
 }
 // split a byte stream into chunks (storage/load.rs:56-114); stops at the first position that is not a chunk
-static void split_chunks(u32 pair, const u8* p, size_t len, std::vector<HostChunk>& out) {
+// `sink` takes every chunk in stream order
+template <class Sink>
+static void split_chunks(u32 pair, const u8* p, size_t len, Sink&& sink) {
   size_t off = 0;
   while (off < len) {
     HostChunk hc;
@@ -2506,23 +2509,23 @@ static void split_chunks(u32 pair, const u8* p, size_t len, std::vector<HostChun
     u64 dlen = 0;
     if (avail < 10 || q[0] != 0x85 || q[1] != 0x6f || q[2] != 0x4a || q[3] != 0x83 || q[8] > 2 || !host_uleb(q, pos, avail, dlen) || dlen > avail - pos) {
       hc.bad = AMH_E_PARSE;
-      out.push_back(std::move(hc));
+      sink(std::move(hc));
       return;
     }
     size_t total = pos + (size_t)dlen;
     if (q[8] == 0) {   // a document chunk inside a change stream stands for its changes (load.rs:84-100): expanded by apply_core
       hc.p = q; hc.len = total; hc.is_doc = true;
-      out.push_back(std::move(hc));
+      sink(std::move(hc));
       off += total;
       continue;
     }
     if (q[8] == 2) {
-      if (!amh_ingest_inflate_change(q, total, hc.owned)) { hc.bad = AMH_E_PARSE; out.push_back(std::move(hc)); return; }
+      if (!amh_ingest_inflate_change(q, total, hc.owned)) { hc.bad = AMH_E_PARSE; sink(std::move(hc)); return; }
       hc.p = nullptr; hc.len = hc.owned.size();
     } else {
       hc.p = q; hc.len = total;
     }
-    out.push_back(std::move(hc));
+    sink(std::move(hc));
     off += total;
   }
 }
@@ -2542,12 +2545,11 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   const bool use_pack = !dst->staged->host_ok;
   if (use_pack && !ensure_actor_pack(dst)) { set_error(ctx, std::string(who) + ": D2H copy failed"); return AMH_ERR_DEVICE; }
   pt.mark("apply: actor tables of dst (device pack)");
-  bool view_ok = true;
-  std::thread view_thread([&]() {
-    rt_set_device(ctx->device);
-    view_ok = ensure_chg(dst);
-  });
-  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } view_joiner{view_thread};
+  // The host view of dst's history (hashes, deps, actors: ~100 bytes per change) is fetched here, before anything else
+  // runs.  (It used to come back on a helper thread beside the staging below; once that staging ran on all host threads
+  // the helper's copies took 33 ms instead of 6.5 and the decisions waited for them.)
+  if (!ensure_chg(dst)) { set_error(ctx, std::string(who) + ": D2H copy failed"); return AMH_ERR_DEVICE; }
+  pt.mark("apply: host view of dst");
   const HostView& ha = dst->hv;
   const BatchDev& DB = dst->B;
   // ---- chunks of every pair: the new ones, then the document's queue -------------------------------
@@ -2572,6 +2574,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   } chunk_guard{chunks, cached};
   if (cached) t_chunks_busy = true;
   std::vector<u32> pc_base(P + 1, 0);
+  bool any_doc = false;   // a document chunk among the incoming chunks
   bool dev_only = dst->queue.empty();   // every item names device-resident chunks only (amh_merge_many of loaded batches): no stream to split
   for (u32 p = 0; p < P && dev_only; p++) dev_only = items[p].bufs.empty();
   if (dev_only) {
@@ -2589,45 +2592,56 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       }
     });
   } else {
-    chunks.clear();
-    std::vector<std::vector<HostChunk>> per_pair(P);
-    host_parallel_for(P, [&](u32 p) {
-      std::vector<HostChunk>& out = per_pair[p];
-      u32 bi = 0;
-      auto qit = dst->queue.find(items[p].doc);
-      out.reserve(items[p].bufs.size() + items[p].dev.size() + (qit != dst->queue.end() ? qit->second.size() : 0));
+    // two walks over the streams' chunk headers: count per pair, then (places by prefix sums) every pair writes its
+    // stretch of the list itself — no list per pair, nothing constructed that is not used; entries left by the last call
+    // are overwritten whole (their `owned` buffers go with the assignment)
+    std::atomic<bool> saw_owned{false}, saw_doc{false};
+    auto walk_pair = [&](u32 p, HostChunk* to) -> u32 {   // to = nullptr: count
+      u32 n = 0, bi = 0;
+      auto emit = [&](HostChunk&& hc) {
+        if (to) {
+          HostChunk& d = to[n];
+          d = std::move(hc);
+          if (!d.owned.empty()) { saw_owned = true; if (!d.p && !d.bad) d.p = d.owned.data(); }
+          if (d.is_doc) saw_doc = true;
+        }
+        n++;
+      };
       for (auto& bf : items[p].bufs) {
-        size_t before = out.size();
-        split_chunks(p, bf.first, bf.second, out);
-        for (size_t k = before; k < out.size(); k++) out[k].buf = bi;
+        const u32 before = n;
+        bool bad = false;
+        split_chunks(p, bf.first, bf.second, [&](HostChunk&& hc) { hc.buf = bi; bad = hc.bad != 0; emit(std::move(hc)); });   // (the count walk inflates a deflated chunk as well: the same decisions in both walks)
         if (!items[p].one_call) bi++;
-        if (out.size() > before && out.back().bad) break;   // nothing behind a bad position is looked at
+        if (n > before && bad) break;   // nothing behind a bad position is looked at
       }
       for (auto& dc : items[p].dev) {
         HostChunk hc;
         hc.pair = p; hc.dev = dc.d; hc.dev_sb = dc.sb; hc.dev_chg = dc.chg; hc.len = dc.len; hc.buf = bi + dc.buf;
-        out.push_back(std::move(hc));
+        emit(std::move(hc));
       }
+      auto qit = dst->queue.find(items[p].doc);
       if (qit != dst->queue.end())
         for (auto& qb : qit->second) {
           HostChunk hc;
           hc.pair = p; hc.p = qb.data(); hc.len = qb.size(); hc.from_queue = true;
-          out.push_back(std::move(hc));
+          emit(std::move(hc));
         }
-    });
+      return n;
+    };
+    std::vector<u32> p_cnt(P);
+    host_parallel_for(P, [&](u32 p) { p_cnt[p] = walk_pair(p, nullptr); });
     size_t total = 0;
-    for (u32 p = 0; p < P; p++) { pc_base[p] = (u32)total; total += per_pair[p].size(); }
+    for (u32 p = 0; p < P; p++) { pc_base[p] = (u32)total; total += p_cnt[p]; }
     chunks.resize(total);
-    host_parallel_for(P, [&](u32 p) {
-      HostChunk* to = chunks.data() + pc_base[p];
-      for (auto& hc : per_pair[p]) *to++ = std::move(hc);
-      std::vector<HostChunk>().swap(per_pair[p]);
-    });
+    pt.mark("apply: chunk list sized");
+    host_parallel_for(P, [&](u32 p) { walk_pair(p, chunks.data() + pc_base[p]); });
+    any_doc = saw_doc;
+    chunk_guard.keep = !saw_owned && !saw_doc;   // a list that owns memory (inflated chunks, expanded documents) is cleared at the end
   }
   pt.mark("apply: split");
   // document chunks inside the streams (load_incremental of a whole saved document): loaded as a batch of their own
   // without the heads check (load.rs:90-93), each then stands for its re-derived changes
-  if (!dev_only) {   // (a list of device-resident chunks holds no document chunk: 700,000 entries are not walked to find that out)
+  if (any_doc) {   // (known from the split: the list is not walked to find that out)
     std::vector<u32> docs_at;
     for (u32 k = 0; k < chunks.size(); k++) if (chunks[k].is_doc) docs_at.push_back(k);
     if (!docs_at.empty()) {
@@ -2679,7 +2693,7 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
     }
   }
   pc_base[P] = (u32)chunks.size();
-  if (!dev_only) for (auto& hc : chunks) if (!hc.p && !hc.bad && !hc.dev) hc.p = hc.owned.data();
+  if (any_doc) for (auto& hc : chunks) if (!hc.p && !hc.bad && !hc.dev) hc.p = hc.owned.data();   // the changes of expanded documents
   // ---- stage the good ones -----------------------------------------------------------------------
   std::unique_ptr<amh_batch, void (*)(amh_batch*)> holder(new amh_batch(), amh_batch_free);
   amh_batch* hb = holder.get();
@@ -2976,9 +2990,6 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
       });
   }
   pt.mark("apply: U parse + count (decode + verify launched)");
-  view_thread.join();
-  if (!view_ok) { set_error(ctx, std::string(who) + ": D2H copy failed"); return AMH_ERR_DEVICE; }
-  pt.mark("apply: wait for dst's host view");
   // ---- host: which changes apply, in which order (automerge.rs:797-858); actors; merged history -----
   MgPlan pl;
   MG_REFS(pl)
