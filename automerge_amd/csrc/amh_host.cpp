@@ -331,7 +331,7 @@ static bool d2h_large(amh_ctx* ctx, void* dst, const void* d_src, size_t n, size
   const size_t PIN = (size_t)32 << 20;
   const rt_stream stream = ctx->stream;
   if (n < min_bytes) return rt_d2h(dst, d_src, n, stream);
-  std::lock_guard<std::mutex> pin_lock(ctx->pin_mu);   // the two pinned buffers serve one copy at a time (a helper thread may be fetching a host view)
+  std::lock_guard<std::mutex> pin_lock(ctx->pin_mu);   // the two pinned buffers serve one copy at a time
   if (!ensure_pins(ctx)) return rt_d2h(dst, d_src, n, stream);
   const size_t pieces = (n + PIN - 1) / PIN;
   bool ok = true;
@@ -2538,10 +2538,8 @@ static int apply_core(amh_ctx* ctx, amh_batch* dst, std::vector<ApplyItem>& item
   if (P == 0) return AMH_SUCCESS;
   AMH_NEEDS_OPS(dst, who)
   PhaseTimer pt(who);
-  // the host view of dst's history (hashes, deps, actors: ~100 bytes per change) comes back on a helper thread while
-  // this one splits, stages and decodes the incoming chunks; it is first needed by the decisions further down
-  // (of the documents' own bytes the decisions read the actor tables: packed on the device when the bytes are not on
-  // the host already)
+  // of the documents' own bytes the decisions further down read the actor tables: packed on the device when the bytes
+  // are not on the host already
   const bool use_pack = !dst->staged->host_ok;
   if (use_pack && !ensure_actor_pack(dst)) { set_error(ctx, std::string(who) + ": D2H copy failed"); return AMH_ERR_DEVICE; }
   pt.mark("apply: actor tables of dst (device pack)");
