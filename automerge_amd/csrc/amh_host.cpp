@@ -65,7 +65,9 @@ struct DevPool {
     n = (n + 255) & ~(size_t)255;
     if (n == 0) n = 256;
     auto it = free_blocks.lower_bound(n);
-    if (it != free_blocks.end() && it->first <= n + n / 4 + 4096) {
+    // a block up to a quarter larger than asked for; for large requests (a hipMalloc of a gigabyte takes milliseconds, and
+    // a request that keeps missing makes the pool grow by one block per call) up to twice as large
+    if (it != free_blocks.end() && (it->first <= n + n / 4 + 4096 || (n >= ((size_t)64 << 20) && it->first <= 2 * n))) {
       void* p = it->second;
       *got = it->first;
       pooled_bytes -= it->first;
@@ -73,6 +75,8 @@ struct DevPool {
       live_bytes += *got;
       return p;
     }
+    static const bool trace = getenv("AMH_POOL_TRACE") != nullptr;   // (development: which requests miss the pool)
+    if (trace) fprintf(stderr, "[amh pool] hipMalloc %zu bytes (live %zu, pooled %zu in %zu blocks)\n", n, live_bytes, pooled_bytes, free_blocks.size());
     void* p = rt_malloc(n);
     if (!p) {  // release the pool and retry once
       trim();
