@@ -863,8 +863,10 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
     B.ht_key = balloc<u64>(b, (size_t)tot_ht + 1, &ok); B.ht_val = balloc<u32>(b, (size_t)tot_ht + 1, &ok);
     B.dn_val = balloc<u32>(b, (size_t)tot_dn + 1, &ok);
     if (!ok) return fail("device out of memory");
+    pt.mark("tail: id tables sized (waits for the decode)");
     rt_memset(B.ht_key, 0, ((size_t)tot_ht + 1) * 8, ctx->stream);
     rt_memset(B.dn_val, 0xFF, ((size_t)tot_dn + 1) * 4, ctx->stream);
+    pt.mark("tail: id tables cleared (launched)");
   }
   launch(ctx, from_rows ? AK_ROWS_M : AK_ROWS, B, B.tot_rows);
   launch(ctx, AK_OBJ_ORDER, B, B.tot_rows);
@@ -879,10 +881,12 @@ static amh_batch* load_tail(amh_ctx* ctx, amh_batch* b, BigSha& big, const amh_l
   B.t_pred_cnt = balloc<u32>(b, (size_t)T + 2, &ok); B.t_pred_base = balloc<u32>(b, (size_t)T + 2, &ok);
   B.t_pred_fill = balloc<u32>(b, (size_t)T + 2, &ok); B.t_chg = balloc<u32>(b, (size_t)T + 2, &ok);
   if (!ok) return fail("device out of memory");
+  pt.mark("tail: rows .. delete table sized");
   rt_memset(B.dt_key, 0, ((size_t)B.tot_dt + 1) * 8, ctx->stream);
   rt_memset(B.d_first_pred_row, 0xFF, ((size_t)B.tot_dt + 1) * 4, ctx->stream);
   rt_memset(B.t_pred_cnt, 0, ((size_t)T + 2) * 4, ctx->stream);
   rt_memset(B.t_pred_fill, 0, ((size_t)T + 2) * 4, ctx->stream);
+  pt.mark("tail: delete table cleared (launched)");
   launch(ctx, AK_SUCC_LINK, B, B.tot_succ);
   B.a_tab_base = balloc<u32>(b, (size_t)B.tot_actors + 2, &ok); B.a_tab = balloc<u32>(b, (size_t)B.tot_chg + 2, &ok);
   B.a_tab_bn = balloc<u64>(b, (size_t)B.tot_actors + 2, &ok); B.a_tab_max = balloc<u32>(b, (size_t)B.tot_chg + 2, &ok);
