@@ -140,6 +140,15 @@ def column_bytes(eng, batch, n_docs):
     }
 
 
+# what holds a kernel below the HBM roofline, where it was measured (DESIGN.md section in brackets)
+ROOFLINE_NOTES = {
+    "encode_size": "scattered 4-byte gathers (op -> row -> ~12 fields, 64 cache lines per wave instruction): 2.63 of 3.72 ms per 6e7 ops with the encode logic removed [4.2b]",
+    "decode_ops": "instruction issue of the token / header / expand steps: 7 waves per SIMD, ~0.9 us per 64-value step [5a]",
+    "mg_rows_new": "scattered gathers of 15 fields per new row out of change order [5a]",
+    "encode_store": "per-lane column state machines of the lane-form encoder (50-op changes) [5a]",
+}
+
+
 def pmc_traffic(workload, dom):
     """HBM bytes per launch of kernel `dom` from the committed rocprofv3 --pmc passes of this same command
     (profiles/traffic_<workload>.json, tools/pmc_traffic.py: 2 x FETCH_SIZE + WRITE_SIZE, separate passes); None when
@@ -347,6 +356,7 @@ def bench_merge(args, eng, rank, world, dist, torch, red_dev):
                "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "traffic": traffic, "algorithmic_bytes_per_launch": model[dom] / dom_calls, "launch_ms": dom_ms / dom_calls,
                             "launches_per_step": dom_calls, "kernel_ms_total": total_kernel_ms,
+                            "limited_by": ROOFLINE_NOTES.get(dom),
                             "sha256": sha_roofline(hashed_bytes, sha_ms)},
                "kernels": kernels}
         if not args.no_cpu and world == 1:
