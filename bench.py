@@ -867,7 +867,7 @@ def main():
                    "sharding": f"documents x{world}", "gen_s": round(t_gen, 2), "stage_s": round(t_stage, 2),
                    "pcie_inclusive_ops_per_s": ops / (elapsed / args.steps + t_stage)},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": per_launch_bytes,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": per_launch_bytes, "limited_by": ROOFLINE_NOTES.get(dom),
                      "launch_ms": per_launch_ms, "kernel_ms_total": total_kernel_ms,
                      "sha256": sha_roofline(st["encoded_bytes"] + st["change_bytes"], sum(kt.get(k, (0, 0))[0] for k in ("chg_hash", "chg_hash_seq", "sha_doc")))},
         "kernels": kernels,
