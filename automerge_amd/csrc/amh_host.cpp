@@ -3763,9 +3763,11 @@ static int sm_to_device(amh_ctx* ctx, amh_batch* b, const amh_sync_state* states
     if (!rt_d2h(doc_sizes.data(), d_docs + R, (size_t)R * 8, ctx->stream)) { set_error(ctx, "D2H copy failed"); return AMH_ERR_DEVICE; }
   }
   // ---- the States, flattened: one hash pool, per-record list bounds, the Haves and their filters ----
-  std::vector<u32> r_doc(R), r_flags(R), r_list((size_t)R * SM_LISTS + 1), r_have(R + 1), pool_rec, h_ls, h_entries, h_probes, h_nbytes;
-  std::vector<u64> h_bits, r_flag_base(R), r_clock_base(R), r_word_base(R);
-  std::vector<u8> pool, blooms;
+  // Three passes, the first and the last over all records in parallel: what every record contributes (hashes, Haves,
+  // filter bytes; everything a record can be refused for), places by prefix sums, the copies.
+  HVec<u32> r_doc(R), r_flags(R), r_list((size_t)R * SM_LISTS + 1), r_have(R + 1), pool_rec, h_ls, h_entries, h_probes, h_nbytes;
+  HVec<u64> h_bits, r_flag_base(R), r_clock_base(R), r_word_base(R);
+  HVec<u8> pool, blooms;
   u64 n_flag = 0, n_clock = 0, n_word = 0;
   // deps of queued changes that are not queued themselves, and the hashes of the queued changes (get_missing_deps)
   struct QInfo { std::vector<u8> deps, hashes; };
@@ -3794,49 +3796,91 @@ static int sm_to_device(amh_ctx* ctx, amh_batch* b, const amh_sync_state* states
     for (auto& h : in_queue) qi.hashes.insert(qi.hashes.end(), h.begin(), h.end());
     return &qinfo.emplace(d, std::move(qi)).first->second;
   };
-  auto add_list = [&](u32 r, const u8* h, size_t k) {
-    if (k) { pool.insert(pool.end(), h, h + 32 * k); pool_rec.insert(pool_rec.end(), k, r); }
-  };
-  for (u32 r = 0; r < R; r++) {
+  // the queues of the documents named (rare; the map is only read from here on)
+  if (!b->queue.empty()) for (u32 r = 0; r < R; r++) if (!b->status[states[r].doc]) (void)queue_of(states[r].doc);
+  auto queue_info = [&](u32 d) -> const QInfo* { if (qinfo.empty()) return nullptr; auto it = qinfo.find(d); return it == qinfo.end() ? nullptr : &it->second; };
+  struct RecSize { u32 hashes, haves; u64 bloom_bytes; };
+  std::vector<RecSize> rs(R);
+  std::atomic<int> flat_err{0};   // 1 = invalid state, 2 = malformed filter
+  host_parallel_for(R, [&](u32 r) {
     const amh_sync_state& s = states[r];
-    if (s.doc >= b->B.n_docs || (s.n_shared_heads && !s.shared_heads32) || (s.n_last_sent_heads && !s.last_sent_heads32) ||
-        (s.n_their_heads && !s.their_heads32) || (s.n_their_need && !s.their_need32) || (s.n_their_have && !s.their_have) ||
-        (s.n_sent_hashes && !s.sent_hashes32)) { set_error(ctx, "amh_generate_sync_messages: invalid sync state"); return AMH_ERR_INVALID_ARG; }
+    if ((s.n_shared_heads && !s.shared_heads32) || (s.n_last_sent_heads && !s.last_sent_heads32) || (s.n_their_heads && !s.their_heads32) ||
+        (s.n_their_need && !s.their_need32) || (s.n_their_have && !s.their_have) || (s.n_sent_hashes && !s.sent_hashes32)) { flat_err = 1; rs[r] = {0, 0, 0}; return; }
+    const bool th = s.flags & AMH_SYNC_THEIR_HEADS, tn = s.flags & AMH_SYNC_THEIR_NEED, tv = s.flags & AMH_SYNC_THEIR_HAVE;
+    const QInfo* qi = b->status[s.doc] ? nullptr : queue_info(s.doc);
+    u64 nh = (u64)s.n_shared_heads + s.n_last_sent_heads + (th ? s.n_their_heads : 0) + (tn ? s.n_their_need : 0) + s.n_sent_hashes +
+             (qi ? qi->deps.size() / 32 + qi->hashes.size() / 32 : 0);
+    u64 bl = 0;
+    const u32 nv = tv ? (u32)std::min<size_t>(s.n_their_have, 0x7FFFFFFFu) : 0;
+    for (u32 k = 0; k < nv; k++) {
+      const amh_sync_have& h = s.their_have[k];
+      if ((h.n_last_sync && !h.last_sync32) || (h.bloom_len && !h.bloom)) { flat_err = 1; rs[r] = {0, 0, 0}; return; }
+      u32 e, pr, nb; size_t at;
+      if (!sm_parse_bloom(h.bloom, h.bloom_len, e, pr, at, nb)) { flat_err = 2; rs[r] = {0, 0, 0}; return; }
+      nh += h.n_last_sync; bl += nb;
+    }
+    rs[r] = {(u32)std::min<u64>(nh, 0xFFFFFFFFull), nv, bl};
+  }, 4096, 1024);
+  if (flat_err == 1) { set_error(ctx, "amh_generate_sync_messages: invalid sync state"); return AMH_ERR_INVALID_ARG; }
+  if (flat_err == 2) { set_error(ctx, "amh_generate_sync_messages: malformed Bloom filter in a Have"); return AMH_ERR_INVALID_ARG; }
+  std::vector<u64> pool_at(R + 1), bloom_at(R + 1);
+  {
+    u64 np = 0, nv = 0, nbl = 0;
+    for (u32 r = 0; r < R; r++) {
+      pool_at[r] = np; r_have[r] = (u32)nv; bloom_at[r] = nbl;
+      np += rs[r].hashes; nv += rs[r].haves; nbl += rs[r].bloom_bytes;
+      if (np >= 0x7FFFFFFFull || nv >= 0x7FFFFFFFull) { set_error(ctx, "amh_generate_sync_messages: too many hashes in one call"); return AMH_ERR_BATCH_TOO_LARGE; }
+      const amh_sync_state& s = states[r];
+      const bool th = s.flags & AMH_SYNC_THEIR_HEADS, tn = s.flags & AMH_SYNC_THEIR_NEED;
+      const QInfo* qi = b->status[s.doc] ? nullptr : queue_info(s.doc);
+      const u32 nc = doc_sizes[2 * (size_t)r], na = doc_sizes[2 * (size_t)r + 1];
+      r_flag_base[r] = n_flag; n_flag += nc;
+      r_clock_base[r] = n_clock; n_clock += na;
+      r_word_base[r] = n_word;
+      n_word += (u64)nc * 3 + (qi ? qi->deps.size() / 32 : 0) + (th ? s.n_their_heads : 0) + 2 * (u64)(tn ? s.n_their_need : 0);
+    }
+    pool_at[R] = np; r_have[R] = (u32)nv; bloom_at[R] = nbl;
+    pool.resize((size_t)np * 32); pool_rec.resize((size_t)np);
+    h_ls.resize(2 * (size_t)nv); h_entries.resize((size_t)nv); h_probes.resize((size_t)nv); h_nbytes.resize((size_t)nv); h_bits.resize((size_t)nv);
+    blooms.resize((size_t)nbl);
+  }
+  host_parallel_for(R, [&](u32 r) {
+    const amh_sync_state& s = states[r];
     r_doc[r] = s.doc;
     r_flags[r] = s.flags & 15u;
-    const bool th = s.flags & AMH_SYNC_THEIR_HEADS, tn = s.flags & AMH_SYNC_THEIR_NEED, tv = s.flags & AMH_SYNC_THEIR_HAVE;
-    const QInfo* qi = b->status[s.doc] ? nullptr : queue_of(s.doc);
+    const bool th = s.flags & AMH_SYNC_THEIR_HEADS, tn = s.flags & AMH_SYNC_THEIR_NEED;
+    const QInfo* qi = b->status[s.doc] ? nullptr : queue_info(s.doc);
+    u32 at = (u32)pool_at[r];
+    auto add_list = [&](const u8* h, size_t k) {
+      if (!k) return;
+      memcpy(pool.data() + (size_t)at * 32, h, 32 * k);
+      for (size_t i = 0; i < k; i++) pool_rec[at + i] = r;
+      at += (u32)k;
+    };
     u32* L = r_list.data() + (size_t)r * SM_LISTS;
-    L[SM_SHARED] = (u32)pool_rec.size(); add_list(r, s.shared_heads32, s.n_shared_heads);
-    L[SM_LAST_SENT] = (u32)pool_rec.size(); add_list(r, s.last_sent_heads32, s.n_last_sent_heads);
-    L[SM_THEIR_HEADS] = (u32)pool_rec.size(); if (th) add_list(r, s.their_heads32, s.n_their_heads);
-    L[SM_THEIR_NEED] = (u32)pool_rec.size(); if (tn) add_list(r, s.their_need32, s.n_their_need);
-    L[SM_SENT] = (u32)pool_rec.size(); add_list(r, s.sent_hashes32, s.n_sent_hashes);
-    L[SM_QDEPS] = (u32)pool_rec.size(); if (qi) add_list(r, qi->deps.data(), qi->deps.size() / 32);
-    L[SM_QHASH] = (u32)pool_rec.size(); if (qi) add_list(r, qi->hashes.data(), qi->hashes.size() / 32);
-    L[SM_LAST_SYNC] = (u32)pool_rec.size();
-    r_have[r] = (u32)h_entries.size();
-    for (size_t k = 0; tv && k < s.n_their_have; k++) {
+    L[SM_SHARED] = at; add_list(s.shared_heads32, s.n_shared_heads);
+    L[SM_LAST_SENT] = at; add_list(s.last_sent_heads32, s.n_last_sent_heads);
+    L[SM_THEIR_HEADS] = at; if (th) add_list(s.their_heads32, s.n_their_heads);
+    L[SM_THEIR_NEED] = at; if (tn) add_list(s.their_need32, s.n_their_need);
+    L[SM_SENT] = at; add_list(s.sent_hashes32, s.n_sent_hashes);
+    L[SM_QDEPS] = at; if (qi) add_list(qi->deps.data(), qi->deps.size() / 32);
+    L[SM_QHASH] = at; if (qi) add_list(qi->hashes.data(), qi->hashes.size() / 32);
+    L[SM_LAST_SYNC] = at;
+    u64 bits_at = bloom_at[r];
+    for (u32 k = 0, hv = r_have[r]; k < rs[r].haves; k++, hv++) {
       const amh_sync_have& h = s.their_have[k];
-      if ((h.n_last_sync && !h.last_sync32) || (h.bloom_len && !h.bloom)) { set_error(ctx, "amh_generate_sync_messages: invalid sync state"); return AMH_ERR_INVALID_ARG; }
-      h_ls.push_back((u32)pool_rec.size());
-      add_list(r, h.last_sync32, h.n_last_sync);
-      h_ls.push_back((u32)pool_rec.size());
-      u32 e, pr, nb; size_t at;
-      if (!sm_parse_bloom(h.bloom, h.bloom_len, e, pr, at, nb)) { set_error(ctx, "amh_generate_sync_messages: malformed Bloom filter in a Have"); return AMH_ERR_INVALID_ARG; }
-      h_entries.push_back(e); h_probes.push_back(pr); h_nbytes.push_back(nb); h_bits.push_back(blooms.size());
-      if (nb) blooms.insert(blooms.end(), h.bloom + at, h.bloom + at + nb);
+      h_ls[2 * (size_t)hv] = at;
+      add_list(h.last_sync32, h.n_last_sync);
+      h_ls[2 * (size_t)hv + 1] = at;
+      u32 e, pr, nb; size_t off;
+      sm_parse_bloom(h.bloom, h.bloom_len, e, pr, off, nb);   // (parsed in the first pass already: cannot fail here)
+      h_entries[hv] = e; h_probes[hv] = pr; h_nbytes[hv] = nb; h_bits[hv] = bits_at;
+      if (nb) memcpy(blooms.data() + bits_at, h.bloom + off, nb);
+      bits_at += nb;
     }
-    if (pool_rec.size() >= 0x7FFFFFFFull) { set_error(ctx, "amh_generate_sync_messages: too many hashes in one call"); return AMH_ERR_BATCH_TOO_LARGE; }
-    const u32 nc = doc_sizes[2 * (size_t)r], na = doc_sizes[2 * (size_t)r + 1];
-    r_flag_base[r] = n_flag; n_flag += nc;
-    r_clock_base[r] = n_clock; n_clock += na;
-    r_word_base[r] = n_word;
-    n_word += (u64)nc * 3 + (L[SM_QHASH] - L[SM_QDEPS]) + (L[SM_THEIR_NEED] - L[SM_THEIR_HEADS]) + 2 * (u64)(L[SM_SENT] - L[SM_THEIR_NEED]);
-  }
-  r_list[(size_t)R * SM_LISTS] = (u32)pool_rec.size();
-  r_have[R] = (u32)h_entries.size();
-  const u32 n_pool = (u32)pool_rec.size();
+  }, 4096, 1024);
+  r_list[(size_t)R * SM_LISTS] = (u32)pool_at[R];
+  const u32 n_pool = (u32)pool_at[R];
   pt.mark("states flattened (host)");
   // ---- one upload: the tables side by side in one device block, put together in pinned memory when they fit it ----
   struct Part { const void* p; size_t bytes; size_t at; };
