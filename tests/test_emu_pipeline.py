@@ -423,3 +423,30 @@ def test_merge_many_with_numpy_indices(emu):
     check_merge_many_numpy(emu, reps)
     from merge_cases import check_merge_of_a_merged_batch
     check_merge_of_a_merged_batch(emu, reps)
+
+
+def test_wide_merges_from_two_threads(emu):
+    """Enough documents per call for the host passes to run on the library's worker pool (>= 128 pairs), and two
+    contexts driven from two threads at once: the second caller finds the pool busy and runs its loops on threads of
+    its own.  Every merged document is compared with the oracle's."""
+    import threading
+    from merge_cases import check_merge_many, split_map_doc
+    blob, offs = emu.gen_map_docs(0x9001, 160, 4, 5, 24, 16, 2)
+    halves = [split_map_doc(bytes(blob[offs[i]:offs[i + 1]])) for i in range(160)]
+    reps = [[a for a, _ in halves], [b for _, b in halves], [bytes(blob[offs[i]:offs[i + 1]]) for i in range(160)]]
+    errors = []
+
+    def run(engine):
+        try:
+            for _ in range(2):
+                check_merge_many(engine, reps)
+        except BaseException as e:   # reported by the main thread
+            errors.append(e)
+
+    other = emu_engine()
+    threads = [threading.Thread(target=run, args=(e,)) for e in (emu, other)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
