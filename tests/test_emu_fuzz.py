@@ -15,3 +15,14 @@ def test_fuzzed_load_and_apply_stay_in_bounds(seed):
     subprocess.check_call(["make", "-s", "-C", _DIR, "fuzz_apply"])
     r = subprocess.run([os.path.join(_DIR, "fuzz_apply"), "700", str(seed)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_host_loops_are_race_free():
+    """tests/emu/pool_tsan.cpp under ThreadSanitizer: wide merge / apply / sync-message calls whose host passes run on
+    the library's worker pool, from one thread and from two threads with a context each.  Skipped where the sanitizer
+    cannot start (some kernels refuse its memory layout)."""
+    subprocess.check_call(["make", "-s", "-C", _DIR, "pool_tsan"])
+    r = subprocess.run([os.path.join(_DIR, "pool_tsan")], capture_output=True, text=True, timeout=900)
+    if "FATAL: ThreadSanitizer" in r.stderr:
+        pytest.skip("ThreadSanitizer cannot start here: " + r.stderr.strip().splitlines()[0])
+    assert r.returncode == 0 and "pool_tsan: 0 0 0" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr, (r.stdout[-2000:], r.stderr[-6000:])
